@@ -1,0 +1,181 @@
+/* libyat_hip.so -- C ABI of the MI355X (gfx950) kernels behind the SANA training-step hot path.
+ *
+ * The reference (frutiemax92/YAT) is pure Python and has no FFI layer; its hot path lands on
+ * third-party CUDA kernels through torch / diffusers calls.  Each entry point below replaces one
+ * of those call sites (cited as file:line under /root/reference).  A reference maintainer binds
+ * them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller (torch's ROCm allocator);
+ * bf16 tensors are raw uint16 storage; row-major with explicit leading dimensions in ELEMENTS;
+ * `stream` is a hipStream_t passed as void*; every call only enqueues work (no sync, no
+ * allocation, graph-capturable) and returns 0 on success, a negative yat error for bad arguments
+ * or a positive hipError_t from the launch.  The library keeps no global mutable state.
+ */
+#ifndef YAT_HIP_H
+#define YAT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* yat_stream_t; /* hipStream_t */
+
+int yat_version(void);
+
+/* ------------------------------------------------------------------------------------------ *
+ * GEMM family (MFMA bf16, fp32 accumulate)
+ * replaces: every nn.Linear / 1x1 Conv2d forward+backward in the SANA block
+ *   attn1/attn2 projections  utils/patch_sana_attention_layers.py:39-65,94,98-104
+ *   GLUMBConv 1x1 convs      utils/patch_sana_attention_layers.py:68,110-113
+ *   patch_embed / proj_out / caption / time-embed linears  utils/patched_sana_transformer.py:119-136,165,284-298,333
+ *   their autograd backward  common/trainer.py:344
+ * ------------------------------------------------------------------------------------------ */
+typedef struct yat_gemm_epilogue {
+    const void* bias;      /* bf16 [N] or NULL: v += bias[n]                                       */
+    void* aux_out;         /* bf16 [M, ld_aux] or NULL: stores the Linear output (pre-activation / */
+                           /* pre-gate), rounded to bf16, for the backward pass                     */
+    int activation;        /* 0 none, 1 SiLU, 2 GELU(tanh)                                         */
+    const void* gate;      /* bf16 [M/rows_per_batch, ld_gate] or NULL: v = gate[b, n] * v          */
+    const void* residual;  /* bf16 [M, ld_residual] or NULL: v += residual[m, n]  (may alias C)     */
+    int ld_aux, ld_gate, ld_residual, rows_per_batch;
+} yat_gemm_epilogue;
+
+/* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
+ * b_t=0: B is [N,K] (k contiguous, nn.Linear weight layout); b_t=1: B is [K,N].
+ * Supported: (0,0) forward y = x W^T; (0,1) dgrad dx = dy W; (1,1) wgrad dW = dy^T x.
+ * Epilogue order: +bias -> round bf16 -> aux_out -> activation -> *gate (rounded) -> +residual.  */
+int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                  void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream);
+
+/* out[c] (+)= sum_r x[r, c]  (bias gradients).  workspace: >= yat_colsum_workspace_bytes(rows, cols). */
+uint64_t yat_colsum_workspace_bytes(int rows, int cols);
+int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out_bf16, int accumulate, void* workspace,
+                    yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * adaLN-single modulation table  (patch_sana_attention_layers.py:85-87, SanaModulatedNorm)
+ *   mod[b, s, :] = bf16(table[s, :] + tmod[b, s*slot_stride : +D])      (slot_stride = D or 0)
+ * backward: dtable[s,:] = sum_b dmod[b,s,:];  dtmod_acc[b, s*slot_stride + d] += dmod[b,s,d]  (fp32)
+ * ------------------------------------------------------------------------------------------ */
+int yat_modulation_fwd(int B, int S, int D, const void* table, const void* tmod, int tmod_ld, int slot_stride,
+                       void* mod_out, yat_stream_t stream);
+int yat_modulation_bwd(int B, int S, int D, const float* dmod, void* dtable_bf16, int accumulate_table,
+                       float* dtmod_acc, int tmod_ld, int slot_stride, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * LayerNorm(no affine) + modulate   (patch_sana_attention_layers.py:38,90-92 and :53,107-108;
+ *                                    final norm patched_sana_transformer.py:163-164,331)
+ *   y = bf16( bf16( bf16(LN(x)) * bf16(1 + scale[b]) ) + shift[b] ),  stats in fp32
+ * shift/scale: bf16 [B, mod_ld] rows (pointers already offset to the slot); b = row / rows_per_batch.
+ * bwd: dx = (dres?) + LN'(dy * (1+scale));  dshift_acc[b,:] += sum_n dy;  dscale_acc[b,:] += sum_n dy * xhat
+ *      (fp32 accumulators with leading dimension acc_ld).
+ * ------------------------------------------------------------------------------------------ */
+uint64_t yat_ln_bwd_workspace_bytes(int M, int D, int rows_per_batch);
+int yat_ln_modulate_fwd(int M, int D, int rows_per_batch, float eps, const void* x, const void* shift,
+                        const void* scale, int mod_ld, void* y, float* mean, float* rstd, yat_stream_t stream);
+int yat_ln_modulate_bwd(int M, int D, int rows_per_batch, const void* x, const float* mean, const float* rstd,
+                        const void* scale, int mod_ld, const void* dy, const void* dres, void* dx,
+                        float* dshift_acc, float* dscale_acc, int acc_ld, void* workspace, yat_stream_t stream);
+
+/* RMSNorm with affine weight, eps inside the sqrt (caption_norm, patched_sana_transformer.py:136,298)
+ *   y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * w ).   bwd: dx, dw (bf16, optional accumulate). */
+uint64_t yat_rmsnorm_bwd_workspace_bytes(int M, int D);
+int yat_rmsnorm_fwd(int M, int D, float eps, const void* x, const void* w, void* y, float* rstd, yat_stream_t stream);
+int yat_rmsnorm_bwd(int M, int D, const void* x, const void* w, const float* rstd, const void* dy, void* dx,
+                    void* dw_bf16, int accumulate_dw, void* workspace, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * ReLU linear attention (SanaLinearAttnProcessor2_0, imported patch_sana_attention_layers.py:7)
+ * qkv: bf16 [B*N, ld] with q at column 0, k at column k_off, v at column v_off, heads of dim 32
+ * laid out head-major inside each of q/k/v.  out: bf16 [B*N, ld_out].  fp32 math throughout:
+ *   S = [V;1] relu(K),  O = S relu(Q),  out = O[:32] / (O[32] + 1e-15)
+ * ------------------------------------------------------------------------------------------ */
+uint64_t yat_linear_attn_workspace_bytes(int B, int N, int H);
+int yat_linear_attn_fwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, void* out, int ld_out,
+                        void* workspace, yat_stream_t stream);
+int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, const void* dout,
+                        int ld_dout, void* dqkv, int ld_dqkv, void* workspace, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Masked softmax cross-attention (attn2 = AttnProcessor2_0 / F.scaled_dot_product_attention,
+ * patch_sana_attention_layers.py:54-65,98-104; mask->bias patched_sana_transformer.py:275-277)
+ *   q: bf16 [B*N, ldq] (head h at col h*dh), k,v: bf16 [B*T, ldkv]; key_bias: float [B, T]
+ *   (0 keep / -10000 drop); kv_len[b] = 1 + last kept key (tiles past it are skipped -- exact,
+ *   their probabilities underflow to 0 -- unless kv_len[b]==0, then all T keys are used).
+ *   out: bf16 [B*N, ldo]; lse: float [B, H, N] (natural log).  dh <= 128, dh % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                 int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream);
+int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                 int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
+                 const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * GLUMBConv middle: SiLU -> depthwise 3x3 (pad 1, bias) -> chunk2 -> a * SiLU(g)
+ * (diffusers GLUMBConv called at patch_sana_attention_layers.py:110-113), on the token-major
+ * layout z[B, h, w, 2*Hc] (no NCHW round trip).  z is the conv_inverted output (pre-SiLU).
+ *   y[b,i,j,c] = u_c * silu(u_{c+Hc}),  u = bias + sum_taps wdw[c, tap] * silu(z[b,i+di,j+dj,c])
+ * wdw: bf16 [2*Hc, 9] (diffusers conv_depth.weight [2Hc,1,3,3] flattened), bdw: bf16 [2*Hc].
+ * bwd: dz (bf16, includes the SiLU derivative), dwdw / dbdw partial sums reduced via workspace.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc);
+int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* z, const void* wdw, const void* bdw, void* y,
+                       yat_stream_t stream);
+int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* z, const void* wdw, const void* bdw, const void* dy,
+                       void* dz, void* dwdw_bf16, void* dbdw_bf16, int accumulate, void* workspace, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * gated residual backward: out = res + bf16(gate[b,:] * lin)   (patch_sana_attention_layers.py:95,113)
+ *   dlin = bf16(gate * dout);  dgate_acc[b,:] += sum_n dout * lin   (fp32)
+ * ------------------------------------------------------------------------------------------ */
+uint64_t yat_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
+int yat_gate_bwd(int M, int D, int rows_per_batch, const void* dout, const void* lin, const void* gate, int gate_ld,
+                 void* dlin, float* dgate_acc, int acc_ld, void* workspace, yat_stream_t stream);
+
+/* elementwise helpers: y = act(x) and dx = dy * act'(x) on bf16 (time-embed / caption MLPs);
+ * act: 1 SiLU, 2 GELU(tanh).  add: out = bf16(a + b).  f32->bf16 convert. */
+int yat_act_fwd(int64_t n, int act, const void* x, void* y, yat_stream_t stream);
+int yat_act_bwd(int64_t n, int act, const void* x, const void* dy, void* dx, yat_stream_t stream);
+int yat_add_bf16(int64_t n, const void* a, const void* b, void* out, yat_stream_t stream);
+int yat_f32_to_bf16(int64_t n, const float* x, void* y, yat_stream_t stream);
+
+/* sinusoidal timestep projection (diffusers get_timestep_embedding(t,256,flip_sin_to_cos=True),
+ * used via AdaLayerNormSingle at patched_sana_transformer.py:133,291-293): out bf16 [B, dim],
+ * cos half first. */
+int yat_timestep_embed_fwd(int B, int dim, const float* t, void* out, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * recipe ops (train_sana.py:168-180, 206-207, 217-218)
+ * ------------------------------------------------------------------------------------------ */
+/* ragged text embeddings -> padded [B, T, C] bf16 + int64 mask + float key bias + kv_len.
+ * src: bf16 concatenation of the B [L_i, C] matrices; offsets: int32 [B+1] row offsets. */
+int yat_pad_mask(int B, int T, int C, const void* src, const int* offsets, void* dst, int64_t* mask, float* key_bias,
+                 int* kv_len, yat_stream_t stream);
+/* noisy = bf16(bf16((1-s)*x) + bf16(s*n)), target = bf16(n - x); sigma: bf16 [B] */
+int yat_flow_mix(int B, int64_t per_sample, const void* x, const void* noise, const void* sigma, void* noisy,
+                 void* target, yat_stream_t stream);
+/* loss = mean((pred - target)^2) in fp32 (written to loss[0]); dpred = bf16(2 (pred-target) * gscale / n) */
+int yat_mse_fwd_bwd(int64_t n, const void* pred, const void* target, float gscale, float* loss, void* dpred,
+                    float* workspace_256, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * optimizer (common/trainer.py:246-248,347-348,356 = torch clip_grad_norm_ + torch.optim.AdamW on
+ * bf16 params with bf16 states), over ONE flat parameter buffer.
+ *   seg_start: int64 [nseg+1] element offsets of each parameter tensor (16-B aligned starts).
+ *   gradnorm: per-tensor bf16-rounded L2 norms -> total (bf16-rounded, as torch does on bf16 grads)
+ *             -> clip_coef[0] = min(1, bf16(max_norm / (total + 1e-6))); norm_out[0] = total.
+ *   adamw: torch's single-tensor op sequence with a bf16 rounding after every op; grads are
+ *          multiplied by clip_coef first (rounded to bf16) when clip_coef != NULL; zero_grad
+ *          clears the gradient buffer in the same pass.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t yat_gradnorm_workspace_bytes(int64_t n, int nseg);
+int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_start, float max_norm, float* norm_out,
+                      float* clip_coef, void* workspace, yat_stream_t stream);
+int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_avg_sq, const float* clip_coef,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int step, int zero_grad,
+                   void* ema_shadow, double ema_decay, yat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAT_HIP_H */

@@ -1,0 +1,70 @@
+"""C-ABI checks that need no GPU: the library builds, loads, exports every symbol that
+include/yat_hip.h declares, and the ctypes binding agrees with the header's parameter lists."""
+import ctypes as C
+import os
+import re
+
+from yat_amd import lib as ylib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "yat_hip.h")
+
+_CT = {
+    "int": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float, "double": C.c_double,
+}
+
+
+def _parse_header():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|uint64_t)\s+(yat_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+        types = []
+        for p in plist:
+            if "*" in p or "yat_stream_t" in p:
+                types.append("ptr")
+            else:
+                base = p.replace("const", "").split()[0]
+                types.append(base)
+        decls[name] = (ret, types)
+    return decls
+
+
+def test_header_declares_what_we_bind():
+    decls = _parse_header()
+    assert set(decls) == set(ylib.SIGNATURES), set(decls) ^ set(ylib.SIGNATURES)
+    for name, (ret, types) in decls.items():
+        res, args = ylib.SIGNATURES[name]
+        assert res is _CT[ret], name
+        assert len(args) == len(types), (name, len(args), len(types))
+        for i, (a, t) in enumerate(zip(args, types)):
+            if t == "ptr":
+                assert a is C.c_void_p or issubclass(a, C._Pointer), (name, i, a)
+            else:
+                assert a is _CT[t], (name, i, a, t)
+
+
+def test_library_loads_and_exports_every_symbol(built_lib):
+    lib = ylib.load()
+    assert lib.yat_version() >= 1
+    for name in _parse_header():
+        assert hasattr(lib, name), name
+
+
+def test_workspace_queries_are_pure_host_code(built_lib):
+    lib = ylib.load()
+    assert lib.yat_colsum_workspace_bytes(8192, 11200) > 0
+    assert lib.yat_ln_bwd_workspace_bytes(8192, 2240, 1024) == 8 * 32 * 4 * 2 * 2240 * 4
+    assert lib.yat_linear_attn_workspace_bytes(8, 1024, 70) == 8 * 70 * 33 * 32 * 4 * (2 + 4)
+    assert lib.yat_gradnorm_workspace_bytes(1 << 20, 7) == 7 * 4 * 4
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(built_lib):
+    lib = ylib.load()
+    # argument validation happens before any launch, so it is testable on the CPU box
+    assert lib.yat_gemm_bf16(0, 0, 0, 8, 8, None, 8, None, 8, None, 8, None, None) == -1
+    assert lib.yat_gemm_bf16(1, 0, 8, 8, 8, 1, 8, 1, 8, 1, 8, None, None) == -1   # TT layout unsupported
+    assert lib.yat_adamw_step(7, 1, 1, 1, 1, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1, None, 0.0, None) == -1
+    assert lib.yat_ln_modulate_fwd(4, 7, 4, 1e-6, 1, 1, 1, 8, 1, 1, 1, None) == -1     # D % 8 != 0

@@ -1,0 +1,422 @@
+"""Per-kernel parity tests (GPU): every C-ABI entry point against a plain PyTorch fp32 restatement of
+the same op on the same bf16 inputs, rounded to bf16 where the reference's dtype flow rounds.
+
+Tolerance (stated once): bf16 has 8 significant bits (ulp = 2^-8 relative).  Both sides round
+their fp32 result to bf16, so they may differ by one bf16 ulp wherever the fp32 values straddle a
+rounding boundary (different accumulation order).  We therefore require
+    relative L2 error <= 2e-3   and   max |a-b| <= 2 bf16 ulps of the local magnitude (+ tiny abs),
+and bit-exactness for integer outputs (mask, kv_len).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from yat_amd import ops as o
+    o._lib()
+    return o
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def close(a, b, name, tol=2e-3, ulps=2.0, atol=1e-6):
+    a, b = a.float(), b.float()
+    assert torch.isfinite(a).all(), f"{name}: non-finite output"
+    r = rel(a, b)
+    bound = ulps * 2.0 ** -8 * b.abs() + atol + 1e-3 * b.abs().mean()
+    worst = ((a - b).abs() - bound).max().item()
+    print(f"[parity] {name}: rel_l2={r:.3e} max_abs={(a - b).abs().max().item():.3e}")
+    assert r <= tol, f"{name}: rel l2 {r:.3e} > {tol}"
+    assert worst <= 0, f"{name}: element error exceeds {ulps} bf16 ulps by {worst:.3e}"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
+
+
+def rb(x):
+    return x.to(BF).float()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 96), (333, 264, 160), (1024, 2240, 5600), (64, 32, 256)])
+def test_gemm_nt_plain(ops, M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    y = ops.linear_fwd(x, w)
+    close(y, (x.float() @ w.float().T).to(BF), f"gemm_nt {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 96), (1000, 2240, 160)])
+def test_gemm_nn_dgrad(ops, M, N, K):
+    dy, w = rnd(M, N, seed=3), rnd(N, K, scale=N ** -0.5, seed=4)
+    dx = ops.linear_dgrad(dy, w)
+    close(dx, (dy.float() @ w.float()).to(BF), f"gemm_nn {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 96), (1056, 264, 2240), (1000, 96, 32)])
+def test_gemm_tn_wgrad(ops, M, N, K):
+    dy, x = rnd(M, N, scale=M ** -0.5, seed=5), rnd(M, K, seed=6)
+    dw = torch.empty(N, K, dtype=BF, device=DEV)
+    ops.linear_wgrad(dy, x, dw)
+    ref = (dy.float().T @ x.float())
+    close(dw, ref.to(BF), f"gemm_tn {M}x{N}x{K}")
+    ops.linear_wgrad(dy, x, dw, accumulate=True)          # grad accumulation: dw += dy^T x
+    close(dw, (rb(ref) + rb(ref)).to(BF), f"gemm_tn_acc {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric B catches a transposed C-write or a swapped fragment map."""
+    n = 128
+    eye = torch.eye(n, dtype=BF, device=DEV)
+    b = (torch.arange(n * n, device=DEV).reshape(n, n) % 251).to(BF)      # exact small integers
+    y = ops.linear_fwd(eye, b)                      # I @ b^T
+    assert torch.equal(y, b.T.contiguous())
+    y = ops.linear_dgrad(eye, b)                    # I @ b
+    assert torch.equal(y, b)
+    dw = torch.empty(n, n, dtype=BF, device=DEV)
+    ops.linear_wgrad(eye, b, dw)                    # I^T @ b
+    assert torch.equal(dw, b)
+    ops.linear_wgrad(b, eye, dw)                    # b^T @ I
+    assert torch.equal(dw, b.T.contiguous())
+
+
+@pytest.mark.parametrize("act", ["silu", "gelu_tanh"])
+def test_gemm_epilogue_bias_act(ops, act):
+    M, N, K = 264, 200, 96
+    x, w, b = rnd(M, K, seed=7), rnd(N, K, scale=K ** -0.5, seed=8), rnd(N, seed=9)
+    z = torch.empty(M, N, dtype=BF, device=DEV)
+    y = ops.linear_fwd(x, w, bias=b, activation=act, aux_out=z)
+    zr = rb(x.float() @ w.float().T + b.float())
+    close(z, zr, f"epi_{act}_preact")
+    yr = F.silu(zr) if act == "silu" else F.gelu(zr, approximate="tanh")
+    close(y, yr.to(BF), f"epi_{act}_out")
+
+
+def test_gemm_epilogue_gate_residual(ops):
+    B, n, D, K = 3, 88, 136, 64
+    M = B * n
+    x, w, b = rnd(M, K, seed=10), rnd(D, K, scale=K ** -0.5, seed=11), rnd(D, seed=12)
+    mod = rnd(B, 6, D, seed=13)
+    res = rnd(M, D, seed=14)
+    lin = torch.empty(M, D, dtype=BF, device=DEV)
+    gate = mod[:, 2]
+    out = ops.linear_fwd(x, w, bias=b, aux_out=lin, gate=gate, ld_gate=6 * D, residual=res, rows_per_batch=n)
+    linr = rb(x.float() @ w.float().T + b.float())
+    close(lin, linr, "epi_gate_lin")
+    g = gate.float().repeat_interleave(n, 0)
+    close(out, (res.float() + rb(g * linr)).to(BF), "epi_gate_out")
+    out2 = ops.linear_fwd(x, w, bias=b, residual=res)       # cross-attention: ungated residual
+    close(out2, (res.float() + linr).to(BF), "epi_residual_out")
+
+
+def test_colsum(ops):
+    rows, cols = 1000, 264
+    x = rnd(rows, cols, seed=15)
+    ws = torch.empty(int(ops._lib().yat_colsum_workspace_bytes(rows, cols)), dtype=torch.uint8, device=DEV)
+    out = torch.zeros(cols, dtype=BF, device=DEV)
+    ops.colsum(x, out, ws)
+    close(out, x.float().sum(0).to(BF), "colsum")
+    ops.colsum(x, out, ws, accumulate=True)
+    close(out, (2 * rb(x.float().sum(0))).to(BF), "colsum_acc")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def _ln_ref(x, shift, scale, eps, n):
+    xf = x.float()
+    xh = rb(F.layer_norm(xf, (xf.shape[-1],), None, None, eps))
+    sc = rb(1 + scale.float()).repeat_interleave(n, 0)
+    sh = shift.float().repeat_interleave(n, 0)
+    return rb(rb(xh * sc) + sh)
+
+
+@pytest.mark.parametrize("B,n,D", [(2, 16, 64), (3, 41, 2240), (2, 33, 1152), (1, 7, 4096)])
+def test_ln_modulate_fwd_bwd(ops, B, n, D):
+    M = B * n
+    x = rnd(M, D, scale=2.0, seed=20) + 0.5
+    mod = rnd(B, 6, D, scale=0.3, seed=21)
+    shift, scale = mod[:, 3], mod[:, 4]
+    y, mean, rstd = ops.ln_modulate_fwd(x, shift, scale, 6 * D, n, 1e-6)
+    close(y, _ln_ref(x, shift, scale, 1e-6, n), f"ln_fwd D={D}")
+    # backward vs autograd of the fp32 formula
+    xr = x.float().requires_grad_(True)
+    scr = scale.float().requires_grad_(True)
+    shr = shift.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), None, None, 1e-6) * (1 + scr).repeat_interleave(n, 0) + shr.repeat_interleave(n, 0)
+    dy = rnd(M, D, seed=22)
+    dres = rnd(M, D, seed=23)
+    yr.backward(dy.float())
+    dx = torch.empty_like(x)
+    acc = torch.zeros(B, 6, D, dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.ln_bwd_workspace_bytes(M, D, n), dtype=torch.uint8, device=DEV)
+    ops.ln_modulate_bwd(x, mean, rstd, scale, 6 * D, n, dy, dres, dx, acc[:, 3], acc[:, 4], 6 * D, ws)
+    close(dx, (xr.grad + dres.float()).to(BF), f"ln_bwd_dx D={D}", tol=4e-3, ulps=3)
+    close(acc[:, 3], shr.grad, f"ln_bwd_dshift D={D}", tol=4e-3, ulps=4, atol=1e-3)
+    close(acc[:, 4], scr.grad, f"ln_bwd_dscale D={D}", tol=8e-3, ulps=6, atol=5e-2)
+    assert acc[:, [0, 1, 2, 5]].abs().max().item() == 0.0
+
+
+def test_rmsnorm_fwd_bwd(ops):
+    M, D = 300, 2240
+    x, w = rnd(M, D, scale=1.5, seed=24), (1 + 0.1 * torch.randn(D)).to(BF).to(DEV)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+    xf = x.float()
+    r = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
+    close(y, (rb(xf * r) * w.float()).to(BF), "rmsnorm_fwd")
+    xr, wr = xf.clone().requires_grad_(True), w.float().clone().requires_grad_(True)
+    (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * wr).backward(rnd(M, D, seed=25).float())
+    dy = rnd(M, D, seed=25)
+    dx, dw = torch.empty_like(x), torch.empty_like(w)
+    ws = torch.empty(int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(M, D)), dtype=torch.uint8, device=DEV)
+    ops.rmsnorm_bwd(x, w, rstd, dy, dx, dw, ws)
+    close(dx, xr.grad.to(BF), "rmsnorm_bwd_dx", tol=4e-3, ulps=3)
+    close(dw, wr.grad.to(BF), "rmsnorm_bwd_dw", tol=4e-3, ulps=3, atol=2e-2)
+
+
+def test_modulation_fwd_bwd(ops):
+    B, S, D = 3, 6, 136
+    table, tmod = rnd(S, D, seed=26), rnd(B, S * D, seed=27)
+    mod = ops.modulation_fwd(table, tmod, D)
+    close(mod, (table.float()[None] + tmod.float().view(B, S, D)).to(BF), "modulation_fwd")
+    emb = rnd(B, D, seed=28)
+    mod2 = ops.modulation_fwd(table[:2].contiguous(), emb, 0)
+    close(mod2, (table[:2].float()[None] + emb.float()[:, None]).to(BF), "modulation_fwd_shared")
+    dmod = torch.randn(B, S, D, device=DEV)
+    dtab = torch.empty(S, D, dtype=BF, device=DEV)
+    dt = torch.zeros(B, S * D, device=DEV)
+    ops.modulation_bwd(dmod, dtab, dt, D)
+    close(dtab, rb(dmod).sum(0).to(BF), "modulation_bwd_table")
+    close(dt, rb(dmod).view(B, S * D), "modulation_bwd_tmod")
+    dt2 = torch.zeros(B, D, device=DEV)
+    ops.modulation_bwd(dmod[:, :2].contiguous(), dtab[:2], dt2, 0)
+    close(dt2, rb(dmod[:, :2]).sum(1), "modulation_bwd_shared")
+
+
+def test_gate_bwd(ops):
+    B, n, D = 3, 150, 264
+    M = B * n
+    dout, lin, mod = rnd(M, D, seed=29), rnd(M, D, seed=30), rnd(B, 6, D, seed=31)
+    gate = mod[:, 5]
+    dlin = torch.empty(M, D, dtype=BF, device=DEV)
+    acc = torch.zeros(B, 6, D, device=DEV)
+    ws = torch.empty(int(ops._lib().yat_gate_bwd_workspace_bytes(M, D, n)), dtype=torch.uint8, device=DEV)
+    ops.gate_bwd(dout, lin, gate, 6 * D, n, dlin, acc[:, 5], 6 * D, ws)
+    close(dlin, (gate.float().repeat_interleave(n, 0) * dout.float()).to(BF), "gate_bwd_dlin")
+    close(acc[:, 5], rb(dout.float() * lin.float()).view(B, n, D).sum(1), "gate_bwd_dgate", atol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _linattn_ref(qkv, B, N, H):
+    D = H * 32
+    q, k, v = qkv.float().view(B, N, 3, H, 32).permute(2, 0, 3, 1, 4)      # [B,H,N,32]
+    q, k = F.relu(q), F.relu(k)
+    v1 = F.pad(v, (0, 1), value=1.0)                                        # [B,H,N,33]
+    S = v1.transpose(-1, -2) @ k                                            # [B,H,33,32]
+    U = q @ S.transpose(-1, -2)                                             # [B,H,N,33]
+    o = U[..., :32] / (U[..., 32:] + 1e-15)
+    return o.permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 16, 2), (2, 300, 3), (1, 1024, 5)])
+def test_linear_attn_fwd_bwd(ops, B, N, H):
+    D = H * 32
+    qkv = rnd(B * N, 3 * D, seed=32)
+    ws = torch.empty(ops.linear_attn_workspace_bytes(B, N, H), dtype=torch.uint8, device=DEV)
+    out = torch.empty(B * N, D, dtype=BF, device=DEV)
+    ops.linear_attn_fwd(qkv, B, N, H, D, 2 * D, out, ws)
+    qr = qkv.float().requires_grad_(True)
+    ref = _linattn_ref(qr, B, N, H)
+    close(out, ref.to(BF), f"linattn_fwd N={N}")
+    dout = rnd(B * N, D, seed=33)
+    ref.backward(dout.float())
+    dqkv = torch.empty_like(qkv)
+    ops.linear_attn_bwd(qkv, B, N, H, D, 2 * D, dout, dqkv, ws)
+    close(dqkv, qr.grad.to(BF), f"linattn_bwd N={N}", tol=4e-3, ulps=3, atol=1e-4)
+
+
+def _sdpa_ref(q, k, v, bias, B, N, T, H, dh, scale):
+    qf = q.float().view(B, N, H, dh).transpose(1, 2)
+    kf = k.float().view(B, T, H, dh).transpose(1, 2)
+    vf = v.float().view(B, T, H, dh).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * scale + bias[:, None, None, :]
+    p = torch.softmax(s, -1)
+    return (p @ vf).transpose(1, 2).reshape(B * N, H * dh), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,T,H,dh,lens", [(2, 64, 64, 1, 32, [64, 20]), (2, 100, 128, 2, 112, [77, 128]),
+                                             (3, 130, 512, 2, 112, [300, 5, 0]), (1, 48, 40, 3, 64, [33])])
+def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
+    D = H * dh
+    scale = 1.0 / math.sqrt(dh)
+    q = rnd(B * N, D, seed=34)
+    kv = rnd(B * T, 2 * D, seed=35)
+    k, v = kv[:, :D], kv[:, D:]
+    mask = torch.zeros(B, T)
+    for b, L in enumerate(lens):
+        mask[b, :L] = 1
+    bias = rb((1 - mask.to(BF).float()) * -10000.0).to(DEV)
+    kvlen = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    out = torch.empty(B * N, D, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=DEV)
+    ops.sdpa_fwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, lse)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k.contiguous(), v.contiguous()))
+    ref, lse_ref = _sdpa_ref(qr, kr, vr, bias, B, N, T, H, dh, scale)
+    close(out, ref.to(BF), f"sdpa_fwd T={T} dh={dh}")
+    close(lse, lse_ref, f"sdpa_lse T={T}", tol=1e-4, ulps=0.01, atol=1e-3)
+    dout = rnd(B * N, D, seed=36)
+    ref.backward(dout.float())
+    dq = torch.empty_like(q)
+    dkv = torch.full_like(kv, float("nan"))
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=DEV)
+    ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:])
+    close(dq, qr.grad.to(BF), f"sdpa_dq T={T}", tol=6e-3, ulps=4, atol=1e-4)
+    close(dkv[:, :D], kr.grad.to(BF), f"sdpa_dk T={T}", tol=6e-3, ulps=4, atol=1e-4)
+    close(dkv[:, D:], vr.grad.to(BF), f"sdpa_dv T={T}", tol=6e-3, ulps=4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ GLUMBConv middle
+def _glu_ref(z, wdw, bdw, B, h, w, Hc):
+    zi = z.float().view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
+    s = rb(F.silu(zi))
+    u = rb(F.conv2d(s, wdw.float().view(2 * Hc, 1, 3, 3), bdw.float(), padding=1, groups=2 * Hc))
+    a, g = u.chunk(2, 1)
+    y = a * rb(F.silu(g))
+    return y.permute(0, 2, 3, 1).reshape(B * h * w, Hc)
+
+
+@pytest.mark.parametrize("B,h,w,Hc", [(2, 4, 4, 16), (2, 5, 9, 40), (1, 16, 64, 160), (2, 33, 3, 8)])
+def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
+    M = B * h * w
+    z = rnd(M, 2 * Hc, seed=37)
+    wdw, bdw = rnd(2 * Hc, 9, scale=1 / 3, seed=38), rnd(2 * Hc, scale=0.1, seed=39)
+    y = torch.empty(M, Hc, dtype=BF, device=DEV)
+    ops.dwconv_glu_fwd(z, B, h, w, Hc, wdw, bdw, y)
+    close(y, _glu_ref(z, wdw, bdw, B, h, w, Hc).to(BF), f"dwconv_fwd {h}x{w}x{Hc}")
+    # backward against autograd of the un-rounded fp32 formula
+    zr, wr, br = z.float().requires_grad_(True), wdw.float().requires_grad_(True), bdw.float().requires_grad_(True)
+    zi = zr.view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
+    u = F.conv2d(F.silu(zi), wr.view(2 * Hc, 1, 3, 3), br, padding=1, groups=2 * Hc)
+    a, g = u.chunk(2, 1)
+    yr = (a * F.silu(g)).permute(0, 2, 3, 1).reshape(M, Hc)
+    dy = rnd(M, Hc, seed=40)
+    yr.backward(dy.float())
+    dz, dw, db = torch.empty_like(z), torch.empty_like(wdw), torch.empty_like(bdw)
+    ws = torch.empty(ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc), dtype=torch.uint8, device=DEV)
+    ops.dwconv_glu_bwd(z, B, h, w, Hc, wdw, bdw, dy, dz, dw, db, ws)
+    close(dz, zr.grad.to(BF), f"dwconv_dz {h}x{w}x{Hc}", tol=8e-3, ulps=4, atol=1e-3)
+    close(dw, wr.grad.to(BF), f"dwconv_dw {h}x{w}x{Hc}", tol=8e-3, ulps=4, atol=3e-2)
+    close(db, br.grad.to(BF), f"dwconv_db {h}x{w}x{Hc}", tol=8e-3, ulps=4, atol=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise / recipe
+def test_elementwise(ops):
+    x, dy = rnd(1000, 37, seed=41), rnd(1000, 37, seed=42)      # numel not a multiple of 8 -> scalar tail
+    for act, f in (("silu", F.silu), ("gelu_tanh", lambda t: F.gelu(t, approximate="tanh"))):
+        close(ops.act_fwd(x, act), f(x.float()).to(BF), f"act_fwd_{act}")
+        xr = x.float().requires_grad_(True)
+        f(xr).backward(dy.float())
+        close(ops.act_bwd(x, dy, act), xr.grad.to(BF), f"act_bwd_{act}", atol=1e-4)
+    close(ops.add_bf16(x, dy), (x.float() + dy.float()).to(BF), "add")
+    f32 = torch.randn(999, device=DEV)
+    assert torch.equal(ops.f32_to_bf16(f32), f32.to(BF))
+
+
+def test_timestep_embed(ops):
+    t = torch.tensor([2.9940121, 957.3083, 510.554, 1000.0, 0.0], device=DEV)
+    out = ops.timestep_embed(t, 256)
+    half = 128
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=DEV) / half)
+    arg = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1).to(BF)
+    close(out, ref, "timestep_embed", tol=3e-3, ulps=2, atol=2e-3)
+
+
+def test_pad_mask(ops):
+    B, T, Cd = 4, 32, 96
+    lens = [5, 32, 1, 17]
+    embs = [rnd(L, Cd, seed=50 + i) for i, L in enumerate(lens)]
+    src = torch.cat(embs)
+    offs = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    dst = torch.full((B, T, Cd), 7.0, dtype=BF, device=DEV)
+    mask = torch.full((B, T), -1, dtype=torch.int64, device=DEV)
+    bias = torch.full((B, T), 3.0, device=DEV)
+    kvl = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.pad_mask(src, offs, B, T, Cd, dst, mask, bias, kvl)
+    for b, (L, e) in enumerate(zip(lens, embs)):
+        assert torch.equal(dst[b, :L], e)
+        if L < T:
+            assert dst[b, L:].abs().max().item() == 0
+            assert (bias[b, L:] == -9984.0).all()
+        assert mask[b].tolist() == [1] * L + [0] * (T - L)
+        assert bias[b, :L].abs().max().item() == 0
+    assert kvl.tolist() == lens
+
+
+def test_flow_mix_and_mse(ops):
+    B, per = 4, 8 * 5 * 7
+    x, n = rnd(B, per, scale=0.5, seed=60), rnd(B, per, seed=61)
+    sig = torch.tensor([0.957, 0.5117, 1.0, 0.003], dtype=BF, device=DEV)
+    noisy, target = ops.flow_mix(x, n, sig)
+    s = sig.float()[:, None]
+    ref = rb(rb(rb(1.0 - s) * x.float()) + rb(s * n.float()))
+    assert torch.equal(noisy.float(), ref)
+    assert torch.equal(target.float(), rb(n.float() - x.float()))
+    pred = rnd(B, per, seed=62)
+    loss = torch.zeros(1, device=DEV)
+    dpred = torch.empty_like(pred)
+    ws = torch.empty(256, device=DEV)
+    ops.mse_fwd_bwd(pred, target, loss, dpred, ws)
+    d = pred.float() - target.float()
+    assert abs(loss.item() - d.pow(2).mean().item()) <= 1e-5 * d.pow(2).mean().item()
+    close(dpred, (2 * d / d.numel()).to(BF), "mse_dpred", atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_clip_and_adamw_match_torch_cpu(ops):
+    """The optimizer oracle is the reference's own dependency: torch.nn.utils.clip_grad_norm_ +
+    torch.optim.AdamW on bf16 CPU tensors (common/trainer.py:246-248,347-348)."""
+    shapes = [(64, 40), (40,), (3, 3, 8), (1000,), (8,)]
+    g = torch.Generator().manual_seed(7)
+    params = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(BF)) for s in shapes]
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.01)
+    # flat device copies, 16-B aligned segment starts
+    starts, off = [], 0
+    for p in params:
+        starts.append(off)
+        off += (p.numel() + 7) // 8 * 8
+    n = off
+    flat = {k: torch.zeros(n, dtype=BF, device=DEV) for k in ("p", "g", "m", "v")}
+    seg = torch.tensor(starts + [n], dtype=torch.int64, device=DEV)
+    for p, s in zip(params, starts):
+        flat["p"][s:s + p.numel()] = p.data.flatten().to(DEV)
+    ws = torch.empty(ops.gradnorm_workspace_bytes(n, len(params)), dtype=torch.uint8, device=DEV)
+    norm, coef = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    for step in range(1, 4):
+        for p, s in zip(params, starts):
+            p.grad = (torch.randn(p.shape, generator=g) * (3.0 if step == 1 else 0.02)).to(BF)
+            flat["g"][s:s + p.numel()] = p.grad.flatten().to(DEV)
+        total = torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        opt.step()
+        ops.gradnorm_clip(flat["g"], seg, 1.0, norm, coef, ws)
+        ops.adamw_step(flat["p"], flat["g"], flat["m"], flat["v"], coef, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+        assert abs(norm.item() - total.float().item()) <= 2 ** -7 * total.float().item(), (norm.item(), total)
+        bad = 0
+        for p, s in zip(params, starts):
+            mine = flat["p"][s:s + p.numel()].cpu().view(p.shape)
+            bad += (mine != p.data).sum().item()
+            close(mine, p.data, f"adamw_step{step}", tol=1e-3, ulps=1)
+        print(f"[parity] adamw step {step}: {bad} / {n} params differ bitwise from torch CPU")
+        assert bad <= 0.002 * n
+        assert flat["g"].abs().max().item() == 0.0     # zero_grad fused

@@ -1,0 +1,236 @@
+// bf16 MFMA GEMM family for gfx950 with fused epilogues.
+//
+//   C[M,N] = epilogue( A_op[M,K] * B_op[K,N] ),   fp32 accumulate, bf16 in/out
+//
+// Three operand layouts cover forward, dgrad and wgrad of every Linear / 1x1-conv in the SANA
+// block (reference call sites: utils/patch_sana_attention_layers.py:94-113 via diffusers
+// Attention/GLUMBConv; autograd backward at common/trainer.py:344):
+//   NT  (a_t=0,b_t=0)  A[M,K] k-contiguous, B[N,K] k-contiguous   y  = x W^T
+//   NN  (a_t=0,b_t=1)  A[M,K] k-contiguous, B[K,N] n-contiguous   dx = dy W
+//   TN  (a_t=1,b_t=1)  A[K,M] m-contiguous, B[K,N] n-contiguous   dW = dy^T x
+//
+// Design (MI355X-first): 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32
+// accumulators.  Operand tiles are moved HBM->LDS by LDS-DMA (buffer_load ... lds, 16 B/lane,
+// hardware range check supplies the zero padding of ragged M/N/K tails), double-buffered, one
+// barrier per K-tile.  LDS images are lane-linear (DMA constraint) with the bank-conflict
+// swizzle applied to the *source* address and undone on the read:
+//   k-contiguous operand: [128 rows][64 k] 128-B rows, ds_read_b128, chunk ^= (row>>1)&7
+//   k-strided operand   : [64 k][128 cols] 256-B rows, ds_read_b64_tr_b16 (hardware
+//                         transpose), 32-B block ^= (k&3)|((k>>3)&1)<<2
+// MFMA operands are swapped (D = B_frag x A_frag) so a lane owns 4 consecutive n of one row m:
+// the epilogue loads/stores 8 B per lane.  Workgroups are remapped so each XCD (private L2)
+// works on a contiguous band of tiles.
+#include "common.hpp"
+#include "../../include/yat_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;  // 32 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;            // 64 KiB -> 2 workgroups / CU
+
+struct GemmP {
+    const bf16_t* A; const bf16_t* B; bf16_t* C;
+    int M, N, K; int lda, ldb, ldc;
+    const bf16_t* bias;    // [N] or null
+    const bf16_t* gate;    // [M/rows_per_batch][gate_ld] or null
+    const bf16_t* res;     // [M, ldr] residual / accumulate input or null
+    bf16_t* aux;           // [M, ldaux] pre-activation / pre-gate linear output or null
+    int ldr, ldaux, gate_ld, rows_per_batch;
+    int act;               // 0 none, 1 silu, 2 gelu_tanh
+    int nbm, nbn;
+    uint64_t a_bytes, b_bytes;
+};
+
+__device__ __forceinline__ uint32_t trswz(uint32_t krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+// stage one operand tile (16 KiB) into LDS: 4 LDS-DMA instructions per wave
+template <bool KSTRIDED>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds, int ld, int idx0, int idx_max,
+                                           int k0, int K, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = j * 4 + wave;  // 1-KiB piece index 0..15
+        uint32_t voff;
+        if (!KSTRIDED) {
+            const int r = piece * 8 + (lane >> 3);           // tile row (m or n index)
+            const int c = swz128(r, lane & 7);               // source chunk for this LDS slot
+            const int gi = idx0 + r, gk = k0 + c * 8;
+            voff = (gi < idx_max && gk < K) ? (uint32_t)(((int64_t)gi * ld + gk) * 2) : YAT_OOB;
+        } else {
+            const int r = piece * 4 + (lane >> 4);           // tile k-row
+            const int c = (lane & 15) ^ trswz(r);            // source chunk (8 cols)
+            const int gk = k0 + r, gi = idx0 + c * 8;
+            voff = (gk < K && gi < idx_max) ? (uint32_t)(((int64_t)gk * ld + gi) * 2) : YAT_OOB;
+        }
+        lds_dma16(rsrc, (YAT_LDS void*)(lds + piece * 1024), voff);
+    }
+}
+
+// fragment for 16 consecutive output indices starting at idx0 (tile-local), k-substep kk (32 wide)
+template <bool KSTRIDED>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds, int idx0, int kk, int lane) {
+    if (!KSTRIDED) {
+        const uint32_t r = idx0 + (lane & 15);
+        const uint32_t c = swz128(r, kk * 4 + (lane >> 4));
+        return lds_read8(lds, r * 128 + c * 16);
+    } else {
+        const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const uint32_t col = idx0 + 4 * p;
+        const uint32_t r0 = kk * 32 + 8 * g + q, r1 = r0 + 4;
+        const uint32_t c0 = (col >> 3) ^ trswz(r0), c1 = (col >> 3) ^ trswz(r1);
+        bf16x4 lo = lds_read_tr4(lds, r0 * 256 + c0 * 16 + (p & 1) * 8);
+        bf16x4 hi = lds_read_tr4(lds, r1 * 256 + c1 * 16 + (p & 1) * 8);
+        return cat4(lo, hi);
+    }
+}
+
+template <bool A_T, bool B_T>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap (bijective): blocks b and b+8 share an XCD -> give each XCD a contiguous band
+    const int nwg = p.nbm * p.nbn;
+    int id;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    // grouped ordering: 8 M-tiles x all N-tiles per group keeps A/B panels L2-resident
+    const int GROUP = 8;
+    const int per_group = GROUP * p.nbn;
+    const int gid = id / per_group, first_m = gid * GROUP;
+    const int gsz = min(p.nbm - first_m, GROUP);
+    const int tm = first_m + (id % per_group) % gsz;
+    const int tn = (id % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (p.K + BK - 1) / BK;
+    stage_tile<A_T>(ra, smem, p.lda, m0, p.M, 0, p.K, wave, lane);
+    stage_tile<B_T>(rb, smem + BM * BK * 2, p.ldb, n0, p.N, 0, p.K, wave, lane);
+
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * STAGE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile t landed for every wave; every wave is done reading the other buffer
+        if (t + 1 < nt) {
+            char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+            stage_tile<A_T>(ra, nxt, p.lda, m0, p.M, (t + 1) * BK, p.K, wave, lane);
+            stage_tile<B_T>(rb, nxt + BM * BK * 2, p.ldb, n0, p.N, (t + 1) * BK, p.K, wave, lane);
+        }
+        const char* la = cur;
+        const char* lb = cur + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = load_frag<A_T>(la, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_T>(lb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);  // D[n][m]
+        }
+    }
+
+    // ---- epilogue: lane owns row m = ..+(lane&15), cols n = ..+4*(lane>>4) + 0..3 ----
+    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / rpb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                float bb[4];
+                unpack4(*reinterpret_cast<const u32x2*>(p.bias + n), bb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            }
+            if (p.aux || p.act || p.res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);  // the Linear's bf16 output
+            }
+            if (p.aux) *reinterpret_cast<u32x2*>(p.aux + (int64_t)m * p.ldaux + n) = pack4(v[0], v[1], v[2], v[3]);
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+            }
+            if (p.gate) {
+                float g[4];
+                unpack4(*reinterpret_cast<const u32x2*>(p.gate + (int64_t)b * p.gate_ld + n), g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rbf(g[e] * v[e]);
+            }
+            if (p.res) {
+                float r[4];
+                unpack4(*reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r[e];
+            }
+            *reinterpret_cast<u32x2*>(p.C + (int64_t)m * p.ldc + n) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                             void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return YAT_EINVAL;
+    if ((N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return YAT_EINVAL;
+    if (a_t && !b_t) return YAT_EINVAL;                // TT-style (A m-contiguous, B k-contiguous) unused
+    if (!a_t && (K & 7)) return YAT_EINVAL;            // 16-B chunks along k
+    if (a_t && (M & 7)) return YAT_EINVAL;             // 16-B chunks along m
+    if (b_t && (N & 7)) return YAT_EINVAL;
+    GemmP p{};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    if (ep) {
+        p.bias = (const bf16_t*)ep->bias; p.gate = (const bf16_t*)ep->gate; p.res = (const bf16_t*)ep->residual;
+        p.aux = (bf16_t*)ep->aux_out; p.ldr = ep->ld_residual ? ep->ld_residual : ldc;
+        p.ldaux = ep->ld_aux ? ep->ld_aux : ldc; p.gate_ld = ep->ld_gate; p.rows_per_batch = ep->rows_per_batch;
+        p.act = ep->activation;
+        if (p.act < 0 || p.act > 2) return YAT_EINVAL;
+        if (p.gate && (p.gate_ld & 3)) return YAT_EINVAL;
+    }
+    p.nbm = (M + BM - 1) / BM; p.nbn = (N + BN - 1) / BN;
+    p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
+    p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
+    if (p.a_bytes > 0x7fffffffull || p.b_bytes > 0x7fffffffull) return YAT_EINVAL;
+    static bool attr_set = false;   // idempotent one-time launch attribute (64 KiB dynamic LDS)
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    dim3 grid(p.nbm * p.nbn), block(256);
+    if (!a_t && !b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
+    else if (!a_t && b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}

@@ -1,0 +1,157 @@
+// Fused optimizer step for gfx950 over ONE flat bf16 parameter buffer:
+//   global gradient-norm clip (torch.nn.utils.clip_grad_norm_, common/trainer.py:347)
+//   + AdamW (torch.optim.AdamW, common/trainer.py:246-248,348) + zero_grad (:356) + optional EMA (:350-351).
+// HBM-bound: 14 B/param algorithmic traffic (read p,g,m,v; write p,m,v) + 2 B for the grad clear.
+// The arithmetic follows torch's single-tensor op sequence on bf16 tensors: every torch op
+// computes in fp32 and rounds its result to bf16, so the kernel rounds at the same points.
+#include "common.hpp"
+#include "../../include/yat_hip.h"
+#include <math.h>
+
+namespace {
+
+constexpr int64_t NORM_CHUNK = 1 << 18;  // elements per gradnorm workgroup
+
+// grid = (maxchunks, nseg): sum of squares of one chunk of one parameter tensor
+__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const bf16_t* g, const int64_t* seg_start, int maxchunks,
+                                                               float* partial) {
+    const int seg = blockIdx.y, ck = blockIdx.x;
+    const int64_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
+    const int64_t c0 = s0 + (int64_t)ck * NORM_CHUNK;
+    if (c0 >= s1) return;
+    const int64_t c1 = (c0 + NORM_CHUNK < s1) ? c0 + NORM_CHUNK : s1;
+    float s = 0.f;
+    // segment starts are 16-B aligned; vector body + scalar tail
+    const int64_t nvec = (c1 - c0) >> 3;
+    for (int64_t i = threadIdx.x; i < nvec; i += 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(g + c0 + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+    }
+    for (int64_t i = c0 + (nvec << 3) + threadIdx.x; i < c1; i += 256) { const float v = bf2f(g[i]); s += v * v; }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)seg * maxchunks + ck] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void gradnorm_final_kernel(int nseg, const int64_t* seg_start, int maxchunks,
+                                                             const float* partial, float max_norm, float* norm_out,
+                                                             float* clip_coef) {
+    float acc = 0.f;
+    for (int seg = threadIdx.x; seg < nseg; seg += 256) {
+        const int64_t len = seg_start[seg + 1] - seg_start[seg];
+        const int nck = (int)((len + NORM_CHUNK - 1) / NORM_CHUNK);
+        float s = 0.f;
+        for (int c = 0; c < nck; ++c) s += partial[(int64_t)seg * maxchunks + c];
+        const float nb = rbf(sqrtf(s));   // per-tensor norm comes back as a bf16 tensor
+        acc += nb * nb;
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = rbf(sqrtf(red[0] + red[1] + red[2] + red[3]));
+        float coef = rbf(max_norm / rbf(total + 1e-6f));
+        coef = fminf(coef, 1.0f);
+        norm_out[0] = total;
+        clip_coef[0] = coef;
+    }
+}
+
+struct AdamP {
+    float wd_mul, w1, beta2, om_b2, bc2_sqrt, eps, neg_step_size, ema_omd;
+    int use_wd, zero_grad;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(int64_t nvec, bf16_t* p, bf16_t* g, bf16_t* m, bf16_t* v,
+                                                    const float* clip_coef, bf16_t* ema, AdamP a) {
+    const float coef = clip_coef ? clip_coef[0] : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float pp[8], gg[8], mm[8], vv[8], ss[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p + i * 8), pp);
+        unpack8(*reinterpret_cast<const u32x4*>(g + i * 8), gg);
+        unpack8(*reinterpret_cast<const u32x4*>(m + i * 8), mm);
+        unpack8(*reinterpret_cast<const u32x4*>(v + i * 8), vv);
+        if (ema) unpack8(*reinterpret_cast<const u32x4*>(ema + i * 8), ss);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gr = clip_coef ? rbf(gg[e] * coef) : gg[e];          // grads.mul_(clip_coef_clamped)
+            float pr = pp[e];
+            if (a.use_wd) pr = rbf(pr * a.wd_mul);                      // param.mul_(1 - lr*wd)
+            const float mr = rbf(mm[e] + a.w1 * (gr - mm[e]));          // exp_avg.lerp_(grad, 1-beta1)
+            float vr = rbf(vv[e] * a.beta2);                            // exp_avg_sq.mul_(beta2)
+            vr = rbf(vr + a.om_b2 * gr * gr);                           //   .addcmul_(grad, grad, value=1-beta2)
+            float den = rbf(sqrtf(vr));                                 // exp_avg_sq.sqrt()
+            den = rbf(den / a.bc2_sqrt);                                //   / bias_correction2_sqrt
+            den = rbf(den + a.eps);                                     //   .add_(eps)
+            pr = rbf(pr + a.neg_step_size * mr / den);                  // param.addcdiv_(exp_avg, denom, -step_size)
+            pp[e] = pr; mm[e] = mr; vv[e] = vr;
+            if (ema) {                                                  // s.sub_(one_minus_decay * (s - p))
+                const float d = rbf(ss[e] - pr);
+                ss[e] = rbf(ss[e] - rbf(a.ema_omd * d));
+            }
+        }
+        *reinterpret_cast<u32x4*>(p + i * 8) = pack8(pp);
+        *reinterpret_cast<u32x4*>(m + i * 8) = pack8(mm);
+        *reinterpret_cast<u32x4*>(v + i * 8) = pack8(vv);
+        if (ema) *reinterpret_cast<u32x4*>(ema + i * 8) = pack8(ss);
+        if (a.zero_grad) *reinterpret_cast<u32x4*>(g + i * 8) = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+static int norm_maxchunks(int64_t n) { return (int)((n + NORM_CHUNK - 1) / NORM_CHUNK); }
+
+uint64_t yat_gradnorm_workspace_bytes(int64_t n, int nseg) {
+    return (uint64_t)nseg * norm_maxchunks(n) * sizeof(float);
+}
+
+int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_start, float max_norm, float* norm_out,
+                      float* clip_coef, void* workspace, yat_stream_t stream) {
+    if (n <= 0 || nseg <= 0 || nseg > 65535 || !grad || !seg_start || !norm_out || !clip_coef || !workspace)
+        return YAT_EINVAL;
+    const int mc = norm_maxchunks(n);
+    hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(mc, nseg), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad,
+                       seg_start, mc, (float*)workspace);
+    YAT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nseg, seg_start, mc,
+                       (const float*)workspace, max_norm, norm_out, clip_coef);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_avg_sq, const float* clip_coef, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int step, int zero_grad, void* ema_shadow,
+                   double ema_decay, yat_stream_t stream) {
+    if (n <= 0 || (n & 7) || step < 1 || !param || !grad || !exp_avg || !exp_avg_sq) return YAT_EINVAL;
+    // scalar prep in double exactly as torch's python does, then narrowed to the kernels' opmath (float)
+    const double dlr = lr, db1 = beta1, db2 = beta2;
+    AdamP a;
+    a.use_wd = weight_decay != 0.0;
+    a.wd_mul = (float)(1.0 - dlr * weight_decay);
+    a.w1 = (float)(1.0 - db1);
+    a.beta2 = (float)db2;
+    a.om_b2 = (float)(1.0 - db2);
+    const double bc1 = 1.0 - pow(db1, (double)step), bc2 = 1.0 - pow(db2, (double)step);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.neg_step_size = (float)(-(dlr / bc1));
+    a.eps = (float)eps;
+    a.ema_omd = (float)(1.0 - ema_decay);
+    a.zero_grad = zero_grad;
+    const int64_t nvec = n >> 3;
+    int64_t nb = (nvec + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, nvec, (bf16_t*)param,
+                       (bf16_t*)grad, (bf16_t*)exp_avg, (bf16_t*)exp_avg_sq, clip_coef, (bf16_t*)ema_shadow, a);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+}  // extern "C"

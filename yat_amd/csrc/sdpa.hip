@@ -1,0 +1,422 @@
+// Masked softmax cross-attention (SANA attn2) forward + backward on MFMA for gfx950.
+//
+// Restates F.scaled_dot_product_attention(q, k, v, attn_mask=bias) as reached through diffusers
+// AttnProcessor2_0 at /root/reference/utils/patch_sana_attention_layers.py:98-104, with the
+// additive key bias built at /root/reference/utils/patched_sana_transformer.py:275-277
+// ((1 - mask) * -10000, no -inf).  Shapes at SANA-1.6B: 20 heads x 112, N = 1024 queries,
+// T = 512 padded keys of which only kv_len[b] are real -> key tiles past kv_len are skipped
+// (exact: their probabilities are exp(-9984 + ..) == 0 in fp32).
+//
+// Flash-style, 64-lane waves, MFMA 16x16x32 bf16, head dim padded to 128 in LDS by the LDS-DMA
+// range check.  Every product is issued with swapped operands so the softmax row (query) index
+// sits on the lane (lane & 15): row max / sum need two shuffles, the probability accumulators are
+// directly the B operand of the next MFMA (no LDS round trip; the k order of that MFMA is the
+// accumulator's own order, and the other operand is fetched in the same order by
+// ds_read_b64_tr_b16 from a row-major tile).
+//   forward : workgroup = 64 queries (4 waves x 16), loop over 64-key tiles, online softmax.
+//   backward: dq kernel (same decomposition, recomputes P, also emits delta = rowsum(dO*O));
+//             dkv kernel (workgroup = 64 keys, loops over 64-query tiles); no atomics.
+#include "common.hpp"
+#include "../../include/yat_hip.h"
+
+namespace {
+
+constexpr int TILE = 16384;  // one [64][128] bf16 image
+
+enum { IMG_ROW = 0, IMG_TR = 1 };
+
+// stage a [64 rows][128 cols] bf16 tile (rows past row_limit / cols past dh read as zero)
+template <int IMG>
+__device__ __forceinline__ void stage64x128(__amdgpu_buffer_rsrc_t rsrc, char* lds, int64_t row0, int64_t row_limit,
+                                            int ld, int col0, int dh, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = j * 4 + wave;
+        const int r = piece * 4 + (lane >> 4);
+        const int slot = lane & 15;
+        const int chunk = IMG == IMG_ROW ? (slot ^ (r & 15)) : (slot ^ ((r & 7) << 1));
+        const int64_t gr = row0 + r;
+        const uint32_t voff = (gr < row_limit && chunk * 8 < dh) ? (uint32_t)((gr * ld + col0 + chunk * 8) * 2) : YAT_OOB;
+        lds_dma16(rsrc, (YAT_LDS void*)(lds + piece * 1024), voff);
+    }
+}
+// operand fragment, natural k order, from a ROW image: idx = row0 + (lane&15), k = ks*32 + 8*(lane>>4) + j
+__device__ __forceinline__ bf16x8 frag_row(const char* lds, int row0, int ks, int lane) {
+    const uint32_t r = row0 + (lane & 15);
+    const uint32_t c = (ks * 4 + (lane >> 4)) ^ (r & 15);
+    return lds_read8(lds, r * 256 + c * 16);
+}
+// operand fragment in ACCUMULATOR k order from a TR image: idx = col0 + (lane&15);
+// k slot (g, j): row = krow0 + 4g + j (j < 4), krow0 + 16 + 4g + (j - 4) (j >= 4)
+__device__ __forceinline__ bf16x8 frag_tr_acc(const char* lds, int krow0, int col0, int lane) {
+    const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const uint32_t col = col0 + 4 * p;
+    const uint32_t r0 = krow0 + 4 * g + q, r1 = r0 + 16;
+    const uint32_t c0 = (col >> 3) ^ ((r0 & 7) << 1), c1 = (col >> 3) ^ ((r1 & 7) << 1);
+    return cat4(lds_read_tr4(lds, r0 * 256 + c0 * 16 + (p & 1) * 8), lds_read_tr4(lds, r1 * 256 + c1 * 16 + (p & 1) * 8));
+}
+// operand fragment straight from global memory (row-operand layout), zero padded
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int64_t row, int64_t row_limit, int ld, int col0, int dh,
+                                              int ks, int lane) {
+    const int d = ks * 32 + 8 * (lane >> 4);
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+    if (row < row_limit && d < dh) z = *reinterpret_cast<const bf16x8*>(base + row * ld + col0 + d);
+    return z;
+}
+// two accumulator tiles (keys/queries 16*(2s) and 16*(2s+1)) -> one bf16 operand fragment
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    return r;
+}
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups that share lane&15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct SdpaP {
+    int N, T, H, dh; float scale;
+    const bf16_t* q; int ldq; const bf16_t* k; const bf16_t* v; int ldkv;
+    const float* bias; const int* kv_len;
+    bf16_t* out; int ldo; float* lse;
+    // backward
+    const bf16_t* dout; int lddo; float* delta; bf16_t* dq; int lddq; bf16_t* dk; bf16_t* dv; int lddkv;
+    uint64_t q_bytes, kv_bytes, do_bytes;
+};
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;            // ROW image
+    char* Vs = smem + TILE;     // TR image
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int kvl = p.kv_len ? p.kv_len[b] : 0;
+    const int klim = kvl > 0 ? kvl : p.T;
+    const int col0 = h * p.dh;
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = frag_global(p.q, (int64_t)b * p.N + q0 + li, (int64_t)b * p.N + p.N, p.ldq, col0, p.dh, ks, lane);
+
+    f32x4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+
+    for (int k0 = 0; k0 < klim; k0 += 64) {
+        __syncthreads();
+        stage64x128<IMG_ROW>(rk, Ks, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rv, Vs, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f32x4 s[4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            s[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s[nj] = mfma16(frag_row(Ks, nj * 16, ks, lane), qf[ks], s[nj]);
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nj * 16 + 4 * g + r;
+                float v = key < p.T ? s[nj][r] * p.scale + p.bias[(int64_t)b * p.T + key] : -1e30f;
+                s[nj][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = group_max(mx);
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[nj][r] - mn);
+                s[nj][r] = e;
+                rs += e;
+            }
+        rs = group_sum(rs);
+        l = l * alpha + rs;
+        m = mn;
+        const bf16x8 pf0 = acc_to_frag(s[0], s[1]), pf1 = acc_to_frag(s[2], s[3]);
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+            o[dt] = mfma16(frag_tr_acc(Vs, 0, dt * 16, lane), pf0, o[dt]);
+            o[dt] = mfma16(frag_tr_acc(Vs, 32, dt * 16, lane), pf1, o[dt]);
+        }
+    }
+    const int qi = q0 + li;
+    if (qi < p.N) {
+        const float inv = 1.0f / l;
+        bf16_t* op = p.out + ((int64_t)b * p.N + qi) * p.ldo + col0;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const int d = dt * 16 + 4 * g;
+            if (d < p.dh) *reinterpret_cast<u32x2*>(op + d) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        }
+        if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+__global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;              // ROW image of K
+    char* Vs = smem + TILE;       // ROW image of V
+    char* Kt = smem + 2 * TILE;   // TR image of K
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int kvl = p.kv_len ? p.kv_len[b] : 0;
+    const int klim = kvl > 0 ? kvl : p.T;
+    const int col0 = h * p.dh;
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
+    const int64_t qrow = (int64_t)b * p.N + q0 + li, qlim = (int64_t)b * p.N + p.N;
+    const int qi = q0 + li;
+
+    bf16x8 qf[4], dof[4];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = frag_global(p.q, qrow, qlim, p.ldq, col0, p.dh, ks, lane);
+        dof[ks] = frag_global(p.dout, qrow, qlim, p.lddo, col0, p.dh, ks, lane);
+        const bf16x8 of = frag_global(p.out, qrow, qlim, p.ldo, col0, p.dh, ks, lane);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[e];
+    }
+    dl = group_sum(dl);
+    const float lse = qi < p.N ? p.lse[((int64_t)b * p.H + h) * p.N + qi] : 1e30f;
+    if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = dl;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < klim; k0 += 64) {
+        __syncthreads();
+        const int64_t r0 = (int64_t)b * p.T + k0, rl = (int64_t)b * p.T + p.T;
+        stage64x128<IMG_ROW>(rk, Ks, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_ROW>(rv, Vs, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rk, Kt, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            s[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s[nj] = mfma16(frag_row(Ks, nj * 16, ks, lane), qf[ks], s[nj]);
+                dp[nj] = mfma16(frag_row(Vs, nj * 16, ks, lane), dof[ks], dp[nj]);
+            }
+        }
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nj * 16 + 4 * g + r;
+                float pr = 0.f;
+                if (key < p.T) pr = __expf(s[nj][r] * p.scale + p.bias[(int64_t)b * p.T + key] - lse);
+                s[nj][r] = pr * (dp[nj][r] - dl);   // dS (w.r.t. the scaled logits)
+            }
+        const bf16x8 f0 = acc_to_frag(s[0], s[1]), f1 = acc_to_frag(s[2], s[3]);
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            acc[dt] = mfma16(frag_tr_acc(Kt, 0, dt * 16, lane), f0, acc[dt]);
+            acc[dt] = mfma16(frag_tr_acc(Kt, 32, dt * 16, lane), f1, acc[dt]);
+        }
+    }
+    if (qi < p.N) {
+        bf16_t* dp_ = p.dq + ((int64_t)b * p.N + qi) * p.lddq + col0;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const int d = dt * 16 + 4 * g;
+            if (d < p.dh)
+                *reinterpret_cast<u32x2*>(dp_ + d) =
+                    pack4(acc[dt][0] * p.scale, acc[dt][1] * p.scale, acc[dt][2] * p.scale, acc[dt][3] * p.scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+__global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;               // ROW image of Q
+    char* Os = smem + TILE;        // ROW image of dO
+    char* Qt = smem + 2 * TILE;    // TR image of Q
+    char* Ot = smem + 3 * TILE;    // TR image of dO
+    float* lse_s = reinterpret_cast<float*>(smem + 4 * TILE);   // [64]
+    float* del_s = lse_s + 64;                                  // [64]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int k0 = blockIdx.x * 64 + wave * 16;
+    const int kvl = p.kv_len ? p.kv_len[b] : 0;
+    const int klim = kvl > 0 ? kvl : p.T;
+    const int col0 = h * p.dh;
+    const int key = k0 + li;
+    bf16_t* dkp = p.dk + ((int64_t)b * p.T + key) * p.lddkv + col0;
+    bf16_t* dvp = p.dv + ((int64_t)b * p.T + key) * p.lddkv + col0;
+
+    if ((int)blockIdx.x * 64 >= klim) {   // whole tile masked out: exact zero gradient
+        if (key < p.T) {
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const int d = dt * 16 + 4 * g;
+                if (d < p.dh) {
+                    *reinterpret_cast<u32x2*>(dkp + d) = u32x2{0u, 0u};
+                    *reinterpret_cast<u32x2*>(dvp + d) = u32x2{0u, 0u};
+                }
+            }
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes), rdo = make_rsrc(p.dout, p.do_bytes);
+    const int64_t krow = (int64_t)b * p.T + key, klimrow = (int64_t)b * p.T + p.T;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = frag_global(p.k, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
+        vf[ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
+    }
+    const float kb = key < p.T ? p.bias[(int64_t)b * p.T + key] : 0.f;
+    const bool kvalid = key < p.T;
+
+    f32x4 adk[8], adv[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) { adk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int q0 = 0; q0 < p.N; q0 += 64) {
+        __syncthreads();
+        const int64_t r0 = (int64_t)b * p.N + q0, rl = (int64_t)b * p.N + p.N;
+        stage64x128<IMG_ROW>(rq, Qs, r0, rl, p.ldq, col0, p.dh, wave, lane);
+        stage64x128<IMG_ROW>(rdo, Os, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rq, Qt, r0, rl, p.ldq, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rdo, Ot, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        if (threadIdx.x < 64) {
+            const int qi = q0 + threadIdx.x;
+            const int64_t si = ((int64_t)b * p.H + h) * p.N + qi;
+            lse_s[threadIdx.x] = qi < p.N ? p.lse[si] : 1e30f;
+            del_s[threadIdx.x] = qi < p.N ? p.delta[si] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int nq = 0; nq < 4; ++nq) {
+            s[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s[nq] = mfma16(frag_row(Qs, nq * 16, ks, lane), kf[ks], s[nq]);     // [q = 16nq+4g+r][key = li]
+                dp[nq] = mfma16(frag_row(Os, nq * 16, ks, lane), vf[ks], dp[nq]);
+            }
+        }
+#pragma unroll
+        for (int nq = 0; nq < 4; ++nq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = nq * 16 + 4 * g + r;
+                const float pr = kvalid ? __expf(s[nq][r] * p.scale + kb - lse_s[ql]) : 0.f;
+                s[nq][r] = pr;                                  // P
+                dp[nq][r] = pr * (dp[nq][r] - del_s[ql]);       // dS
+            }
+        const bf16x8 pf0 = acc_to_frag(s[0], s[1]), pf1 = acc_to_frag(s[2], s[3]);
+        const bf16x8 sf0 = acc_to_frag(dp[0], dp[1]), sf1 = acc_to_frag(dp[2], dp[3]);
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            adv[dt] = mfma16(frag_tr_acc(Ot, 0, dt * 16, lane), pf0, adv[dt]);
+            adv[dt] = mfma16(frag_tr_acc(Ot, 32, dt * 16, lane), pf1, adv[dt]);
+            adk[dt] = mfma16(frag_tr_acc(Qt, 0, dt * 16, lane), sf0, adk[dt]);
+            adk[dt] = mfma16(frag_tr_acc(Qt, 32, dt * 16, lane), sf1, adk[dt]);
+        }
+    }
+    if (kvalid) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const int d = dt * 16 + 4 * g;
+            if (d < p.dh) {
+                *reinterpret_cast<u32x2*>(dvp + d) = pack4(adv[dt][0], adv[dt][1], adv[dt][2], adv[dt][3]);
+                *reinterpret_cast<u32x2*>(dkp + d) =
+                    pack4(adk[dt][0] * p.scale, adk[dt][1] * p.scale, adk[dt][2] * p.scale, adk[dt][3] * p.scale);
+            }
+        }
+    }
+}
+
+constexpr int FWD_LDS = 2 * TILE, DQ_LDS = 3 * TILE, DKV_LDS = 4 * TILE + 512;
+
+int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv) {
+    if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7)) return YAT_EINVAL;
+    if ((uint64_t)B * N * ldq * 2 > 0x7fffffffull || (uint64_t)B * T * ldkv * 2 > 0x7fffffffull) return YAT_EINVAL;
+    return YAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                 int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream) {
+    if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 3) || !q || !k || !v || !key_bias || !out) return YAT_EINVAL;
+    SdpaP p{};
+    p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
+    p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
+    p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = lse;
+    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2;
+    hipLaunchKernelGGL(sdpa_fwd_kernel, dim3((N + 63) / 64, H, B), dim3(256), FWD_LDS, (hipStream_t)stream, p);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                 int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
+                 const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, yat_stream_t stream) {
+    if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddkv & 3) || !q || !k || !v ||
+        !key_bias || !out || !dout || !lse || !delta || !dq || !dk || !dv)
+        return YAT_EINVAL;
+    if ((uint64_t)B * N * lddo * 2 > 0x7fffffffull) return YAT_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) !=
+            hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    SdpaP p{};
+    p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
+    p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
+    p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = (float*)lse;
+    p.dout = (const bf16_t*)dout; p.lddo = lddo; p.delta = delta; p.dq = (bf16_t*)dq; p.lddq = lddq;
+    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lddkv = lddkv;
+    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
+    hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), DQ_LDS, (hipStream_t)stream, p);
+    YAT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sdpa_bwd_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), DKV_LDS, (hipStream_t)stream, p);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""ctypes binding of libyat_hip.so -- the only door between the Python host code and the HIP kernels.
+
+The signatures below mirror include/yat_hip.h one to one (tests/test_abi.py checks that every
+symbol the header declares is exported and bound).  There is NO fallback: if the library is
+missing or a symbol cannot be resolved, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyat_hip.so")
+
+P, I, I64, U64, F, D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
+                ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I)]
+
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    "yat_version": (I, []),
+    "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
+    "yat_colsum_workspace_bytes": (U64, [I, I]),
+    "yat_colsum_bf16": (I, [I, I, P, I, P, I, P, P]),
+    "yat_modulation_fwd": (I, [I, I, I, P, P, I, I, P, P]),
+    "yat_modulation_bwd": (I, [I, I, I, P, P, I, P, I, I, P]),
+    "yat_ln_bwd_workspace_bytes": (U64, [I, I, I]),
+    "yat_ln_modulate_fwd": (I, [I, I, I, F, P, P, P, I, P, P, P, P]),
+    "yat_ln_modulate_bwd": (I, [I, I, I, P, P, P, P, I, P, P, P, P, P, I, P, P]),
+    "yat_rmsnorm_bwd_workspace_bytes": (U64, [I, I]),
+    "yat_rmsnorm_fwd": (I, [I, I, F, P, P, P, P, P]),
+    "yat_rmsnorm_bwd": (I, [I, I, P, P, P, P, P, P, I, P, P]),
+    "yat_linear_attn_workspace_bytes": (U64, [I, I, I]),
+    "yat_linear_attn_fwd": (I, [I, I, I, P, I, I, I, P, I, P, P]),
+    "yat_linear_attn_bwd": (I, [I, I, I, P, I, I, I, P, I, P, I, P, P]),
+    "yat_sdpa_fwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, P]),
+    "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P]),
+    "yat_dwconv_glu_bwd_workspace_bytes": (U64, [I, I, I, I]),
+    "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P]),
+    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, I, P, P]),
+    "yat_gate_bwd_workspace_bytes": (U64, [I, I, I]),
+    "yat_gate_bwd": (I, [I, I, I, P, P, P, I, P, P, I, P, P]),
+    "yat_act_fwd": (I, [I64, I, P, P, P]),
+    "yat_act_bwd": (I, [I64, I, P, P, P, P]),
+    "yat_add_bf16": (I, [I64, P, P, P, P]),
+    "yat_f32_to_bf16": (I, [I64, P, P, P]),
+    "yat_timestep_embed_fwd": (I, [I, I, P, P, P]),
+    "yat_pad_mask": (I, [I, I, I, P, P, P, P, P, P, P]),
+    "yat_flow_mix": (I, [I, I64, P, P, P, P, P, P]),
+    "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
+    "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
+    "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
+    "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, P]),
+}
+
+
+class YatLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libyat_hip.so and bind every symbol.  Raises YatLibraryError -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YatLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m yat_amd.build` (or __graft_entry__.build()). "
+            "The HIP path has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise YatLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise YatLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = "invalid argument" if rc < 0 else f"hipError_t {rc}"
+        raise YatLibraryError(f"{what} failed: {kind}")

@@ -1,0 +1,280 @@
+"""Thin torch-tensor wrappers over the C ABI (yat_amd.lib).  torch supplies device memory and the
+stream; every computation happens in libyat_hip.so.  No CPU fallback: a CPU tensor is an error.
+
+Each wrapper names the C entry point it calls; see include/yat_hip.h for the reference call site
+that entry point replaces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+
+BF16 = torch.bfloat16
+ACT = {"none": 0, "silu": 1, "gelu_tanh": 2}
+
+
+def _lib():
+    return _l.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _l.YatLibraryError("yat_amd ops need device tensors (there is no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None and t.dtype != BF16:
+            raise TypeError(f"expected bf16, got {t.dtype}")
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
+         activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0):
+    """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
+    _chk_bf16(a, b, out, bias, aux_out, gate, residual)
+    lda = lda if lda is not None else (M if a_t else K)
+    ldb = ldb if ldb is not None else (N if b_t else K)
+    ldc = ldc if ldc is not None else N
+    ep = None
+    if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None:
+        ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
+                             ld_residual, rows_per_batch)
+    rc = _lib().yat_gemm_bf16(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
+                              C.byref(ep) if ep is not None else None, _stream())
+    _l.check(rc, "yat_gemm_bf16")
+    return out
+
+
+def linear_fwd(x2d, w, bias=None, out=None, **ep):
+    """y = x W^T (+bias ...): x2d [M,K], w [N,K] (nn.Linear layout)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    out = out if out is not None else torch.empty(M, N, dtype=BF16, device=x2d.device)
+    return gemm(x2d, w, out, M=M, N=N, K=K, bias=bias, **ep)
+
+
+def linear_dgrad(dy2d, w, out=None, **ep):
+    """dx = dy W : dy [M,N], w [N,K] -> [M,K]."""
+    M, N = dy2d.shape
+    K = w.shape[1]
+    out = out if out is not None else torch.empty(M, K, dtype=BF16, device=dy2d.device)
+    return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, **ep)
+
+
+def linear_wgrad(dy2d, x2d, out, accumulate=False):
+    """dW = dy^T x : dy [M,N], x [M,K] -> out [N,K] (optionally += for gradient accumulation)."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    return gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=N, ldb=K, ldc=K,
+                residual=out if accumulate else None)
+
+
+def colsum(x2d, out, workspace, accumulate=False):
+    """yat_colsum_bf16: out[c] (+)= sum_r x[r,c]."""
+    rows, cols = x2d.shape
+    rc = _lib().yat_colsum_bf16(rows, cols, _p(x2d), x2d.stride(0), _p(out), int(accumulate), _p(workspace), _stream())
+    _l.check(rc, "yat_colsum_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- norms / modulation
+def modulation_fwd(table, tmod, slot_stride, out=None):
+    S, D = table.shape
+    B = tmod.shape[0]
+    out = out if out is not None else torch.empty(B, S, D, dtype=BF16, device=table.device)
+    rc = _lib().yat_modulation_fwd(B, S, D, _p(table), _p(tmod), tmod.stride(0), slot_stride, _p(out), _stream())
+    _l.check(rc, "yat_modulation_fwd")
+    return out
+
+
+def modulation_bwd(dmod_f32, dtable, dtmod_acc_f32, slot_stride, accumulate_table=False):
+    B, S, D = dmod_f32.shape
+    rc = _lib().yat_modulation_bwd(B, S, D, _p(dmod_f32), _p(dtable), int(accumulate_table), _p(dtmod_acc_f32),
+                                   dtmod_acc_f32.stride(0), slot_stride, _stream())
+    _l.check(rc, "yat_modulation_bwd")
+
+
+def ln_modulate_fwd(x2d, shift, scale, mod_ld, rows_per_batch, eps, y=None, mean=None, rstd=None):
+    M, D = x2d.shape
+    dev = x2d.device
+    y = y if y is not None else torch.empty_like(x2d)
+    mean = mean if mean is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = rstd if rstd is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    rc = _lib().yat_ln_modulate_fwd(M, D, rows_per_batch, eps, _p(x2d), _p(shift), _p(scale), mod_ld, _p(y), _p(mean),
+                                    _p(rstd), _stream())
+    _l.check(rc, "yat_ln_modulate_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd_workspace_bytes(M, D, rpb):
+    return int(_lib().yat_ln_bwd_workspace_bytes(M, D, rpb))
+
+
+def ln_modulate_bwd(x2d, mean, rstd, scale, mod_ld, rows_per_batch, dy, dres, dx, dshift_acc, dscale_acc, acc_ld,
+                    workspace):
+    M, D = x2d.shape
+    rc = _lib().yat_ln_modulate_bwd(M, D, rows_per_batch, _p(x2d), _p(mean), _p(rstd), _p(scale), mod_ld, _p(dy),
+                                    _p(dres), _p(dx), _p(dshift_acc), _p(dscale_acc), acc_ld, _p(workspace), _stream())
+    _l.check(rc, "yat_ln_modulate_bwd")
+    return dx
+
+
+def rmsnorm_fwd(x2d, w, eps, y=None, rstd=None):
+    M, D = x2d.shape
+    y = y if y is not None else torch.empty_like(x2d)
+    rstd = rstd if rstd is not None else torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rc = _lib().yat_rmsnorm_fwd(M, D, eps, _p(x2d), _p(w), _p(y), _p(rstd), _stream())
+    _l.check(rc, "yat_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(x2d, w, rstd, dy, dx, dw, workspace, accumulate_dw=False):
+    M, D = x2d.shape
+    rc = _lib().yat_rmsnorm_bwd(M, D, _p(x2d), _p(w), _p(rstd), _p(dy), _p(dx), _p(dw), int(accumulate_dw),
+                                _p(workspace), _stream())
+    _l.check(rc, "yat_rmsnorm_bwd")
+
+
+def gate_bwd(dout, lin, gate, gate_ld, rows_per_batch, dlin, dgate_acc, acc_ld, workspace):
+    M, D = dout.shape
+    rc = _lib().yat_gate_bwd(M, D, rows_per_batch, _p(dout), _p(lin), _p(gate), gate_ld, _p(dlin), _p(dgate_acc), acc_ld,
+                             _p(workspace), _stream())
+    _l.check(rc, "yat_gate_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def linear_attn_workspace_bytes(B, N, H):
+    return int(_lib().yat_linear_attn_workspace_bytes(B, N, H))
+
+
+def linear_attn_fwd(qkv2d, B, N, H, k_off, v_off, out, workspace):
+    rc = _lib().yat_linear_attn_fwd(B, N, H, _p(qkv2d), qkv2d.stride(0), k_off, v_off, _p(out), out.stride(0),
+                                    _p(workspace), _stream())
+    _l.check(rc, "yat_linear_attn_fwd")
+    return out
+
+
+def linear_attn_bwd(qkv2d, B, N, H, k_off, v_off, dout, dqkv, workspace):
+    rc = _lib().yat_linear_attn_bwd(B, N, H, _p(qkv2d), qkv2d.stride(0), k_off, v_off, _p(dout), dout.stride(0),
+                                    _p(dqkv), dqkv.stride(0), _p(workspace), _stream())
+    _l.check(rc, "yat_linear_attn_bwd")
+    return dqkv
+
+
+def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse):
+    """k2d / v2d may be column slices of one fused [B*T, 2*H*dh] projection (same row stride)."""
+    assert k2d.stride(0) == v2d.stride(0)
+    rc = _lib().yat_sdpa_fwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
+                             _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(lse), _stream())
+    _l.check(rc, "yat_sdpa_fwd")
+    return out
+
+
+def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv):
+    assert k2d.stride(0) == v2d.stride(0) and dk.stride(0) == dv.stride(0)
+    rc = _lib().yat_sdpa_bwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
+                             _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
+                             _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0), _stream())
+    _l.check(rc, "yat_sdpa_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- GLUMBConv middle
+def dwconv_glu_fwd(z, B, h, w, Hc, wdw, bdw, y):
+    rc = _lib().yat_dwconv_glu_fwd(B, h, w, Hc, _p(z), _p(wdw), _p(bdw), _p(y), _stream())
+    _l.check(rc, "yat_dwconv_glu_fwd")
+    return y
+
+
+def dwconv_glu_bwd_workspace_bytes(B, h, w, Hc):
+    return int(_lib().yat_dwconv_glu_bwd_workspace_bytes(B, h, w, Hc))
+
+
+def dwconv_glu_bwd(z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False):
+    rc = _lib().yat_dwconv_glu_bwd(B, h, w, Hc, _p(z), _p(wdw), _p(bdw), _p(dy), _p(dz), _p(dwdw), _p(dbdw),
+                                   int(accumulate), _p(workspace), _stream())
+    _l.check(rc, "yat_dwconv_glu_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- elementwise / recipe
+def act_fwd(x, act, y=None):
+    y = y if y is not None else torch.empty_like(x)
+    _l.check(_lib().yat_act_fwd(x.numel(), ACT[act], _p(x), _p(y), _stream()), "yat_act_fwd")
+    return y
+
+
+def act_bwd(x, dy, act, dx=None):
+    dx = dx if dx is not None else torch.empty_like(x)
+    _l.check(_lib().yat_act_bwd(x.numel(), ACT[act], _p(x), _p(dy), _p(dx), _stream()), "yat_act_bwd")
+    return dx
+
+
+def add_bf16(a, b, out=None):
+    out = out if out is not None else torch.empty_like(a)
+    _l.check(_lib().yat_add_bf16(a.numel(), _p(a), _p(b), _p(out), _stream()), "yat_add_bf16")
+    return out
+
+
+def f32_to_bf16(x, y=None):
+    y = y if y is not None else torch.empty(x.shape, dtype=BF16, device=x.device)
+    _l.check(_lib().yat_f32_to_bf16(x.numel(), _p(x), _p(y), _stream()), "yat_f32_to_bf16")
+    return y
+
+
+def timestep_embed(t_f32, dim=256, out=None):
+    B = t_f32.numel()
+    out = out if out is not None else torch.empty(B, dim, dtype=BF16, device=t_f32.device)
+    _l.check(_lib().yat_timestep_embed_fwd(B, dim, _p(t_f32), _p(out), _stream()), "yat_timestep_embed_fwd")
+    return out
+
+
+def pad_mask(src_cat, offsets_i32, B, T, Cdim, dst, mask_i64, key_bias_f32, kv_len_i32):
+    rc = _lib().yat_pad_mask(B, T, Cdim, _p(src_cat), _p(offsets_i32), _p(dst), _p(mask_i64), _p(key_bias_f32),
+                             _p(kv_len_i32), _stream())
+    _l.check(rc, "yat_pad_mask")
+
+
+def flow_mix(x, noise, sigma_bf16, noisy=None, target=None):
+    B = x.shape[0]
+    per = x.numel() // B
+    noisy = noisy if noisy is not None else torch.empty_like(x)
+    target = target if target is not None else torch.empty_like(x)
+    rc = _lib().yat_flow_mix(B, per, _p(x), _p(noise), _p(sigma_bf16), _p(noisy), _p(target), _stream())
+    _l.check(rc, "yat_flow_mix")
+    return noisy, target
+
+
+def mse_fwd_bwd(pred, target, loss_f32, dpred, workspace_f32, gscale=1.0):
+    rc = _lib().yat_mse_fwd_bwd(pred.numel(), _p(pred), _p(target), gscale, _p(loss_f32), _p(dpred), _p(workspace_f32),
+                                _stream())
+    _l.check(rc, "yat_mse_fwd_bwd")
+    return loss_f32
+
+
+# ----------------------------------------------------------------------------------------------- optimizer
+def gradnorm_workspace_bytes(n, nseg):
+    return int(_lib().yat_gradnorm_workspace_bytes(n, nseg))
+
+
+def gradnorm_clip(grad_flat, seg_start_i64, max_norm, norm_out, clip_coef, workspace):
+    nseg = seg_start_i64.numel() - 1
+    rc = _lib().yat_gradnorm_clip(grad_flat.numel(), _p(grad_flat), nseg, _p(seg_start_i64), max_norm, _p(norm_out),
+                                  _p(clip_coef), _p(workspace), _stream())
+    _l.check(rc, "yat_gradnorm_clip")
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, clip_coef, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True,
+               ema_shadow=None, ema_decay=0.0):
+    rc = _lib().yat_adamw_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(clip_coef), lr, beta1,
+                               beta2, eps, weight_decay, step, int(zero_grad), _p(ema_shadow), ema_decay, _stream())
+    _l.check(rc, "yat_adamw_step")
