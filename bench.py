@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SANA-1.6B 1024 px bf16 training step, images/sec (whole job), on N MI355X.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = the whole hot path of common/trainer.py:312-356 x train_sana.py:163-219 on one batch of synthetic
+cached features: pad/mask of the ragged text embeddings, noise + logit-normal timestep draw, flow-matching
+mix, SANA-1.6B forward, fp32 MSE, backward, (bucketed RCCL gradient all-reduce overlapped with backward when
+N > 1), global-norm clip and AdamW.  B = 8 images per GPU (BASELINE config 2), weak scaling.  Inputs (latents and
+the concatenated text embeddings) are resident in HBM before the timed region; weights are random-init of the
+1.6 B architecture (no checkpoints offline).
+
+The JSON line carries, besides the driver's contract:
+  roofline      dominant kernel = the MFMA GEMM family.  achieved = algorithmic FLOPs of every GEMM launch in the
+                timed region (2*M*N*K each) / the summed HIP-event durations of those launches, recorded live on the
+                launch stream; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  mfma_util_step  whole-step figure: algorithmic training FLOPs (6 x MAC, SURVEY.md 8d: 9.285 TFLOP/image at
+                N=1024,T=512) x img/s/GPU / 2.5e15.
+  cpu_baseline  the CPU oracle (torch restatement of the reference path; diffusers is absent offline) timed on this
+                box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0
+# latent-grid buckets (h, w) = ASPECT_RATIO_1024_BIN / 32, all ~1024 tokens
+BUCKETS = [(32, 32), (16, 64), (24, 42), (44, 22)]
+
+
+def train_flops_per_image(cfg, N, T):
+    """Algorithmic training FLOPs of one image: 6 x forward MACs (fwd + dgrad + wgrad), no recompute."""
+    D, Hc, Cc = cfg.inner_dim, cfg.ffn_hidden, cfg.caption_channels
+    blk = (N * D * 3 * D + N * D * D            # qkv, attn1.out
+           + 2 * 33 * 32 * N * cfg.num_attention_heads   # linear attention state + apply
+           + N * D * D + T * D * 2 * D + N * D * D       # attn2 q, kv, out
+           + 2 * N * T * D                                # QK^T and PV
+           + N * D * 2 * Hc + 9 * 2 * Hc * N + N * Hc * D)   # conv_inverted, depthwise, conv_point
+    head = (N * cfg.in_channels * D + 256 * D + D * D + D * 6 * D + T * Cc * D + T * D * D + N * D * cfg.out_channels)
+    return 6.0 * (cfg.num_layers * blk + head)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Time the CPU oracle on a bounded sample of the same workload: full-width SANA blocks (D=2240, N=1024, T=512),
+    B=1, bf16, fwd+bwd+clip+AdamW, with L=2 and L=4 blocks; per-block and non-block costs are separated linearly and
+    the 20-block step time is reconstructed."""
+    from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
+    from oracle.recipe_ref import FlowMatchSchedule, optimize_ref, clip_and_adamw_step
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1234)
+    lat = (torch.randn(1, 32, 32, 32, generator=g) * 0.5).to(torch.bfloat16)
+    embs = [torch.randn(160, 2304, generator=g).to(torch.bfloat16)]
+    times = {}
+    for L in (2, 4):
+        m = SanaTransformerRef(RefCfg(num_layers=L))
+        init_like_pretrained(m, 0)
+        m = m.to(torch.bfloat16)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+        sched = FlowMatchSchedule()
+        best = None
+        for it in range(2):                      # 1 warm-up + 1 timed
+            t0 = time.perf_counter()
+            loss, _, _ = optimize_ref(m, sched, lat, embs, torch.Generator(), 512, torch.bfloat16)
+            loss.backward()
+            clip_and_adamw_step(list(m.parameters()), opt)
+            best = time.perf_counter() - t0
+        times[L] = best
+        del m, opt
+    t_block = max((times[4] - times[2]) / 2.0, 1e-6)
+    t_rest = max(times[2] - 2 * t_block, 0.0)
+    t_full = t_rest + 20 * t_block
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": 1.0 / t_full, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": (f"CPU oracle (torch restatement of the reference path; diffusers unavailable offline), bf16, B=1, "
+                       f"N=1024, T=512, full-width blocks: measured {times[2]:.2f}s @L=2 and {times[4]:.2f}s @L=4 "
+                       f"(fwd+bwd+clip+AdamW), extrapolated linearly to L=20 = {t_full:.1f}s/image"),
+            "cpu_model": cpu}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 2: 8)")
+    ap.add_argument("--layers", type=int, default=20, help="debug only; anything but 20 is not the headline config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from yat_amd import ops
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.optim import FlatAdamW
+    from yat_amd.ddp import HipDDP
+
+    cfg = SanaConfig(num_layers=args.layers)
+    model = SanaTransformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
+    opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
+    ddp = HipDDP(model) if world > 1 else None
+    if ddp:
+        ddp.broadcast_parameters()
+    recipe = SanaRecipe(model, pad_to=512, device=dev)
+    B, T, Cc = args.batch, 512, cfg.caption_channels
+
+    # ---- synthetic cached features, resident in HBM (seed 1234 + rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    hg = torch.Generator().manual_seed(1234 + rank)
+    batches = []
+    for (h, w) in BUCKETS:
+        lat = (torch.randn(B, cfg.in_channels, h, w, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+        lens = torch.randint(20, 301, (B,), generator=hg).tolist()
+        offs = [0]
+        for L in lens:
+            offs.append(offs[-1] + L)
+        src = torch.randn(offs[-1], Cc, generator=g, device=dev).to(torch.bfloat16)
+        batches.append(dict(h=h, w=w, lat=lat, src=src, offsets=torch.tensor(offs, dtype=torch.int32, device=dev)))
+    enc = torch.empty(B, T, Cc, dtype=torch.bfloat16, device=dev)
+    mask = torch.empty(B, T, dtype=torch.int64, device=dev)
+    bias = torch.empty(B, T, dtype=torch.float32, device=dev)
+    kvl = torch.empty(B, dtype=torch.int32, device=dev)
+    loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+    noise_gen = torch.Generator(device=dev).manual_seed(99 + rank)   # throughput mode: advancing device stream
+    ts_gen = torch.Generator().manual_seed(77 + rank)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)                       # train_sana.py:168-180
+        noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)  # :183
+        _, t_host, sig_host = recipe.scheduler.sample(B, ts_gen)                                    # :185-204
+        t_dev, sig_dev = t_host.to(dev, non_blocking=True), sig_host.to(dev, non_blocking=True)
+        recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, sig_dev, loss_dev)      # :206-218 + backward
+        if ddp:
+            ddp.wait()
+        opt.step()                                                                                  # trainer.py:347-356
+        return b["h"] * b["w"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    timer = None if args.no_gemm_timer else []
+    ops.GEMM_TIMER = timer
+    t0 = time.perf_counter()
+    flops = 0.0
+    for i in range(args.steps):
+        ntok = step(args.warmup + i)
+        flops += B * train_flops_per_image(cfg, ntok, T)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    loss_val = loss_dev.item()
+
+    if rank == 0:
+        img_s = world * B * args.steps / elapsed
+        res = {
+            "metric": "images/sec (whole node) SANA-1.6B 1024px bf16 training step",
+            "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("train_sana.py: SANA-1.6B (D=2240, 20 blocks) 1024px, bf16, full fine-tune, "
+                                    f"cached latents/text embeds, aspect buckets {BUCKETS} round-robin, T=512, AdamW+clip"),
+                       "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",
+                       "num_layers": cfg.num_layers, "params": model.numel_flat},
+            "loss": loss_val,
+            "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),
+            "algorithmic_tflop_per_step": flops / args.steps / 1e12,
+        }
+        if timer:
+            gf = sum(t[0] for t in timer)
+            gms = sum(t[1].elapsed_time(t[2]) for t in timer)
+            ach = gf / (gms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN, all epilogues)",
+                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "launches": len(timer), "avg_launch_us": 1e3 * gms / len(timer),
+                               "gemm_share_of_step": gms / (1e3 * elapsed)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is a reported side number; never let it sink the bench line
+                res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

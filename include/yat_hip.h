@@ -42,7 +42,7 @@ typedef struct yat_gemm_epilogue {
 
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
  * b_t=0: B is [N,K] (k contiguous, nn.Linear weight layout); b_t=1: B is [K,N].
- * Supported: (0,0) forward y = x W^T; (0,1) dgrad dx = dy W; (1,1) wgrad dW = dy^T x.
+ * (0,0) forward y = x W^T; (0,1) dgrad dx = dy W; (1,1) wgrad dW = dy^T x; (1,0) x^T W^T.
  * Epilogue order: +bias -> round bf16 -> aux_out -> activation -> *gate (rounded) -> +residual.  */
 int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                   void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream);
@@ -138,6 +138,10 @@ int yat_act_fwd(int64_t n, int act, const void* x, void* y, yat_stream_t stream)
 int yat_act_bwd(int64_t n, int act, const void* x, const void* dy, void* dx, yat_stream_t stream);
 int yat_add_bf16(int64_t n, const void* a, const void* b, void* out, yat_stream_t stream);
 int yat_f32_to_bf16(int64_t n, const float* x, void* y, yat_stream_t stream);
+
+/* batched transpose in[B,R,C] -> out[B,C,R]: NCHW latents <-> token-major rows
+ * (PatchEmbed flatten/transpose patched_sana_transformer.py:284; unpatchify :336-340). */
+int yat_transpose_bf16(int B, int R, int C, const void* in, void* out, yat_stream_t stream);
 
 /* sinusoidal timestep projection (diffusers get_timestep_embedding(t,256,flip_sin_to_cos=True),
  * used via AdaLayerNormSingle at patched_sana_transformer.py:133,291-293): out bf16 [B, dim],

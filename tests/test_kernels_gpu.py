@@ -1,11 +1,19 @@
 """Per-kernel parity tests (GPU): every C-ABI entry point against a plain PyTorch fp32 restatement of
 the same op on the same bf16 inputs, rounded to bf16 where the reference's dtype flow rounds.
 
-Tolerance (stated once): bf16 has 8 significant bits (ulp = 2^-8 relative).  Both sides round
-their fp32 result to bf16, so they may differ by one bf16 ulp wherever the fp32 values straddle a
-rounding boundary (different accumulation order).  We therefore require
-    relative L2 error <= 2e-3   and   max |a-b| <= 2 bf16 ulps of the local magnitude (+ tiny abs),
-and bit-exactness for integer outputs (mask, kv_len).
+Tolerance (stated once): bf16 has 8 significant bits (ulp = 2^-8 relative; one rounding is an RMS
+relative error of ~1.1e-3).  Two kinds of check:
+
+* close(hip, ref): `ref` is computed with the SAME rounding points as the kernel (the reference's
+  bf16 op flow).  Both sides may still differ by one bf16 ulp where fp32 values straddle a rounding
+  boundary, so we require relative L2 <= 2e-3 and max |a-b| <= 2 bf16 ulps of the local magnitude.
+* as_good_as(hip, flow, truth): for backward passes the reference IS torch's bf16 autograd
+  (`flow`, run here with stock torch bf16 ops, every op rounding to bf16) and `truth` is the same
+  math in fp32.  The kernel must sit as close to the truth as the reference's own arithmetic does:
+  rel(hip, truth) <= 1.25 * rel(flow, truth) + 5e-4, and rel(hip, flow) <= 6e-3 (two independent
+  chains of a few bf16 roundings).
+Integer outputs (mask, kv_len) and the optimizer are checked bit-exactly.
+All checks of a test are evaluated and printed before the test fails.
 """
 import math
 
@@ -31,15 +39,44 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
 
 
+_FAILS = []
+
+
+@pytest.fixture(autouse=True)
+def _collect_failures():
+    _FAILS.clear()
+    yield
+    assert not _FAILS, "; ".join(_FAILS)
+
+
 def close(a, b, name, tol=2e-3, ulps=2.0, atol=1e-6):
     a, b = a.float(), b.float()
-    assert torch.isfinite(a).all(), f"{name}: non-finite output"
+    if not torch.isfinite(a).all():
+        _FAILS.append(f"{name}: non-finite output")
+        print(f"[parity] {name}: NON-FINITE")
+        return
     r = rel(a, b)
     bound = ulps * 2.0 ** -8 * b.abs() + atol + 1e-3 * b.abs().mean()
     worst = ((a - b).abs() - bound).max().item()
     print(f"[parity] {name}: rel_l2={r:.3e} max_abs={(a - b).abs().max().item():.3e}")
-    assert r <= tol, f"{name}: rel l2 {r:.3e} > {tol}"
-    assert worst <= 0, f"{name}: element error exceeds {ulps} bf16 ulps by {worst:.3e}"
+    if r > tol:
+        _FAILS.append(f"{name}: rel l2 {r:.3e} > {tol}")
+    if worst > 0:
+        _FAILS.append(f"{name}: element error exceeds {ulps} bf16 ulps by {worst:.3e}")
+
+
+def as_good_as(hip, flow, truth, name, slack=1.25, floor=5e-4, tol_flow=6e-3):
+    hip, flow, truth = hip.float(), flow.float(), truth.float()
+    if not torch.isfinite(hip).all():
+        _FAILS.append(f"{name}: non-finite output")
+        print(f"[parity] {name}: NON-FINITE")
+        return
+    eh, ef, hf = rel(hip, truth), rel(flow, truth), rel(hip, flow)
+    print(f"[parity] {name}: hip_vs_fp32={eh:.3e} torchbf16_vs_fp32={ef:.3e} hip_vs_torchbf16={hf:.3e}")
+    if eh > slack * ef + floor:
+        _FAILS.append(f"{name}: error vs fp32 truth {eh:.3e} > {slack} * reference's own {ef:.3e} + {floor}")
+    if ef <= tol_flow and hf > tol_flow:      # (skipped when torch's own bf16 kernel is far from the truth)
+        _FAILS.append(f"{name}: rel l2 vs torch bf16 flow {hf:.3e} > {tol_flow}")
 
 
 def rnd(*shape, scale=1.0, seed=0):
@@ -122,6 +159,17 @@ def test_gemm_epilogue_gate_residual(ops):
     close(out2, (res.float() + linr).to(BF), "epi_residual_out")
 
 
+def test_gemm_tt_and_transpose(ops):
+    Bn, R, Cc = 3, 50, 24
+    x = rnd(Bn, R, Cc, seed=70)
+    assert torch.equal(ops.transpose(x), x.transpose(1, 2).contiguous())
+    M, N, K = 136, 72, 64                      # A stored [K, M], B stored [N, K]
+    a, b = rnd(K, M, seed=71), rnd(N, K, scale=K ** -0.5, seed=72)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm(a, b, out, a_t=True, b_t=False, M=M, N=N, K=K)
+    close(out, (a.float().T @ b.float().T).to(BF), "gemm_tt")
+
+
 def test_colsum(ops):
     rows, cols = 1000, 264
     x = rnd(rows, cols, seed=15)
@@ -150,21 +198,25 @@ def test_ln_modulate_fwd_bwd(ops, B, n, D):
     shift, scale = mod[:, 3], mod[:, 4]
     y, mean, rstd = ops.ln_modulate_fwd(x, shift, scale, 6 * D, n, 1e-6)
     close(y, _ln_ref(x, shift, scale, 1e-6, n), f"ln_fwd D={D}")
-    # backward vs autograd of the fp32 formula
-    xr = x.float().requires_grad_(True)
-    scr = scale.float().requires_grad_(True)
-    shr = shift.float().requires_grad_(True)
-    yr = F.layer_norm(xr, (D,), None, None, 1e-6) * (1 + scr).repeat_interleave(n, 0) + shr.repeat_interleave(n, 0)
+    # backward: torch autograd of the reference's op sequence, once in bf16 (the reference) and once in fp32
     dy = rnd(M, D, seed=22)
     dres = rnd(M, D, seed=23)
-    yr.backward(dy.float())
+
+    def run(dt):
+        xr = x.detach().to(dt).clone().requires_grad_(True)
+        scr = scale.detach().to(dt).clone().requires_grad_(True)
+        shr = shift.detach().to(dt).clone().requires_grad_(True)
+        yr = F.layer_norm(xr, (D,), None, None, 1e-6) * (1 + scr).repeat_interleave(n, 0) + shr.repeat_interleave(n, 0)
+        yr.backward(dy.to(dt))
+        return xr.grad + dres.to(dt), shr.grad, scr.grad
+    flow, truth = run(BF), run(torch.float32)
     dx = torch.empty_like(x)
     acc = torch.zeros(B, 6, D, dtype=torch.float32, device=DEV)
     ws = torch.empty(ops.ln_bwd_workspace_bytes(M, D, n), dtype=torch.uint8, device=DEV)
     ops.ln_modulate_bwd(x, mean, rstd, scale, 6 * D, n, dy, dres, dx, acc[:, 3], acc[:, 4], 6 * D, ws)
-    close(dx, (xr.grad + dres.float()).to(BF), f"ln_bwd_dx D={D}", tol=4e-3, ulps=3)
-    close(acc[:, 3], shr.grad, f"ln_bwd_dshift D={D}", tol=4e-3, ulps=4, atol=1e-3)
-    close(acc[:, 4], scr.grad, f"ln_bwd_dscale D={D}", tol=8e-3, ulps=6, atol=5e-2)
+    as_good_as(dx, flow[0], truth[0], f"ln_bwd_dx D={D}")
+    as_good_as(acc[:, 3], flow[1], truth[1], f"ln_bwd_dshift D={D}", tol_flow=2e-2)
+    as_good_as(acc[:, 4], flow[2], truth[2], f"ln_bwd_dscale D={D}", tol_flow=2e-2)
     assert acc[:, [0, 1, 2, 5]].abs().max().item() == 0.0
 
 
@@ -175,14 +227,20 @@ def test_rmsnorm_fwd_bwd(ops):
     xf = x.float()
     r = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
     close(y, (rb(xf * r) * w.float()).to(BF), "rmsnorm_fwd")
-    xr, wr = xf.clone().requires_grad_(True), w.float().clone().requires_grad_(True)
-    (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * wr).backward(rnd(M, D, seed=25).float())
     dy = rnd(M, D, seed=25)
+
+    def run(dt):       # diffusers RMSNorm op sequence (oracle/sana_ref.py RMSNorm)
+        xr, wr = x.detach().to(dt).clone().requires_grad_(True), w.detach().to(dt).clone().requires_grad_(True)
+        var = xr.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        hcur = (xr * torch.rsqrt(var + 1e-5)).to(dt) * wr
+        hcur.backward(dy.to(dt))
+        return xr.grad, wr.grad
+    flow, truth = run(BF), run(torch.float32)
     dx, dw = torch.empty_like(x), torch.empty_like(w)
     ws = torch.empty(int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(M, D)), dtype=torch.uint8, device=DEV)
     ops.rmsnorm_bwd(x, w, rstd, dy, dx, dw, ws)
-    close(dx, xr.grad.to(BF), "rmsnorm_bwd_dx", tol=4e-3, ulps=3)
-    close(dw, wr.grad.to(BF), "rmsnorm_bwd_dw", tol=4e-3, ulps=3, atol=2e-2)
+    as_good_as(dx, flow[0], truth[0], "rmsnorm_bwd_dx")
+    as_good_as(dw, flow[1], truth[1], "rmsnorm_bwd_dw", tol_flow=1e-2)
 
 
 def test_modulation_fwd_bwd(ops):
@@ -273,17 +331,24 @@ def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
     ops.sdpa_fwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, lse)
     qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k.contiguous(), v.contiguous()))
     ref, lse_ref = _sdpa_ref(qr, kr, vr, bias, B, N, T, H, dh, scale)
-    close(out, ref.to(BF), f"sdpa_fwd T={T} dh={dh}")
+    # the reference's op: F.scaled_dot_product_attention on bf16 tensors with the additive bf16 mask
+    qb, kb, vb = (t.clone().view(B, -1, H, dh).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    mb = bias.to(BF)[:, None, None, :].expand(B, H, 1, T)
+    flow = F.scaled_dot_product_attention(qb, kb, vb, attn_mask=mb)
+    flow2d = flow.transpose(1, 2).reshape(B * N, D)
+    as_good_as(out, flow2d, ref, f"sdpa_fwd T={T} dh={dh}")
     close(lse, lse_ref, f"sdpa_lse T={T}", tol=1e-4, ulps=0.01, atol=1e-3)
     dout = rnd(B * N, D, seed=36)
     ref.backward(dout.float())
+    flow2d.backward(dout)
+    fl = [t.grad.transpose(1, 2).reshape(-1, D) for t in (qb, kb, vb)]
     dq = torch.empty_like(q)
     dkv = torch.full_like(kv, float("nan"))
     delta = torch.empty(B, H, N, dtype=torch.float32, device=DEV)
     ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:])
-    close(dq, qr.grad.to(BF), f"sdpa_dq T={T}", tol=6e-3, ulps=4, atol=1e-4)
-    close(dkv[:, :D], kr.grad.to(BF), f"sdpa_dk T={T}", tol=6e-3, ulps=4, atol=1e-4)
-    close(dkv[:, D:], vr.grad.to(BF), f"sdpa_dv T={T}", tol=6e-3, ulps=4, atol=1e-4)
+    as_good_as(dq, fl[0], qr.grad, f"sdpa_dq T={T}", tol_flow=1e-2)
+    as_good_as(dkv[:, :D], fl[1], kr.grad, f"sdpa_dk T={T}", tol_flow=1e-2)
+    as_good_as(dkv[:, D:], fl[2], vr.grad, f"sdpa_dv T={T}", tol_flow=1e-2)
 
 
 # ------------------------------------------------------------------------------------------------ GLUMBConv middle
@@ -304,20 +369,24 @@ def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     y = torch.empty(M, Hc, dtype=BF, device=DEV)
     ops.dwconv_glu_fwd(z, B, h, w, Hc, wdw, bdw, y)
     close(y, _glu_ref(z, wdw, bdw, B, h, w, Hc).to(BF), f"dwconv_fwd {h}x{w}x{Hc}")
-    # backward against autograd of the un-rounded fp32 formula
-    zr, wr, br = z.float().requires_grad_(True), wdw.float().requires_grad_(True), bdw.float().requires_grad_(True)
-    zi = zr.view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
-    u = F.conv2d(F.silu(zi), wr.view(2 * Hc, 1, 3, 3), br, padding=1, groups=2 * Hc)
-    a, g = u.chunk(2, 1)
-    yr = (a * F.silu(g)).permute(0, 2, 3, 1).reshape(M, Hc)
+    # backward: torch autograd of diffusers GLUMBConv's op sequence in bf16 (the reference) and in fp32
     dy = rnd(M, Hc, seed=40)
-    yr.backward(dy.float())
+
+    def run(dt):
+        zr, wr, br = (t.detach().to(dt).clone().requires_grad_(True) for t in (z, wdw, bdw))
+        zi = zr.view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
+        u = F.conv2d(F.silu(zi), wr.view(2 * Hc, 1, 3, 3), br, padding=1, groups=2 * Hc)
+        a, g = torch.chunk(u, 2, dim=1)
+        yr = (a * F.silu(g)).permute(0, 2, 3, 1).reshape(M, Hc)
+        yr.backward(dy.to(dt))
+        return zr.grad, wr.grad, br.grad
+    flow, truth = run(BF), run(torch.float32)
     dz, dw, db = torch.empty_like(z), torch.empty_like(wdw), torch.empty_like(bdw)
     ws = torch.empty(ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc), dtype=torch.uint8, device=DEV)
     ops.dwconv_glu_bwd(z, B, h, w, Hc, wdw, bdw, dy, dz, dw, db, ws)
-    close(dz, zr.grad.to(BF), f"dwconv_dz {h}x{w}x{Hc}", tol=8e-3, ulps=4, atol=1e-3)
-    close(dw, wr.grad.to(BF), f"dwconv_dw {h}x{w}x{Hc}", tol=8e-3, ulps=4, atol=3e-2)
-    close(db, br.grad.to(BF), f"dwconv_db {h}x{w}x{Hc}", tol=8e-3, ulps=4, atol=3e-2)
+    as_good_as(dz, flow[0], truth[0], f"dwconv_dz {h}x{w}x{Hc}", tol_flow=1e-2)
+    as_good_as(dw, flow[1], truth[1], f"dwconv_dw {h}x{w}x{Hc}", tol_flow=1e-2)
+    as_good_as(db, flow[2], truth[2], f"dwconv_db {h}x{w}x{Hc}", tol_flow=1e-2)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise / recipe

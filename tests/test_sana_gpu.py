@@ -1,0 +1,147 @@
+"""End-to-end parity (GPU): HIP SANA training step vs the CPU oracle on fixed seeds.
+
+The oracle is run twice on identical inputs and weights: in bf16 (the reference's dtype flow,
+train_sana.py:21-22,39) and in fp32 (ground truth).  Stated tolerances:
+
+* loss: the north star asks for 1e-3 relative; the reference's own bf16 loss sits up to ~2e-3 from the fp32
+  value of the same step, so the check is against the fp32 truth with the reference's own error as the yardstick:
+  |hip - fp32| <= 1.3 * |oracle_bf16 - fp32| + 1e-3 * |fp32|;
+* predicted noise / gradients: bf16 tensors of two correct implementations differ by rounding noise,
+  so the requirement is "as close to the fp32 truth as the reference's own bf16 arithmetic":
+  rel_l2(hip, fp32) <= 1.3 * rel_l2(oracle_bf16, fp32) + 1e-3, reported next to rel_l2(hip, oracle_bf16);
+* one clip+AdamW step: updated parameters within 1 bf16 ulp of torch's CPU optimizer on >= 99 % of
+  elements (the optimizer kernel itself is bit-exact, see test_kernels_gpu; differences here come
+  only from the rounding noise of the gradients that feed it).
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def _setup(cfg_kw, B, h, w, lens, pad_to, seed=0):
+    from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    rcfg = RefCfg.tiny(**cfg_kw)
+    ref = SanaTransformerRef(rcfg)
+    init_like_pretrained(ref, seed)
+    ref_bf = copy.deepcopy(ref).to(BF)
+    ref_32 = copy.deepcopy(ref_bf).float()          # same (bf16-representable) weights, fp32 arithmetic
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV)
+    hip.load_state_dict(ref_bf.state_dict())
+    g = torch.Generator().manual_seed(100 + seed)
+    latents = (torch.randn(B, rcfg.in_channels, h, w, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in lens]
+    return ref_bf, ref_32, hip, latents, embs
+
+
+@pytest.mark.parametrize("B,h,w,lens,pad_to,layers", [
+    (2, 4, 4, [5, 16], 16, 2),
+    (3, 6, 10, [7, 40, 1], 64, 2),
+    (2, 16, 8, [100, 33], 128, 3),
+])
+def test_step_matches_oracle(B, h, w, lens, pad_to, layers):
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.scheduler import FlowMatchSchedule
+    from yat_amd.optim import FlatAdamW
+    ref_bf, ref_32, hip, latents, embs = _setup(dict(num_layers=layers), B, h, w, lens, pad_to)
+    sched = RefSched()
+    # the reference creates a fresh, unseeded CPU generator every step (common/trainer.py:325)
+    loss_bf, pred_bf, _ = optimize_ref(ref_bf, sched, latents, embs, torch.Generator(), pad_to, BF)
+    loss_32, pred_32, _ = optimize_ref(ref_32, sched, latents, embs, torch.Generator(), pad_to, torch.float32)
+    loss_bf.backward()
+    loss_32.backward()
+
+    recipe = SanaRecipe(hip, FlowMatchSchedule(), pad_to=pad_to, device=DEV)
+    loss, pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
+    print(f"[parity] loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
+    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 1e-3 * abs(l_t)
+    e_h, e_b, e_hb = rel(pred, pred_32), rel(pred_bf, pred_32), rel(pred, pred_bf)
+    print(f"[parity] pred  hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={e_hb:.3e}")
+    assert e_h <= 1.3 * e_b + 1e-3
+
+    # gradients, every parameter tensor
+    p32 = dict(ref_32.named_parameters())
+    worst = []
+    num_h = num_b = den = 0.0
+    for name, pb in ref_bf.named_parameters():
+        gh, gb, gt = hip.G[name].float().cpu(), pb.grad.float(), p32[name].grad.float()
+        assert torch.isfinite(gh).all(), name
+        num_h += (gh - gt).pow(2).sum().item()
+        num_b += (gb - gt).pow(2).sum().item()
+        den += gt.pow(2).sum().item()
+        worst.append((rel(gh, gt), rel(gb, gt), name))
+    tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
+    print(f"[parity] grads (all params) hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
+    for eh, eb, name in sorted(worst, reverse=True)[:8]:
+        print(f"[parity]   {name}: hip={eh:.3e} oracle_bf16={eb:.3e}")
+    assert tot_h <= 1.3 * tot_b + 1e-3
+    for eh, eb, name in worst:
+        assert eh <= 2.0 * eb + 2e-2, (name, eh, eb)
+
+    # one clip + AdamW step against torch's CPU optimizer fed with the ORACLE's bf16 gradients
+    opt_ref = torch.optim.AdamW(ref_bf.parameters(), lr=1e-3, weight_decay=0.01)
+    total = torch.nn.utils.clip_grad_norm_(ref_bf.parameters(), max_norm=1.0)
+    opt_ref.step()
+    opt = FlatAdamW(hip, lr=1e-3, weight_decay=0.01)
+    opt.step()
+    torch.cuda.synchronize()
+    gn = opt.grad_norm.item()
+    print(f"[parity] grad norm hip={gn:.5f} torch={total.item():.5f}")
+    assert abs(gn - total.float().item()) <= 2e-2 * total.float().item()
+    n_bad = n_all = 0
+    for name, pb in ref_bf.named_parameters():
+        a, b = hip.P[name].float().cpu(), pb.data.float()
+        ulp = 2.0 ** -7 * b.abs().clamp_min(1e-30)
+        n_bad += ((a - b).abs() > ulp).sum().item()
+        n_all += b.numel()
+    print(f"[parity] AdamW: {n_bad}/{n_all} parameters differ by more than 1 bf16 ulp from torch CPU")
+    assert n_bad <= 0.01 * n_all
+    assert hip.flat_grad.abs().max().item() == 0.0
+
+
+def test_state_dict_roundtrip_and_no_grad_forward(tmp_path):
+    ref_bf, _, hip, latents, embs = _setup(dict(num_layers=1), 1, 4, 4, [3], 8)
+    sd = hip.state_dict()
+    assert set(sd) == set(ref_bf.state_dict())
+    for k, v in ref_bf.state_dict().items():
+        assert torch.equal(sd[k].cpu(), v), k
+    hip.save_pretrained(str(tmp_path / "m"))
+    from yat_amd.sana import SanaTransformer2DModelHIP
+    again = SanaTransformer2DModelHIP.from_pretrained(str(tmp_path / "m"), device=DEV)
+    assert torch.equal(again.flat_param, hip.flat_param)
+    with torch.no_grad():
+        enc = torch.zeros(1, 8, ref_bf.cfg.caption_channels, dtype=BF, device=DEV)
+        out = hip(latents.to(DEV), encoder_hidden_states=enc, timestep=torch.tensor([500.0]),
+                  encoder_attention_mask=torch.ones(1, 8, dtype=torch.long)).sample
+    assert out.shape == latents.shape and torch.isfinite(out.float()).all()
+
+
+def test_grad_accumulation_adds():
+    """Two micro-steps with accumulate_grads=True on the second must equal g1 + g2 (accelerator.accumulate)."""
+    from yat_amd.recipe import SanaRecipe
+    _, _, hip, latents, embs = _setup(dict(num_layers=1), 2, 4, 4, [5, 9], 16)
+    recipe = SanaRecipe(hip, pad_to=16, device=DEV)
+    recipe.optimize(latents, embs, torch.Generator()).backward()
+    g1 = hip.flat_grad.clone()
+    hip.accumulate_grads = True
+    recipe.optimize(latents, embs, torch.Generator()).backward()
+    hip.accumulate_grads = False
+    g2 = hip.flat_grad.float()
+    expect = (g1.float() * 2)
+    assert rel(g2, expect) <= 4e-3

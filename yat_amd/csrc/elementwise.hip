@@ -60,6 +60,21 @@ __global__ void timestep_embed_kernel(int B, int dim, const float* t, bf16_t* ou
     out[(int64_t)b * dim + half + j] = f2bf(sinf(arg));
 }
 
+// batched 2-D transpose through a padded LDS tile: in [B, R, Cc] -> out [B, Cc, R]
+// (NCHW latents <-> token-major rows for patch-embed / unpatchify, patched_sana_transformer.py:284,336-340)
+__global__ void transpose_kernel(int R, int Cc, const bf16_t* in, bf16_t* out) {
+    __shared__ bf16_t tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+    const bf16_t* ib = in + (int64_t)b * R * Cc;
+    bf16_t* ob = out + (int64_t)b * R * Cc;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < Cc) tile[k][tx] = ib[(int64_t)(r0 + k) * Cc + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < Cc && r0 + tx < R) ob[(int64_t)(c0 + k) * R + r0 + tx] = tile[tx][k];
+}
+
 // one wave per destination row: copy the source row or write zeros; lane 0 writes mask / bias
 __global__ void pad_mask_kernel(int B, int T, int C, const bf16_t* src, const int* offsets, bf16_t* dst, int64_t* mask,
                                 float* key_bias, int* kv_len) {
@@ -148,6 +163,13 @@ int yat_add_bf16(int64_t n, const void* a, const void* b, void* out, yat_stream_
 int yat_f32_to_bf16(int64_t n, const float* x, void* y, yat_stream_t stream) {
     if (n <= 0 || !x || !y) return YAT_EINVAL;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, x, (bf16_t*)y);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+int yat_transpose_bf16(int B, int R, int Cc, const void* in, void* out, yat_stream_t stream) {
+    if (B <= 0 || R <= 0 || Cc <= 0 || B > 65535 || !in || !out || in == out) return YAT_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, R, Cc,
+                       (const bf16_t*)in, (bf16_t*)out);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

@@ -200,10 +200,10 @@ extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* 
     hipStream_t stream = (hipStream_t)stream_;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return YAT_EINVAL;
     if ((N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return YAT_EINVAL;
-    if (a_t && !b_t) return YAT_EINVAL;                // TT-style (A m-contiguous, B k-contiguous) unused
     if (!a_t && (K & 7)) return YAT_EINVAL;            // 16-B chunks along k
     if (a_t && (M & 7)) return YAT_EINVAL;             // 16-B chunks along m
     if (b_t && (N & 7)) return YAT_EINVAL;
+    if (!b_t && (K & 7)) return YAT_EINVAL;
     GemmP p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -223,14 +223,16 @@ extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* 
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return YAT_EINVAL;
         attr_set = true;
     }
     dim3 grid(p.nbm * p.nbn), block(256);
     if (!a_t && !b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
     else if (!a_t && b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
+    else if (a_t && b_t) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, LDS_BYTES, stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

@@ -15,6 +15,10 @@ from . import lib as _l
 BF16 = torch.bfloat16
 ACT = {"none": 0, "silu": 1, "gelu_tanh": 2}
 
+# Optional live profiler for bench.py: when set to a list, every GEMM launch appends
+# (flops, start_event, end_event) recorded on the launch stream.
+GEMM_TIMER = None
+
 
 def _lib():
     return _l.load()
@@ -50,8 +54,15 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
     if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None:
         ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
                              ld_residual, rows_per_batch)
+    timer = GEMM_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib().yat_gemm_bf16(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
                               C.byref(ep) if ep is not None else None, _stream())
+    if timer is not None:
+        e1.record()
+        timer.append((2.0 * M * N * K, e0, e1))
     _l.check(rc, "yat_gemm_bf16")
     return out
 
@@ -229,6 +240,14 @@ def f32_to_bf16(x, y=None):
     y = y if y is not None else torch.empty(x.shape, dtype=BF16, device=x.device)
     _l.check(_lib().yat_f32_to_bf16(x.numel(), _p(x), _p(y), _stream()), "yat_f32_to_bf16")
     return y
+
+
+def transpose(x3d, out=None):
+    """yat_transpose_bf16: [B, R, C] -> [B, C, R]."""
+    B, R, Cc = x3d.shape
+    out = out if out is not None else torch.empty(B, Cc, R, dtype=BF16, device=x3d.device)
+    _l.check(_lib().yat_transpose_bf16(B, R, Cc, _p(x3d), _p(out), _stream()), "yat_transpose_bf16")
+    return out
 
 
 def timestep_embed(t_f32, dim=256, out=None):

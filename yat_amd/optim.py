@@ -1,0 +1,62 @@
+"""Fused clip + AdamW (+EMA) over the model's flat parameter buffer (C ABI: yat_gradnorm_clip, yat_adamw_step).
+
+Mirrors the optimizer section of the reference step loop (common/trainer.py:246-248,347-356):
+``clip_grad_norm_(max_norm=1.0)`` -> ``AdamW.step()`` -> ``EMAModel.step`` -> ``zero_grad()``, with torch's
+defaults (betas 0.9/0.999, eps 1e-8) and the states in the parameter dtype (bf16).  Everything stays on the
+device: the clip coefficient is a device scalar consumed by the AdamW kernel, so the step never syncs.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+class FlatAdamW:
+    def __init__(self, model, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, use_ema=False,
+                 ema_decay=0.999):
+        self.model = model
+        dev = model.flat_param.device
+        self.param_groups = [dict(lr=lr, initial_lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
+        self.max_grad_norm = max_grad_norm
+        self.exp_avg = torch.zeros_like(model.flat_param)
+        self.exp_avg_sq = torch.zeros_like(model.flat_param)
+        self.step_count = 0
+        self.seg_start = model.seg_start.to(dev)
+        nseg = self.seg_start.numel() - 1
+        self._ws = torch.empty(ops.gradnorm_workspace_bytes(model.numel_flat, nseg), dtype=torch.uint8, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.clip_coef = torch.ones(1, dtype=torch.float32, device=dev)
+        self.ema_shadow = model.flat_param.clone() if use_ema else None
+        self.ema_decay = ema_decay
+        self.ema_steps = 0
+
+    def _ema_decay_now(self):
+        """[RECALL] diffusers EMAModel.get_decay (use_ema_warmup=False): min(decay, (1+s)/(10+s)), 0 on the first call."""
+        step = max(0, self.ema_steps - 1)
+        if step <= 0:
+            return 0.0
+        return max(min((1 + step) / (10 + step), self.ema_decay), 0.0)
+
+    def step(self):
+        g = self.param_groups[0]
+        self.step_count += 1
+        m = self.model
+        coef = None
+        if self.max_grad_norm is not None:
+            ops.gradnorm_clip(m.flat_grad, self.seg_start, float(self.max_grad_norm), self.grad_norm, self.clip_coef,
+                              self._ws)
+            coef = self.clip_coef
+        ema_decay = 0.0
+        if self.ema_shadow is not None:
+            self.ema_steps += 1
+            ema_decay = self._ema_decay_now()
+        ops.adamw_step(m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, coef, g["lr"], g["betas"][0],
+                       g["betas"][1], g["eps"], g["weight_decay"], self.step_count, zero_grad=True,
+                       ema_shadow=self.ema_shadow, ema_decay=ema_decay)
+
+    def zero_grad(self, set_to_none=False):
+        # the gradient clear is fused into step(); explicit calls (e.g. before the first step) still work
+        self.model.flat_grad.zero_()

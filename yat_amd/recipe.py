@@ -1,0 +1,124 @@
+"""SANA flow-matching training recipe on the HIP path (``SanaModel.optimize``, train_sana.py:163-219).
+
+Reference op order, kept: pad text embeddings to 512 + mask (:168-180) -> noise in bf16 from the CPU
+generator (:183) -> logit-normal timestep indices (:185-193) -> sigmas (:195-204) ->
+noisy = (1-sigma) x + sigma n (:206-207) -> model (:210-215) -> target = n - x (:217) ->
+MSE in fp32 (:218).
+
+What changes on MI355X: the Python pad loop and its B small H2D copies become one pinned staging
+buffer, ONE H2D copy and one ``yat_pad_mask`` launch; ``get_sigmas``' B device->host syncs disappear
+(the index is known on the host); mix/target/loss(+dL/dpred) are two fused launches.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .scheduler import FlowMatchSchedule
+
+BF16 = torch.bfloat16
+
+
+class _MseLoss(torch.autograd.Function):
+    """mean((pred.float() - target.float())**2) with the gradient produced in the same launch."""
+
+    @staticmethod
+    def forward(ctx, pred, target, ws):
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        ops.mse_fwd_bwd(pred.contiguous(), target, loss, dpred, ws)
+        ctx.save_for_backward(dpred)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g.to(dpred.dtype), None, None
+
+
+class SanaRecipe:
+    def __init__(self, model, scheduler: FlowMatchSchedule | None = None, pad_to: int = 512, device="cuda"):
+        self.model = model
+        self.scheduler = scheduler or FlowMatchSchedule()
+        self.pad_to = pad_to
+        self.dev = torch.device(device)
+        self._mse_ws = torch.empty(256, dtype=torch.float32, device=self.dev)
+        self._pin = None
+        self.device_rng = None     # torch.Generator(device) for the throughput mode
+
+    # ---- text embeddings: ragged list -> padded [B, T, C] + mask/bias/kv_len on device (one H2D)
+    def pad_embeddings(self, embeddings):
+        B, T = len(embeddings), self.pad_to
+        C = embeddings[0].shape[1]
+        lens = [int(e.shape[0]) for e in embeddings]
+        if max(lens) > T:
+            raise ValueError(f"embedding longer than pad length {T}")
+        offs = [0]
+        for L in lens:
+            offs.append(offs[-1] + L)
+        if embeddings[0].is_cuda:
+            src = torch.cat([e.to(BF16) for e in embeddings])
+        else:
+            total = offs[-1]
+            if self._pin is None or self._pin.numel() < total * C:
+                self._pin = torch.empty(max(total * C, B * T * C), dtype=BF16).pin_memory()
+            stage = self._pin[: total * C].view(total, C)
+            torch.cat([e.to(BF16) for e in embeddings], out=stage)
+            src = stage.to(self.dev, non_blocking=True)
+        offsets = torch.tensor(offs, dtype=torch.int32).to(self.dev, non_blocking=True)
+        enc = torch.empty(B, T, C, dtype=BF16, device=self.dev)
+        mask = torch.empty(B, T, dtype=torch.int64, device=self.dev)
+        bias = torch.empty(B, T, dtype=torch.float32, device=self.dev)
+        kvl = torch.empty(B, dtype=torch.int32, device=self.dev)
+        ops.pad_mask(src, offsets, B, T, C, enc, mask, bias, kvl)
+        return enc, mask, bias, kvl
+
+    def draw(self, shape, generator):
+        """noise (bf16, drawn first), then timestep indices -- the reference's draw order.
+        ``generator`` None/CPU -> host draw exactly like the reference; a device generator draws on the GPU."""
+        B = shape[0]
+        if generator is not None and generator.device.type == "cuda":
+            noise = torch.randn(shape, generator=generator, device=self.dev, dtype=BF16)
+            cpu_gen = getattr(self, "_cpu_gen", None)
+            idx, t, sig = self.scheduler.sample(B, cpu_gen)
+        else:
+            noise = torch.randn(shape, generator=generator, device="cpu", dtype=BF16).to(self.dev, non_blocking=True)
+            idx, t, sig = self.scheduler.sample(B, generator)
+        return noise, t.to(self.dev, non_blocking=True), sig.to(self.dev, non_blocking=True)
+
+    def optimize(self, latents, embeddings, generator=None, return_pred=False):
+        """-> loss (0-dim fp32 tensor attached to the HIP autograd node)."""
+        enc, mask, bias, kvl = self.pad_embeddings(embeddings)
+        latents = latents.to(device=self.dev, dtype=BF16).contiguous()
+        noise, timesteps, sigmas = self.draw(latents.shape, generator)
+        noisy, target = ops.flow_mix(latents, noise, sigmas)
+        pred = self.model(noisy, encoder_hidden_states=enc, timestep=timesteps, encoder_attention_mask=mask).sample
+        loss = _MseLoss.apply(pred, target, self._mse_ws)
+        return (loss, pred, target) if return_pred else loss
+
+    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out):
+        """Graph-friendly straight-line step on device-resident inputs: forward, loss+dL/dpred, backward.
+        Used by bench.py and the trainer fast path (no autograd objects, no allocation besides pred)."""
+        bias, kvl = mask_bias_kvl
+        noisy, target = ops.flow_mix(latents, noise, sigmas, self._noisy(latents), self._target(latents))
+        pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl)
+        dpred = self._dpred(pred)
+        ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws)
+        self.model.backward_impl(dpred)
+        return loss_out
+
+    def _scratch(self, name, like):
+        t = getattr(self, name, None)
+        if t is None or t.shape != like.shape:
+            t = torch.empty_like(like)
+            setattr(self, name, t)
+        return t
+
+    def _noisy(self, like):
+        return self._scratch("_noisy_buf", like)
+
+    def _target(self, like):
+        return self._scratch("_target_buf", like)
+
+    def _dpred(self, like):
+        return self._scratch("_dpred_buf", like)

@@ -1,0 +1,513 @@
+"""SANA transformer on the HIP C-ABI: explicit forward and hand-scheduled backward.
+
+Mirrors ``SanaTransformer2DModel`` as the reference trains it
+(/root/reference/utils/patched_sana_transformer.py:88-167,229-349 and
+/root/reference/utils/patch_sana_attention_layers.py:19-115; called at train_sana.py:210-215):
+same call contract ``model(hidden_states, encoder_hidden_states=, timestep=, encoder_attention_mask=).sample``,
+same ``state_dict()`` keys (diffusers checkpoint layout), an ``nn.Module`` with
+``.parameters()``, ``.dtype``, ``enable_gradient_checkpointing()``.
+
+MI355X-first design rather than an autograd graph:
+
+* all parameters live in ONE flat bf16 HBM buffer in forward-execution order (gradients in a
+  second one, AdamW states in two more): the optimizer and the gradient-norm are single launches,
+  gradient buckets for the data-parallel all-reduce are contiguous slices that complete in
+  reverse order during backward (``grad_ready`` callback per bucket);
+* to_q/to_k/to_v (and attn2 to_k/to_v) sit back to back, so QKV is one [3D, D] GEMM while the
+  checkpoint still sees three tensors;
+* the token-major [B*N, C] layout is kept end to end (GLUMBConv's NCHW permutes vanish);
+* every activation the backward needs is kept (288 GB HBM: no gradient checkpointing, the
+  reference's recompute at train_sana.py:63 is unnecessary) in a persistent arena, so a step
+  allocates nothing;
+* forward/backward are straight-line sequences of C-ABI launches on the current HIP stream.
+
+Autograd integration: ``forward`` returns a tensor attached to a single autograd node whose
+backward runs :meth:`backward_impl` and writes parameter gradients straight into the flat
+gradient buffer (``p.grad`` are views of it).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, asdict
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class SanaConfig:
+    # defaults: utils/patched_sana_transformer.py:88-112 (SANA-1.6B)
+    in_channels: int = 32
+    out_channels: int = 32
+    num_attention_heads: int = 70
+    attention_head_dim: int = 32
+    num_layers: int = 20
+    num_cross_attention_heads: int = 20
+    cross_attention_head_dim: int = 112
+    cross_attention_dim: int = 2240
+    caption_channels: int = 2304
+    mlp_ratio: float = 2.5
+    sample_size: int = 32
+    patch_size: int = 1
+    norm_eps: float = 1e-6
+    modified_blocks: list = field(default_factory=list)
+
+    @property
+    def inner_dim(self):
+        return self.num_attention_heads * self.attention_head_dim
+
+    @property
+    def ffn_hidden(self):
+        return int(self.inner_dim * self.mlp_ratio)
+
+    def validate(self):
+        D = self.inner_dim
+        if self.attention_head_dim != 32:
+            raise ValueError("linear attention kernel is built for head dim 32 (SANA)")
+        if self.patch_size != 1:
+            raise ValueError("patch_size 1 only (SANA)")
+        if self.modified_blocks:
+            raise NotImplementedError("softmax self-attention blocks (modified_blocks) are not built yet")
+        if self.num_cross_attention_heads * self.cross_attention_head_dim != D or self.cross_attention_dim != D:
+            raise ValueError("cross attention inner dim must equal the model dim")
+        if D % 8 or self.ffn_hidden % 8 or self.caption_channels % 8 or self.in_channels % 8 or self.out_channels % 4:
+            raise ValueError("channel sizes must be multiples of 8 (16-byte vector accesses)")
+        if self.cross_attention_head_dim > 128 or self.cross_attention_head_dim % 8:
+            raise ValueError("cross attention head dim must be <= 128 and a multiple of 8")
+
+
+def _param_specs(cfg: SanaConfig):
+    """(diffusers key, shape) in forward-execution order."""
+    D, Hc, Cc = cfg.inner_dim, cfg.ffn_hidden, cfg.caption_channels
+    p = cfg.patch_size
+    specs = [
+        ("patch_embed.proj.weight", (D, cfg.in_channels, p, p)), ("patch_embed.proj.bias", (D,)),
+        ("time_embed.emb.timestep_embedder.linear_1.weight", (D, 256)),
+        ("time_embed.emb.timestep_embedder.linear_1.bias", (D,)),
+        ("time_embed.emb.timestep_embedder.linear_2.weight", (D, D)),
+        ("time_embed.emb.timestep_embedder.linear_2.bias", (D,)),
+        ("time_embed.linear.weight", (6 * D, D)), ("time_embed.linear.bias", (6 * D,)),
+        ("caption_projection.linear_1.weight", (D, Cc)), ("caption_projection.linear_1.bias", (D,)),
+        ("caption_projection.linear_2.weight", (D, D)), ("caption_projection.linear_2.bias", (D,)),
+        ("caption_norm.weight", (D,)),
+    ]
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}."
+        specs += [
+            (b + "scale_shift_table", (6, D)),
+            (b + "attn1.to_q.weight", (D, D)), (b + "attn1.to_k.weight", (D, D)), (b + "attn1.to_v.weight", (D, D)),
+            (b + "attn1.to_out.0.weight", (D, D)), (b + "attn1.to_out.0.bias", (D,)),
+            (b + "attn2.to_q.weight", (D, D)), (b + "attn2.to_q.bias", (D,)),
+            (b + "attn2.to_k.weight", (D, D)), (b + "attn2.to_v.weight", (D, D)),
+            (b + "attn2.to_k.bias", (D,)), (b + "attn2.to_v.bias", (D,)),
+            (b + "attn2.to_out.0.weight", (D, D)), (b + "attn2.to_out.0.bias", (D,)),
+            (b + "ff.conv_inverted.weight", (2 * Hc, D, 1, 1)), (b + "ff.conv_inverted.bias", (2 * Hc,)),
+            (b + "ff.conv_depth.weight", (2 * Hc, 1, 3, 3)), (b + "ff.conv_depth.bias", (2 * Hc,)),
+            (b + "ff.conv_point.weight", (D, Hc, 1, 1)),
+        ]
+    specs += [("scale_shift_table", (2, D)), ("proj_out.weight", (cfg.out_channels, D)),
+              ("proj_out.bias", (cfg.out_channels,))]
+    return specs
+
+
+class _Node(nn.Module):
+    """Anonymous container so parameter names can carry the diffusers dotted paths."""
+
+
+class _WholeModel(torch.autograd.Function):
+    """One autograd node for the whole transformer: backward = the hand-scheduled HIP backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, latents, enc, timestep, mask):
+        ctx.model = model
+        return model.forward_impl(latents, enc, timestep, mask)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.model.backward_impl(dout.contiguous())
+        return None, None, None, None, None, None
+
+
+class SanaTransformer2DModelHIP(nn.Module):
+    def __init__(self, cfg: SanaConfig | None = None, device="cuda", **cfg_kw):
+        super().__init__()
+        cfg = cfg or SanaConfig(**cfg_kw)
+        cfg.validate()
+        self.cfg = cfg
+        self.config = SimpleNamespace(**asdict(cfg))          # diffusers-style `.config.sample_size`
+        self.dev = torch.device(device)
+        specs = _param_specs(cfg)
+        offs, off = [], 0
+        for _, shape in specs:
+            offs.append(off)
+            off += (math.prod(shape) + 7) // 8 * 8            # 16-byte aligned segment starts
+        self.numel_flat = off
+        self.flat_param = torch.zeros(off, dtype=BF16, device=self.dev)
+        self.flat_grad = torch.zeros(off, dtype=BF16, device=self.dev)
+        self.seg_start = torch.tensor(offs + [off], dtype=torch.int64)     # host copy (true tensor extents)
+        self._seg_numel = [math.prod(s) for _, s in specs]
+        self.P, self.G = {}, {}
+        for (name, shape), o in zip(specs, offs):
+            n = math.prod(shape)
+            param = nn.Parameter(self.flat_param[o:o + n].view(shape))
+            param.grad = self.flat_grad[o:o + n].view(shape)
+            self._register(name, param)
+            self.P[name], self.G[name] = param.data, param.grad
+        self._offset = dict(zip([n for n, _ in specs], offs))
+        # bucket boundaries for data parallel reduction: head | one per block (+tail on the last)
+        self.bucket_bounds = self._make_buckets(specs, offs, off)
+        self.grad_ready = None            # callable(bucket_index) set by HipDDP
+        self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
+        self._arena = {}
+        self._saved = None
+        self._anchor = torch.zeros((), device=self.dev, requires_grad=True)
+        self.gradient_checkpointing = False
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            if not hasattr(mod, part):
+                mod.add_module(part, _Node())
+            mod = getattr(mod, part)
+        mod.register_parameter(parts[-1], param)
+
+    def _make_buckets(self, specs, offs, total):
+        names = [n for n, _ in specs]
+        starts = [0]
+        for i in range(self.cfg.num_layers):
+            starts.append(offs[names.index(f"transformer_blocks.{i}.scale_shift_table")])
+        bounds = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)] + [(starts[-1], total)]
+        return bounds        # bucket 0 = embedders; bucket i+1 = block i (last one also holds the output head)
+
+    @property
+    def dtype(self):
+        return BF16
+
+    @property
+    def device(self):
+        return self.dev
+
+    def enable_gradient_checkpointing(self):
+        """Accepted for drop-in compatibility (train_sana.py:63); all activations fit in 288 GB HBM,
+        so nothing is recomputed."""
+        self.gradient_checkpointing = True
+
+    def _apply(self, fn, *a, **k):
+        # parameters are views of flat device buffers; .to()/.cuda()/.bfloat16() must not re-materialise them
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        missing = [k for k in self.P if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self.P]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k in self.P:
+                    self.P[k].copy_(v.to(device=self.dev, dtype=BF16).view(self.P[k].shape))
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def init_synthetic(self, seed: int = 0):
+        """Deterministic random weights of the right scale (no checkpoints offline): weights ~ N(0, 1/fan_in),
+        small biases, scale/shift tables as the ctor of the reference draws them (randn / sqrt(D))."""
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.P.items():
+                if name == "caption_norm.weight":
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=self.dev))
+                elif "scale_shift_table" in name:
+                    p.copy_(torch.randn(p.shape, generator=g, device=self.dev) / p.shape[-1] ** 0.5)
+                elif p.ndim == 1:
+                    p.copy_(0.02 * torch.randn(p.shape, generator=g, device=self.dev))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g, device=self.dev) / math.sqrt(p[0].numel()))
+        return self
+
+    # ------------------------------------------------------------------ arena
+    def _buf(self, name, shape, dtype=BF16):
+        n = math.prod(shape)
+        t = self._arena.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+            self._arena[name] = t
+        return t[:n].view(shape)
+
+    def _fused(self, first_key, rows_total, cols=None):
+        """Contiguous view spanning consecutive parameter tensors (e.g. to_q|to_k|to_v -> [3D, D])."""
+        o = self._offset[first_key]
+        if cols is None:
+            return self.flat_param[o:o + rows_total], self.flat_grad[o:o + rows_total]
+        n = rows_total * cols
+        return self.flat_param[o:o + n].view(rows_total, cols), self.flat_grad[o:o + n].view(rows_total, cols)
+
+    # ------------------------------------------------------------------ public forward (reference call contract)
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, encoder_attention_mask=None,
+                return_dict=True, **unused):
+        if torch.is_grad_enabled():
+            out = _WholeModel.apply(self._anchor, self, hidden_states, encoder_hidden_states, timestep,
+                                    encoder_attention_mask)
+        else:
+            out = self.forward_impl(hidden_states, encoder_hidden_states, timestep, encoder_attention_mask)
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    # ------------------------------------------------------------------ forward
+    def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None):
+        cfg, P = self.cfg, self.P
+        D, Hc, H1, H2, dh2 = cfg.inner_dim, cfg.ffn_hidden, cfg.num_attention_heads, cfg.num_cross_attention_heads, \
+            cfg.cross_attention_head_dim
+        B, Cin, h, w = latents.shape
+        N, M = h * w, B * h * w
+        T = enc.shape[1]
+        Mt = B * T
+        Cout = cfg.out_channels
+        dev = self.dev
+        latents = latents.to(device=dev, dtype=BF16).contiguous()
+        enc2d = enc.to(device=dev, dtype=BF16).contiguous().view(Mt, -1)
+        t_f32 = timestep.to(device=dev, dtype=torch.float32).contiguous()
+        if key_bias is None:
+            # mask -> additive bias in bf16 as the reference does (patched_sana_transformer.py:275-277)
+            if mask is None:
+                key_bias = torch.zeros(B, T, dtype=torch.float32, device=dev)
+                kv_len = torch.full((B,), T, dtype=torch.int32, device=dev)
+            else:
+                mdev = mask.to(dev)
+                key_bias = ((1 - mdev.to(BF16)) * -10000.0).float().contiguous()
+                idx = torch.arange(1, T + 1, device=dev, dtype=torch.int32)
+                kv_len = (mdev.to(torch.int32) * idx).amax(dim=1).to(torch.int32).contiguous()
+        S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, key_bias=key_bias, kv_len=kv_len, enc2d=enc2d, blocks=[])
+        buf = self._buf
+
+        # 1. patch embed (1x1 conv == Linear over channels) on token-major rows
+        S.x_tok = ops.transpose(latents.view(B, Cin, N), buf("x_tok", (B, N, Cin))).view(M, Cin)
+        x = ops.linear_fwd(S.x_tok, P["patch_embed.proj.weight"].view(D, Cin), P["patch_embed.proj.bias"],
+                           out=buf("x0", (M, D)))
+        # 2. timestep embedding (AdaLayerNormSingle)
+        S.tproj = ops.timestep_embed(t_f32, 256, buf("tproj", (B, 256)))
+        S.z1 = buf("te_z1", (B, D))
+        S.e1 = ops.linear_fwd(S.tproj, P["time_embed.emb.timestep_embedder.linear_1.weight"],
+                              P["time_embed.emb.timestep_embedder.linear_1.bias"], out=buf("te_e1", (B, D)),
+                              activation="silu", aux_out=S.z1)
+        S.embedded = ops.linear_fwd(S.e1, P["time_embed.emb.timestep_embedder.linear_2.weight"],
+                                    P["time_embed.emb.timestep_embedder.linear_2.bias"], out=buf("te_emb", (B, D)))
+        S.se = ops.act_fwd(S.embedded, "silu", buf("te_se", (B, D)))
+        S.tmod = ops.linear_fwd(S.se, P["time_embed.linear.weight"], P["time_embed.linear.bias"],
+                                out=buf("te_tmod", (B, 6 * D)))
+        # 3. caption projection + RMSNorm
+        S.zc1 = buf("cap_z1", (Mt, D))
+        S.c1 = ops.linear_fwd(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
+                              out=buf("cap_c1", (Mt, D)), activation="gelu_tanh", aux_out=S.zc1)
+        S.c2 = ops.linear_fwd(S.c1, P["caption_projection.linear_2.weight"], P["caption_projection.linear_2.bias"],
+                              out=buf("cap_c2", (Mt, D)))
+        S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, buf("cap_n", (Mt, D)),
+                                             buf("cap_rstd", (Mt,), torch.float32))
+        la_ws = buf("la_ws", (ops.linear_attn_workspace_bytes(B, N, H1),), torch.uint8)
+        scale2 = 1.0 / math.sqrt(dh2)
+        # 4. transformer blocks
+        for i in range(cfg.num_layers):
+            pre = f"transformer_blocks.{i}."
+            A = SimpleNamespace(x_in=x)
+            A.mod = ops.modulation_fwd(P[pre + "scale_shift_table"], S.tmod, D, buf(f"b{i}.mod", (B, 6, D)))
+            mod2d = A.mod.view(B, 6 * D)
+            A.h1, A.mean1, A.rstd1 = ops.ln_modulate_fwd(
+                x, mod2d[:, 0:D], mod2d[:, D:2 * D], 6 * D, N, cfg.norm_eps, buf(f"b{i}.h1", (M, D)),
+                buf(f"b{i}.mean1", (M,), torch.float32), buf(f"b{i}.rstd1", (M,), torch.float32))
+            wqkv, _ = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
+            A.qkv = ops.linear_fwd(A.h1, wqkv, out=buf(f"b{i}.qkv", (M, 3 * D)))
+            A.attn = ops.linear_attn_fwd(A.qkv, B, N, H1, D, 2 * D, buf(f"b{i}.attn", (M, D)), la_ws)
+            A.lin1 = buf(f"b{i}.lin1", (M, D))
+            A.x1 = ops.linear_fwd(A.attn, P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"],
+                                  out=buf(f"b{i}.x1", (M, D)), aux_out=A.lin1, gate=mod2d[:, 2 * D:3 * D],
+                                  ld_gate=6 * D, residual=x, rows_per_batch=N)
+            A.q2 = ops.linear_fwd(A.x1, P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"],
+                                  out=buf(f"b{i}.q2", (M, D)))
+            wkv, _ = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
+            bkv, _ = self._fused(pre + "attn2.to_k.bias", 2 * D)
+            A.kv2 = ops.linear_fwd(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D)))
+            A.o2 = buf(f"b{i}.o2", (M, D))
+            A.lse = buf(f"b{i}.lse", (B, H2, N), torch.float32)
+            ops.sdpa_fwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, key_bias, kv_len, A.o2, A.lse)
+            A.x2 = ops.linear_fwd(A.o2, P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"],
+                                  out=buf(f"b{i}.x2", (M, D)), residual=A.x1)
+            A.h2, A.mean2, A.rstd2 = ops.ln_modulate_fwd(
+                A.x2, mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, buf(f"b{i}.h2", (M, D)),
+                buf(f"b{i}.mean2", (M,), torch.float32), buf(f"b{i}.rstd2", (M,), torch.float32))
+            A.z = ops.linear_fwd(A.h2, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D),
+                                 P[pre + "ff.conv_inverted.bias"], out=buf(f"b{i}.z", (M, 2 * Hc)))
+            A.y = ops.dwconv_glu_fwd(A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
+                                     P[pre + "ff.conv_depth.bias"], buf(f"b{i}.y", (M, Hc)))
+            A.lin3 = buf(f"b{i}.lin3", (M, D))
+            x = ops.linear_fwd(A.y, P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=buf(f"b{i}.x3", (M, D)),
+                               aux_out=A.lin3, gate=mod2d[:, 5 * D:6 * D], ld_gate=6 * D, residual=A.x2,
+                               rows_per_batch=N)
+            S.blocks.append(A)
+        # 5. output head: modulated norm + proj_out + unpatchify
+        S.x_last = x
+        S.modf = ops.modulation_fwd(P["scale_shift_table"], S.embedded, 0, buf("modf", (B, 2, D)))
+        modf2d = S.modf.view(B, 2 * D)
+        S.hf, S.meanf, S.rstdf = ops.ln_modulate_fwd(x, modf2d[:, 0:D], modf2d[:, D:2 * D], 2 * D, N, 1e-6,
+                                                     buf("hf", (M, D)), buf("meanf", (M,), torch.float32),
+                                                     buf("rstdf", (M,), torch.float32))
+        out_tok = ops.linear_fwd(S.hf, P["proj_out.weight"], P["proj_out.bias"], out=buf("out_tok", (M, Cout)))
+        pred = ops.transpose(out_tok.view(B, N, Cout), torch.empty(B, Cout, N, dtype=BF16, device=dev))
+        self._saved = S
+        return pred.view(B, Cout, h, w)
+
+    # ------------------------------------------------------------------ backward
+    def backward_impl(self, dpred):
+        S = self._saved
+        if S is None:
+            raise RuntimeError("backward_impl called without a saved forward")
+        cfg, P, G = self.cfg, self.P, self.G
+        D, Hc, H1, H2, dh2 = cfg.inner_dim, cfg.ffn_hidden, cfg.num_attention_heads, cfg.num_cross_attention_heads, \
+            cfg.cross_attention_head_dim
+        B, h, w, N, M, T, Mt = S.B, S.h, S.w, S.N, S.M, S.T, S.Mt
+        Cout, Cin = cfg.out_channels, cfg.in_channels
+        acc = self.accumulate_grads
+        buf = self._buf
+        f32, u8 = torch.float32, torch.uint8
+        ws_col = buf("ws_col", (int(ops._lib().yat_colsum_workspace_bytes(max(M, Mt), max(2 * Hc, 6 * D, 3 * D))),), u8)
+        ws_ln = buf("ws_ln", (ops.ln_bwd_workspace_bytes(M, D, N),), u8)
+        ws_gate = buf("ws_gate", (int(ops._lib().yat_gate_bwd_workspace_bytes(M, D, N)),), u8)
+        ws_dw = buf("ws_dw", (ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc),), u8)
+        la_ws = buf("la_ws", (ops.linear_attn_workspace_bytes(B, N, H1),), u8)
+        scale2 = 1.0 / math.sqrt(dh2)
+
+        def wgrad(dy, x, key, shape2d):
+            ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
+
+        def bgrad(dy, key):
+            ops.colsum(dy, G[key], ws_col, accumulate=acc)
+
+        # ---- output head
+        d_out_tok = ops.transpose(dpred.to(BF16).contiguous().view(B, Cout, N), buf("d_out_tok", (B, N, Cout))).view(M, Cout)
+        wgrad(d_out_tok, S.hf, "proj_out.weight", (Cout, D))
+        bgrad(d_out_tok, "proj_out.bias")
+        dhf = ops.linear_dgrad(d_out_tok, P["proj_out.weight"], out=buf("dh", (M, D)))
+        dmodf = buf("dmodf", (B, 2, D), f32).zero_()
+        dtmod = buf("dtmod", (B, 6 * D), f32).zero_()
+        demb = buf("demb", (B, D), f32).zero_()
+        dxa, dxb = buf("dx_a", (M, D)), buf("dx_b", (M, D))
+        dmodf2d = dmodf.view(B, 2 * D)
+        dx = ops.ln_modulate_bwd(S.x_last, S.meanf, S.rstdf, S.modf.view(B, 2 * D)[:, D:2 * D], 2 * D, N, dhf, None, dxa,
+                                 dmodf2d[:, 0:D], dmodf2d[:, D:2 * D], 2 * D, ws_ln)
+        ops.modulation_bwd(dmodf, G["scale_shift_table"], demb, 0, accumulate_table=acc)
+        denc = buf("denc", (Mt, D))
+        # ---- blocks, last to first
+        for i in reversed(range(cfg.num_layers)):
+            pre = f"transformer_blocks.{i}."
+            A = S.blocks[i]
+            mod2d = A.mod.view(B, 6 * D)
+            dmod = buf("dmod", (B, 6, D), f32).zero_()
+            dmod2d = dmod.view(B, 6 * D)
+            # x3 = x2 + gate_mlp * lin3
+            dlin = buf("dlin", (M, D))
+            ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
+            wgrad(dlin, A.y, pre + "ff.conv_point.weight", (D, Hc))
+            dy = ops.linear_dgrad(dlin, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
+            dz = buf("dz", (M, 2 * Hc))
+            ops.dwconv_glu_bwd(A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
+                               P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
+                               G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc)
+            wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D))
+            bgrad(dz, pre + "ff.conv_inverted.bias")
+            dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf("dh", (M, D)))
+            other = dxb if dx is dxa else dxa
+            dx2 = ops.ln_modulate_bwd(A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2_, dx, other,
+                                      dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln)
+            # x2 = x1 + to_out(o2)
+            wgrad(dx2, A.o2, pre + "attn2.to_out.0.weight", (D, D))
+            bgrad(dx2, pre + "attn2.to_out.0.bias")
+            do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf("dh", (M, D)))
+            dq2 = buf("dq2", (M, D))
+            dkv2 = buf("dkv2", (Mt, 2 * D))
+            delta = buf("delta", (B, H2, N), f32)
+            ops.sdpa_bwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse,
+                         delta, dq2, dkv2[:, :D], dkv2[:, D:])
+            wgrad(dq2, A.x1, pre + "attn2.to_q.weight", (D, D))
+            bgrad(dq2, pre + "attn2.to_q.bias")
+            dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=dx2, residual=dx2)      # dx1 = dx2 + dq2 Wq
+            wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
+            _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
+            ops.linear_wgrad(dkv2, S.encn, gkv, accumulate=acc)
+            ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
+            ops.linear_dgrad(dkv2, wkv, out=denc, residual=None if i == cfg.num_layers - 1 else denc)
+            # x1 = x + gate_msa * lin1
+            ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate)
+            wgrad(dlin, A.attn, pre + "attn1.to_out.0.weight", (D, D))
+            bgrad(dlin, pre + "attn1.to_out.0.bias")
+            dattn = ops.linear_dgrad(dlin, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
+            dqkv = buf("dqkv", (M, 3 * D))
+            ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws)
+            wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
+            ops.linear_wgrad(dqkv, A.h1, gqkv, accumulate=acc)
+            dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf("dh", (M, D)))
+            other = dxb if dx1 is dxa else dxa
+            dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1, dx1, other,
+                                     dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln)
+            ops.modulation_bwd(dmod, G[pre + "scale_shift_table"], dtmod, D, accumulate_table=acc)
+            if self.grad_ready is not None:
+                self.grad_ready(i + 1)
+        # ---- embedders
+        wgrad(dx, S.x_tok, "patch_embed.proj.weight", (D, Cin))
+        bgrad(dx, "patch_embed.proj.bias")
+        # caption branch
+        dc2 = buf("dc2", (Mt, D))
+        ws_rms = buf("ws_rms", (int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(Mt, D)),), u8)
+        ops.rmsnorm_bwd(S.c2, P["caption_norm.weight"], S.enc_rstd, denc, dc2, G["caption_norm.weight"], ws_rms,
+                        accumulate_dw=acc)
+        wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D))
+        bgrad(dc2, "caption_projection.linear_2.bias")
+        dc1 = ops.linear_dgrad(dc2, P["caption_projection.linear_2.weight"], out=denc)
+        dzc1 = ops.act_bwd(S.zc1, dc1, "gelu_tanh", dc2)
+        wgrad(dzc1, S.enc2d, "caption_projection.linear_1.weight", (D, cfg.caption_channels))
+        bgrad(dzc1, "caption_projection.linear_1.bias")
+        # timestep branch
+        dtmod_b = ops.f32_to_bf16(dtmod, buf("dtmod_b", (B, 6 * D)))
+        wgrad(dtmod_b, S.se, "time_embed.linear.weight", (6 * D, D))
+        bgrad(dtmod_b, "time_embed.linear.bias")
+        dse = ops.linear_dgrad(dtmod_b, P["time_embed.linear.weight"], out=buf("te_d1", (B, D)))
+        demb_a = ops.act_bwd(S.embedded, dse, "silu", buf("te_d2", (B, D)))
+        demb_b = ops.f32_to_bf16(demb, buf("te_d3", (B, D)))
+        d_emb = ops.add_bf16(demb_a, demb_b, buf("te_d1", (B, D)))
+        wgrad(d_emb, S.e1, "time_embed.emb.timestep_embedder.linear_2.weight", (D, D))
+        bgrad(d_emb, "time_embed.emb.timestep_embedder.linear_2.bias")
+        de1 = ops.linear_dgrad(d_emb, P["time_embed.emb.timestep_embedder.linear_2.weight"], out=buf("te_d2", (B, D)))
+        dz1 = ops.act_bwd(S.z1, de1, "silu", buf("te_d3", (B, D)))
+        wgrad(dz1, S.tproj, "time_embed.emb.timestep_embedder.linear_1.weight", (D, 256))
+        bgrad(dz1, "time_embed.emb.timestep_embedder.linear_1.bias")
+        if self.grad_ready is not None:
+            self.grad_ready(0)
+
+    # ------------------------------------------------------------------ checkpoint I/O (diffusers layout)
+    def save_pretrained(self, path):
+        import json
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        save_file(sd, os.path.join(path, "diffusion_pytorch_model.safetensors"))
+        cfgd = asdict(self.cfg)
+        cfgd.update({"_class_name": "SanaTransformer2DModel", "cross_attention_dim": self.cfg.cross_attention_dim,
+                     "attention_bias": False, "dropout": 0.0, "norm_elementwise_affine": False,
+                     "interpolation_scale": None})
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(cfgd, f, indent=2)
+
+    @classmethod
+    def from_pretrained(cls, path, device="cuda", **_):
+        import json
+        import os
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            raw = json.load(f)
+        known = {k: raw[k] for k in SanaConfig.__dataclass_fields__ if k in raw}
+        model = cls(SanaConfig(**known), device=device)
+        model.load_state_dict(load_file(os.path.join(path, "diffusion_pytorch_model.safetensors")))
+        return model
