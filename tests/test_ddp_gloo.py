@@ -1,0 +1,74 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercising the bucketed gradient reduction, the parameter
+broadcast, and the bucket sampler's one-exchange-per-batch consensus."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FlatModel:
+    """The attributes HipDDP needs from SanaTransformer2DModelHIP, on CPU."""
+
+    def __init__(self, n, bounds):
+        self.flat_param = torch.zeros(n, dtype=torch.float32)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32)
+        self.bucket_bounds = bounds
+        self.grad_ready = None
+
+
+def _ddp_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yat_amd.ddp import HipDDP
+    m = _FlatModel(100, [(0, 30), (30, 70), (70, 100)])
+    m.flat_param += rank + 1
+    ddp = HipDDP(m)
+    ddp.broadcast_parameters()
+    assert torch.all(m.flat_param == 1)                       # rank 0's weights everywhere
+    m.flat_grad[:] = torch.arange(100, dtype=torch.float32) * (rank + 1)
+    for i in (2, 1, 0):                                       # backward order: last bucket first
+        m.grad_ready(i)
+    ddp.wait()
+    assert torch.allclose(m.flat_grad, torch.arange(100, dtype=torch.float32) * 1.5)       # mean over 2 ranks
+    # no_sync (gradient accumulation): nothing is reduced
+    ddp.sync = False
+    m.flat_grad[:] = rank
+    m.grad_ready(0)
+    ddp.wait()
+    assert torch.all(m.flat_grad == rank)
+    t = ddp.all_reduce_scalar_mean(torch.tensor([float(rank)]))
+    assert t.item() == 0.5
+
+    # bucket sampler consensus: both ranks must yield the same ratio at every step
+    from tests.test_host_logic import _make_shards
+    from yat_amd.common.aspect_ratios import ASPECT_RATIO_1024_BIN
+    from yat_amd.common.bucket_sampler import BucketSampler
+    from yat_amd.common.trainer import HipAccelerator
+    import pathlib
+    paths = _make_shards(pathlib.Path(tmp) / f"r{rank}", 2, 30, seed=rank)
+    model = type("M", (), {"aspect_ratios": ASPECT_RATIO_1024_BIN})()
+    acc = HipAccelerator(1, device="cpu")
+    it = iter(BucketSampler([], acc, batch_size=3, model=model, seed=5, local_paths=paths))
+    for _ in range(8):
+        b = next(it)
+        r = torch.tensor([b.ratio])
+        both = [torch.zeros(1), torch.zeros(1)]
+        dist.all_gather(both, r)
+        assert both[0].item() == both[1].item()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo(tmp_path):
+    for r in range(2):
+        (tmp_path / f"r{r}").mkdir()
+    mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

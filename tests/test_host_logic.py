@@ -1,0 +1,123 @@
+"""Host-side logic that needs no GPU: schedule, LR warm-up, shard format, bucket sampler, model parameter layout,
+FLOP accounting."""
+import os
+
+import pytest
+import torch
+
+from yat_amd.common.aspect_ratios import ASPECT_RATIO_1024_BIN, ASPECT_RATIO_512_BIN, table_for_resolution
+from yat_amd.common.bucket_sampler import BucketSampler
+from yat_amd.common.shards import read_shard, write_shard
+from yat_amd.common.trainer import HipAccelerator, WarmupLR
+from yat_amd.scheduler import FlowMatchSchedule
+
+
+def test_schedule_equals_oracle_tables():
+    from oracle.recipe_ref import FlowMatchSchedule as Ref, draw_recipe_randoms
+    a, b = FlowMatchSchedule(shift=3.0), Ref(shift=3.0)
+    assert torch.equal(a.sigmas, b.sigmas) and torch.equal(a.timesteps, b.timesteps)
+    # same draws as the oracle when the noise is drawn first (reference order)
+    g1, g2 = torch.Generator(), torch.Generator()
+    torch.randn((4, 8, 4, 4), generator=g1, dtype=torch.bfloat16)
+    idx, t, sig = a.sample(4, g1)
+    _, ridx, rt, rsig = draw_recipe_randoms((4, 8, 4, 4), 4, b, g2)
+    assert torch.equal(idx, ridx) and torch.equal(t, rt) and torch.equal(sig, rsig)
+
+
+def test_warmup_matches_torch_lambdalr():
+    class Opt:
+        param_groups = [dict(lr=1e-3, initial_lr=1e-3)]
+    w = WarmupLR(Opt(), 4)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-3)
+    ref = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: s / 4 if s < 4 else 1.0)
+    for _ in range(7):
+        assert abs(w.get_last_lr()[0] - ref.get_last_lr()[0]) < 1e-12
+        opt.step()
+        ref.step()
+        w.step()
+
+
+def test_aspect_tables():
+    assert ASPECT_RATIO_1024_BIN["1.0"] == [1024.0, 1024.0] and len(ASPECT_RATIO_1024_BIN) == 33
+    assert ASPECT_RATIO_512_BIN["0.25"] == [256.0, 1024.0]
+    assert table_for_resolution(1024) is ASPECT_RATIO_1024_BIN
+    for k, (h, w) in ASPECT_RATIO_1024_BIN.items():
+        assert h % 32 == 0 and w % 32 == 0 and abs(h / w - float(k)) < 0.02
+
+
+def _make_shards(tmp_path, n_shards=2, per=24, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ratios = ["1.0", "0.5", "2.0"]
+    paths = []
+    for s in range(n_shards):
+        samples = []
+        for i in range(per):
+            r = ratios[(i + s) % 3]
+            H, W = ASPECT_RATIO_1024_BIN[r]
+            L = int(torch.randint(1, 20, (1,), generator=g))
+            samples.append(dict(__key__=f"{s:03d}{i:05d}", ratio=r,
+                                latent=torch.randn(8, int(H) // 256, int(W) // 256, generator=g).to(torch.bfloat16),
+                                emb=torch.randn(L, 16, generator=g).to(torch.bfloat16)))
+        p = str(tmp_path / f"shard-{s:06d}.tar")
+        write_shard(p, samples)
+        paths.append(p)
+    return paths
+
+
+def test_shard_roundtrip(tmp_path):
+    paths = _make_shards(tmp_path, 1, 5)
+    out = list(read_shard(paths[0]))
+    assert len(out) == 5
+    assert out[0]["ratio"] in (1.0, 0.5, 2.0) and out[0]["latent.pt"].dtype == torch.bfloat16
+    assert out[0]["emb.pt"].shape[1] == 16
+
+
+def test_bucket_sampler_single_process(tmp_path):
+    paths = _make_shards(tmp_path)
+    model = type("M", (), {"aspect_ratios": ASPECT_RATIO_1024_BIN})()
+    acc = HipAccelerator(1, device="cpu")
+    s = BucketSampler([], acc, batch_size=4, model=model, seed=3, local_paths=paths)
+    it = iter(s)
+    seen = set()
+    for _ in range(12):
+        b = next(it)
+        assert b.vae_features.shape[0] == 4 and len(b.embeddings) == 4
+        H, W = ASPECT_RATIO_1024_BIN[str(b.ratio)]
+        assert tuple(b.vae_features.shape[2:]) == (int(H) // 256, int(W) // 256)      # one ratio per batch
+        seen.add(b.ratio)
+    assert seen == {1.0, 0.5, 2.0}
+    # deterministic for a given seed
+    s2 = BucketSampler([], acc, batch_size=4, model=model, seed=3, local_paths=paths)
+    b1, b2 = next(iter(BucketSampler([], acc, 4, model=model, seed=3, local_paths=paths))), next(iter(s2))
+    assert b1.ratio == b2.ratio and torch.equal(b1.vae_features, b2.vae_features)
+
+
+def test_model_parameter_layout_on_cpu():
+    """Construction, state-dict keys and bucket bounds need no GPU (compute does)."""
+    from oracle.sana_ref import SanaConfig as RC, SanaTransformerRef
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    rc = RC.tiny()
+    ref = SanaTransformerRef(rc)
+    m = SanaTransformer2DModelHIP(SanaConfig(**{k: getattr(rc, k) for k in SanaConfig.__dataclass_fields__}), device="cpu")
+    sd, rsd = m.state_dict(), ref.state_dict()
+    assert set(sd) == set(rsd)
+    assert all(sd[k].shape == rsd[k].shape for k in sd)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in rsd.items()})
+    assert torch.equal(m.state_dict()["proj_out.bias"], rsd["proj_out.bias"].to(torch.bfloat16))
+    # to_q | to_k | to_v are contiguous in the flat buffer (one fused QKV GEMM)
+    D = rc.inner_dim
+    w, _ = m._fused("transformer_blocks.0.attn1.to_q.weight", 3 * D, D)
+    assert torch.equal(w[D:2 * D], m.P["transformer_blocks.0.attn1.to_k.weight"])
+    assert m.bucket_bounds[0][0] == 0 and m.bucket_bounds[-1][1] == m.numel_flat
+    assert all(a[1] == b[0] for a, b in zip(m.bucket_bounds, m.bucket_bounds[1:]))
+    assert all(p.grad is not None and p.grad.data_ptr() >= m.flat_grad.data_ptr() for p in m.parameters())
+    with pytest.raises(Exception):            # the product path fails loudly without a GPU: no CPU fallback
+        m(torch.zeros(1, 8, 4, 4), encoder_hidden_states=torch.zeros(1, 8, 96), timestep=torch.zeros(1))
+
+
+def test_flop_accounting_matches_survey():
+    import bench
+    from yat_amd.sana import SanaConfig
+    f = bench.train_flops_per_image(SanaConfig(), 1024, 512)
+    assert abs(f / 9.285e12 - 1) < 2e-3                 # 9.285 TFLOP / image

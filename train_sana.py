@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""SANA trainer entry point -- same CLI as the reference (`train_sana.py --config config.yaml`, README.md:45,
+train_sana.py:221-237), driving the MI355X-native hot path.
+
+    python train_sana.py --config config.yaml                      # 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_sana.py --config config.yaml
+
+``pretrained_model_path`` (or ``pretrained_pipe_path``/transformer) must be a LOCAL diffusers directory
+(config.json + diffusion_pytorch_model.safetensors); with neither present the 1.6B architecture is random-initialised
+(there is no network here).  Feature extraction (VAE / text encoder, ``extract_features`` / ``compute_features``) and
+validation image sampling are outside the hot-path scope: training consumes cached-feature shards.
+"""
+import argparse
+import json
+import os
+
+import torch
+
+from yat_amd.common.training_parameters_reader import TrainingParameters
+from yat_amd.common.trainer import Model
+from yat_amd.common.aspect_ratios import table_for_resolution
+from yat_amd.recipe import SanaRecipe
+from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+from yat_amd.scheduler import FlowMatchSchedule
+
+
+class SanaModel(Model):
+    def __init__(self, params: TrainingParameters, accelerator=None, config: SanaConfig | None = None):
+        super().__init__(params, accelerator)
+        dev = self.accelerator.device
+        path = params.pretrained_model_path
+        if path is None and params.pretrained_pipe_path and os.path.isdir(os.path.join(params.pretrained_pipe_path, "transformer")):
+            path = os.path.join(params.pretrained_pipe_path, "transformer")
+        if path is not None and os.path.isdir(path):
+            self.model = SanaTransformer2DModelHIP.from_pretrained(path, device=dev)          # train_sana.py:20-23
+        else:
+            self.model = SanaTransformer2DModelHIP(config or SanaConfig(), device=dev).init_synthetic(0)
+        shift = 3.0
+        sched_cfg = os.path.join(params.pretrained_pipe_path or "", "scheduler", "scheduler_config.json")
+        if os.path.isfile(sched_cfg):                                                          # :41
+            with open(sched_cfg) as f:
+                shift = float(json.load(f).get("shift", shift))
+        self.scheduler = FlowMatchSchedule(shift=shift)
+        vae_compression = 32                                                                   # :45-57
+        self.aspect_ratios = table_for_resolution(self.model.config.sample_size * vae_compression)
+        self.model.enable_gradient_checkpointing()                                             # :63 (no-op here)
+        self.recipe = SanaRecipe(self.model, self.scheduler, pad_to=512, device=dev)
+        self.pipe = None
+
+    def extract_latents(self, images):
+        raise NotImplementedError("VAE encoding is outside the hot-path scope; train from cached-feature shards")
+
+    def extract_embeddings(self, captions):
+        raise NotImplementedError("text encoding is outside the hot-path scope; train from cached-feature shards")
+
+    def optimize(self, ratio, latents, embeddings, repa_tokens, generator: torch.Generator = None):
+        """train_sana.py:163-219 on the HIP path (yat_amd.recipe.SanaRecipe.optimize)."""
+        return self.recipe.optimize(latents, embeddings, generator)
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", required=True, type=str)
+    parser.add_argument("--max-steps", type=int, default=None)
+    args = parser.parse_args()
+    params = TrainingParameters()
+    params.read_yaml(args.config)
+    if params.extract_features:
+        raise SystemExit("extract_features (VAE/text-encoder feature extraction) is outside this build's scope")
+    trainer = SanaModel(params)
+    trainer.run(max_steps=args.max_steps)

@@ -1,0 +1,294 @@
+"""Trainer core: the reference's ``Model`` base class and step loop (common/trainer.py:25-407) on the HIP path.
+
+Same subclass contract (hooks ``extract_latents``, ``extract_embeddings``, ``validate``, ``optimize(ratio, latents,
+embeddings, repa_tokens, generator)``, ``save_model``; attributes ``model``, ``scheduler``, ``aspect_ratios``,
+``params``, ``accelerator``) and the same step semantics (per-batch CFG dropout :319-323, fresh generator per step
+:325, exploration steps :326-336, accumulate/no_sync :317, clip 1.0 :347, AdamW :348, EMA :350-351, LR warm-up
+:255-262,353-354, zero_grad :356, loss = cross-rank mean of the SUM of micro-losses :343,359-360, validate/save
+cadence :371-401).
+
+What is different (MI355X-first, documented in DESIGN.md):
+* ``HipAccelerator`` replaces HuggingFace Accelerate: one process per GPU from the launcher's env, RCCL process group
+  with xGMI P2P left ENABLED (the reference disables it, :27-28 -- right for its dual consumer GPUs, wrong here);
+* DDP is ``yat_amd.ddp.HipDDP`` (flat bucketed all-reduce overlapped with backward), clip+AdamW+EMA+zero_grad are
+  one fused launch pair, so ``clip_grad_norm_`` is a no-op hook here;
+* logging keeps the loss on the device until it is actually written (no per-step ``.item()`` stall unless a logger
+  is attached).
+PEFT adapters, dual-GPU mode, Dreambooth, REPA and DeepSpeed are out of scope.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import random
+from datetime import timedelta
+
+import torch
+import torch.distributed as dist
+
+from ..ddp import HipDDP
+from ..optim import FlatAdamW
+from .aspect_ratios import ASPECT_RATIO_1024_BIN, ASPECT_RATIO_512_BIN
+
+
+class HipAccelerator:
+    """The slice of accelerate.Accelerator the reference trainer touches, natively."""
+
+    def __init__(self, gradient_accumulation_steps=1, device=None, backend=None, timeout_s=3600):
+        self.gradient_accumulation_steps = int(gradient_accumulation_steps or 1)
+        self.process_index = int(os.environ.get("RANK", "0"))
+        self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if device is None:
+            device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        if self.num_processes > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
+            dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s))
+        self.is_main_process = self.process_index == 0
+        self.sync_gradients = True
+        self._micro = 0
+        self.ddp = None
+        self.state = type("State", (), {"deepspeed_plugin": None})()
+
+    # -- accelerate surface
+    def prepare(self, *objs):
+        for o in objs:
+            if hasattr(o, "flat_grad") and hasattr(o, "bucket_bounds"):
+                self.ddp = HipDDP(o)
+                self.ddp.broadcast_parameters()
+        return objs if len(objs) != 1 else objs[0]
+
+    def unwrap_model(self, model):
+        return model
+
+    @contextlib.contextmanager
+    def accumulate(self, model):
+        self._micro += 1
+        self.sync_gradients = (self._micro % self.gradient_accumulation_steps) == 0
+        model.accumulate_grads = (self._micro % self.gradient_accumulation_steps) != 1 and \
+            self.gradient_accumulation_steps > 1
+        if self.ddp is not None:
+            self.ddp.sync = self.sync_gradients
+        yield
+
+    def backward(self, loss):
+        (loss / self.gradient_accumulation_steps if self.gradient_accumulation_steps > 1 else loss).backward()
+        if self.ddp is not None and self.sync_gradients:
+            self.ddp.wait()
+
+    def clip_grad_norm_(self, parameters, max_norm):
+        return None        # fused into FlatAdamW.step (yat_gradnorm_clip + yat_adamw_step)
+
+    def gather(self, t):
+        if self.num_processes == 1:
+            return t.reshape(1)
+        out = [torch.empty_like(t) for _ in range(self.num_processes)]
+        dist.all_gather(out, t)
+        return torch.stack(out)
+
+    def reduce(self, t, reduction="mean"):
+        if self.num_processes > 1:
+            dist.all_reduce(t)
+            if reduction == "mean":
+                t = t / self.num_processes
+        return t
+
+    def wait_for_everyone(self):
+        if self.num_processes > 1:
+            dist.barrier()
+
+
+class Model:
+    def __init__(self, params, accelerator: HipAccelerator | None = None):
+        # NCCL_P2P_DISABLE / NCCL_IB_DISABLE of the reference (:27-28) are deliberately NOT set: xGMI needs P2P.
+        self.accelerator = accelerator or HipAccelerator(params.gradient_accumulation_steps)
+        self.params = params
+        self.process_index = self.accelerator.process_index
+        self.num_processes = self.accelerator.num_processes
+        self.timesteps = [int(t) for t in params.timesteps]
+        if self.timesteps:                                   # :51-64 timestep whitelist
+            def get_timesteps_from_list(batch_size):
+                idx = [random.choice(self.timesteps) for _ in range(batch_size)]
+                return self.scheduler.timesteps[idx].to(self.accelerator.device)
+            self.get_timesteps = get_timesteps_from_list
+        # per-rank shard range (:66-84)
+        n = params.num_shards
+        if getattr(params, "dreambooth_dataset_folder", None) is None and n is not None and n >= self.num_processes:
+            per = n // self.num_processes
+            self.shard_index_begin = self.process_index * per
+            self.shard_index_end = n if self.process_index == self.num_processes - 1 else self.shard_index_begin + per
+        else:
+            self.shard_index_begin, self.shard_index_end = 0, (n or 0)
+        self.global_step = 0
+        self.logger = None
+        self.sampler = None
+        self.optimizer = None
+        self.lr_scheduler = None
+        self.ema_model = None
+        self.empty_embeddings = None
+
+    # ---- hooks of the subclass contract (:93-107,122-124,283-296)
+    def extract_latents(self, images):
+        raise NotImplementedError
+
+    def extract_embeddings(self, captions):
+        raise NotImplementedError
+
+    def format_embeddings(self, embeds):
+        pass
+
+    def validate(self):
+        raise NotImplementedError
+
+    def optimize(self, ratio, latents, embeddings, repa_tokens, generator):
+        raise NotImplementedError
+
+    def enable_efficient_attention(self):
+        pass            # attention kernels are always the HIP ones
+
+    def finalize(self):
+        pass
+
+    def get_timesteps(self, batch_size):
+        """:96-101 -- logit-normal indices from the GLOBAL torch RNG -> scheduler.timesteps."""
+        u = torch.sigmoid(torch.normal(mean=0.0, std=1.0, size=(batch_size,)))
+        idx = (u * self.scheduler.config.num_train_timesteps).long()
+        return self.scheduler.timesteps[idx].to(self.accelerator.device)
+
+    def find_closest_ratio(self, ratio):
+        best, dist_ = 0.6, 100
+        for r in self.aspect_ratios.keys():
+            d = abs(float(r) - ratio)
+            if dist_ > d:
+                best, dist_ = r, d
+        return str(best)
+
+    def save_model(self):
+        self.accelerator.unwrap_model(self.model).save_pretrained(f"models/{self.global_step}")
+
+    def make_sampler(self):
+        """Cached-feature sampler over this rank's shard range (the intended path of :165-181)."""
+        from .bucket_sampler import BucketSampler
+        shards = [f"shard-{i:06d}.tar" for i in range(self.shard_index_begin, self.shard_index_end)]
+        return BucketSampler(shards, self.accelerator, self.params.batch_size, model=self,
+                             seed=self.params.dataset_seed, local_paths=self.params.local_shard_paths)
+
+    # ---- :126-281
+    def initialize(self):
+        p = self.params
+        if p.aspect_ratios == 512:
+            self.aspect_ratios = ASPECT_RATIO_512_BIN
+        elif p.aspect_ratios == 1024:
+            self.aspect_ratios = ASPECT_RATIO_1024_BIN
+        self.enable_efficient_attention()
+        if self.accelerator.is_main_process:
+            os.makedirs("models", exist_ok=True)
+        if self.sampler is None:
+            self.sampler = self.make_sampler()
+        if getattr(p, "lora_rank", None) is not None:
+            raise NotImplementedError("PEFT adapters (lora/loha/lokr) are a later row of the scope table")
+        self.optimizer = FlatAdamW(self.model, lr=p.learning_rate, weight_decay=p.weight_decay, max_grad_norm=1.0,
+                                   use_ema=bool(getattr(p, "use_ema", False)), ema_decay=0.999)
+        self.accelerator.prepare(self.model)
+        self.lr_scheduler = None
+        if getattr(p, "warmup_steps", None) is not None:
+            self.lr_scheduler = WarmupLR(self.optimizer, p.warmup_steps)
+        self.ema_model = self.optimizer.ema_shadow
+
+    # ---- :298-403
+    def run(self, max_steps=None):
+        p = self.params
+        self.initialize()
+        dev = self.accelerator.device
+        avg_loss = torch.zeros((), device=dev)
+        self.accelerator.wait_for_everyone()
+        if self.empty_embeddings is None and p.train_unconditional_prob > 0:
+            with torch.no_grad():
+                self.empty_embeddings = self.extract_embeddings([""])
+        steps = p.steps if max_steps is None else min(p.steps, max_steps)
+        self.loss_history = []
+        while self.global_step < steps:
+            for batch in self.sampler:
+                ratio, latents, embeddings, repa = batch.ratio, batch.vae_features, batch.embeddings, batch.repa_features
+                with self.accelerator.accumulate(self.model):
+                    if random.random() < p.train_unconditional_prob:          # whole-batch CFG dropout (:319-323)
+                        embeddings = [self.empty_embeddings[0] for _ in embeddings]
+                    generator = torch.Generator()                             # fresh, unseeded (:325)
+                    if p.exploration_steps is not None:                       # :326-336
+                        with torch.no_grad():
+                            states, losses = [], []
+                            for _ in range(p.exploration_steps):
+                                states.append(generator.get_state())
+                                losses.append(self.optimize(ratio, latents, embeddings, repa, generator))
+                        generator.set_state(states[int(torch.argmin(torch.stack(losses)))])
+                    loss = self.optimize(ratio, latents, embeddings, repa, generator)
+                    avg_loss = avg_loss + loss.detach()
+                    self.accelerator.backward(loss)
+                    if self.accelerator.sync_gradients:
+                        self.accelerator.clip_grad_norm_(None, max_norm=1.0)  # fused below
+                        self.optimizer.step()                                 # clip + AdamW + EMA + zero_grad
+                        if self.lr_scheduler is not None:
+                            self.lr_scheduler.step()
+                if self.accelerator.sync_gradients:
+                    mean_loss = self.accelerator.gather(avg_loss).mean()
+                    avg_loss = torch.zeros((), device=dev)
+                    self.loss_history.append(mean_loss)
+                    if self.logger is not None and self.accelerator.is_main_process:
+                        try:
+                            self.logger.add_scalar("train/loss", mean_loss.item(), self.global_step)
+                            if self.lr_scheduler is not None:
+                                self.logger.add_scalar("train/lr", self.lr_scheduler.get_last_lr()[0], self.global_step)
+                        except Exception as e:  # :363-369
+                            print(f"[Warning] logging failed: {e}")
+                    if self.global_step % p.num_steps_per_validation == 0:
+                        self._validate_and_save()
+                    self.global_step += 1
+                    if self.global_step >= steps:
+                        break
+        self.finalize()
+
+    def _validate_and_save(self):
+        """:371-401: EMA mean across ranks, then rank 0 swaps EMA weights in, validates, saves, swaps back."""
+        with torch.no_grad():
+            opt = self.optimizer
+            if opt.ema_shadow is not None and self.accelerator.num_processes > 1:
+                dist.all_reduce(opt.ema_shadow)            # one flat all-reduce instead of ~600 per-tensor calls
+                opt.ema_shadow /= self.accelerator.num_processes
+            if self.accelerator.is_main_process:
+                stored = None
+                if opt.ema_shadow is not None:
+                    stored = self.model.flat_param.clone()
+                    self.model.flat_param.copy_(opt.ema_shadow)
+                try:
+                    self.validate()
+                except NotImplementedError:
+                    pass
+                self.save_model()
+                if stored is not None:
+                    self.model.flat_param.copy_(stored)
+
+
+class WarmupLR:
+    """LambdaLR(lr * min(1, step / warmup)) of common/trainer.py:255-262, including LambdaLR's initial step(0)."""
+
+    def __init__(self, optimizer, warmup_steps):
+        self.opt, self.warmup, self.last_epoch = optimizer, warmup_steps, 0
+        self._apply()
+
+    def _factor(self, s):
+        return float(s) / float(max(1, self.warmup)) if s < self.warmup else 1.0
+
+    def _apply(self):
+        for g in self.opt.param_groups:
+            g["lr"] = g["initial_lr"] * self._factor(self.last_epoch)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.opt.param_groups]
