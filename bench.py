@@ -52,14 +52,38 @@ def train_flops_per_image(cfg, N, T):
     return 6.0 * (cfg.num_layers * blk + head)
 
 
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup cpu quota) -- os.cpu_count() reports the whole
+    host and oversubscribing OpenMP threads on a 16-core share makes the CPU leg crawl."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Time the CPU oracle on a bounded sample of the same workload: full-width SANA blocks (D=2240, N=1024, T=512),
     B=1, bf16, fwd+bwd+clip+AdamW, with L=2 and L=4 blocks; per-block and non-block costs are separated linearly and
     the 20-block step time is reconstructed."""
     from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
     from oracle.recipe_ref import FlowMatchSchedule, optimize_ref, clip_and_adamw_step
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host cores (os.cpu_count()={os.cpu_count()})")
     g = torch.Generator().manual_seed(1234)
     lat = (torch.randn(1, 32, 32, 32, generator=g) * 0.5).to(torch.bfloat16)
     embs = [torch.randn(160, 2304, generator=g).to(torch.bfloat16)]
@@ -78,6 +102,7 @@ def cpu_baseline(seconds_budget=30.0):
             clip_and_adamw_step(list(m.parameters()), opt)
             best = time.perf_counter() - t0
         times[L] = best
+        log(f"cpu_baseline: L={L} step {best:.2f}s")
         del m, opt
     t_block = max((times[4] - times[2]) / 2.0, 1e-6)
     t_rest = max(times[2] - 2 * t_block, 0.0)
@@ -131,6 +156,7 @@ def main():
     from yat_amd.ddp import HipDDP
 
     cfg = SanaConfig(num_layers=args.layers)
+    log(f"rank {rank}/{world}: building SANA ({args.layers} blocks) on {dev}")
     model = SanaTransformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
     opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
     ddp = HipDDP(model) if world > 1 else None
@@ -176,9 +202,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("inputs resident; warm-up")
     for i in range(args.warmup):
         step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log(f"first step done, loss={loss_dev.item():.4f}")
     barrier()
+    log(f"timing {args.steps} steps")
     timer = None if args.no_gemm_timer else []
     ops.GEMM_TIMER = timer
     t0 = time.perf_counter()
@@ -194,6 +225,7 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     loss_val = loss_dev.item()
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps, loss={loss_val:.4f}")
 
     if rank == 0:
         img_s = world * B * args.steps / elapsed
@@ -223,7 +255,7 @@ def main():
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is a reported side number; never let it sink the bench line
-                res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": usable_cores(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(res))
     if world > 1:

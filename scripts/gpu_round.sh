@@ -12,6 +12,9 @@ for s in $STEPS; do
     tests)
       timeout -k 10 600 python -m pytest tests -m gpu -q -s -p no:cacheprovider > gpurun_out/tests_gpu.log 2>&1; rc=$?
       echo "exit=$rc" >> gpurun_out/tests_gpu.log; grep -E "passed|failed" gpurun_out/tests_gpu.log | tail -2 ;;
+    benchsmall)
+      timeout -k 10 180 python bench.py --layers 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_small.json 2> gpurun_out/bench_small.err; rc=$?
+      echo "benchsmall rc=$rc"; cat gpurun_out/bench_small.json; tail -8 gpurun_out/bench_small.err ;;
     bench)
       timeout -k 10 600 python bench.py --steps "${BENCH_STEPS:-20}" --warmup "${BENCH_WARMUP:-5}" > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
       echo "bench rc=$rc"; tail -c 3000 gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
@@ -24,5 +27,6 @@ for s in $STEPS; do
       tail -3 gpurun_out/smoke.log ;;
   esac
   ok_to_continue $rc || { echo "step $s killed by timeout (rc=$rc): stopping"; exit $rc; }
+  [ "$s" = benchsmall ] && [ "$rc" -ne 0 ] && { echo "benchsmall failed: stopping"; exit $rc; }
 done
 exit 0
