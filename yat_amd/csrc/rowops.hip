@@ -155,24 +155,36 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(int D, int rpb, const b
     }
 }
 
-// out[b*ld_out + j] += sum_g ws[(b*G + g)*W + j]   (fp32 accumulate) -- j over W columns
-__global__ void reduce_partials_f32_kernel(int B, int G, int W, const float* ws, float* out0, float* out1, int half,
-                                           int ld_out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (j >= W) return;
+// Partial-row reductions: a 256-thread block owns 64 columns; 4 thread rows split the G partial rows and meet in LDS
+// (fixed order -> bit-reproducible).  grid.x = ceil(W / 64).
+__device__ __forceinline__ float reduce_rows64(const float* ws, int G, int W, int j, bool valid) {
+    __shared__ float red[4][64];
+    const int part = threadIdx.x >> 6;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += ws[((int64_t)b * G + g) * W + j];
+    if (valid)
+        for (int g = part; g < G; g += 4) s += ws[(int64_t)g * W + j];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    return red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63];
+}
+
+// out[b*ld_out + j] += sum_g ws[(b*G + g)*W + j]   (fp32 accumulate) -- j over W columns
+__global__ __launch_bounds__(256) void reduce_partials_f32_kernel(int B, int G, int W, const float* ws, float* out0,
+                                                                  float* out1, int half, int ld_out) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y;
+    const float s = reduce_rows64(ws + (int64_t)b * G * W, G, W, j, j < W);
+    if (threadIdx.x >= 64 || j >= W) return;
     // columns [0, half) go to out0, [half, W) to out1 (dshift / dscale live in different slots)
     if (j < half) out0[(int64_t)b * ld_out + j] += s;
     else if (out1) out1[(int64_t)b * ld_out + (j - half)] += s;
 }
 
 // bf16 output variant (bias / weight gradients): out[j] = (accumulate ? out[j] : 0) + sum_g ws[g*W + j]
-__global__ void reduce_partials_bf16_kernel(int G, int W, const float* ws, bf16_t* out, int accumulate) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= W) return;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += ws[(int64_t)g * W + j];
+__global__ __launch_bounds__(256) void reduce_partials_bf16_kernel(int G, int W, const float* ws, bf16_t* out,
+                                                                   int accumulate) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    float s = reduce_rows64(ws, G, W, j, j < W);
+    if (threadIdx.x >= 64 || j >= W) return;
     if (accumulate) s = rbf(s) + bf2f(out[j]);
     out[j] = f2bf(s);
 }
@@ -390,7 +402,7 @@ int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean,
     });
     if (rc) return rc;
     const int W = 2 * D, G = nchunks * WAVES;
-    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, B, G, W,
+    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((W + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, B, G, W,
                        (const float*)workspace, dshift_acc, dscale_acc, D, acc_ld);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
@@ -424,7 +436,7 @@ int yat_rmsnorm_bwd(int M, int D, const void* x, const void* w, const float* rst
     });
     if (rc) return rc;
     // rows past M never wrote their partial row: zero-filled? no -- every wave writes its (possibly zero) partials
-    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        nblk * WAVES, D, (const float*)workspace, (bf16_t*)dw, accumulate_dw);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
@@ -443,7 +455,7 @@ int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out, int ac
                        (const bf16_t*)x, ld, (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr,
                        (float*)workspace);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        gy * WAVES, cols, (const float*)workspace, (bf16_t*)out, accumulate);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
@@ -466,7 +478,7 @@ int yat_gate_bwd(int M, int D, int rpb, const void* dout, const void* lin, const
                        (const bf16_t*)dout, D, (const bf16_t*)lin, (const bf16_t*)gate, gate_ld, (bf16_t*)dlin,
                        (float*)workspace);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, B,
+    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, B,
                        gy * WAVES, D, (const float*)workspace, dgate_acc, (float*)nullptr, D, acc_ld);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
