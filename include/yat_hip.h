@@ -47,6 +47,11 @@ typedef struct yat_gemm_epilogue {
 int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                   void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream);
 
+/* Same, with an explicit tile variant for tests / tuning: 0 = automatic policy (what yat_gemm_bf16 uses),
+ * 1 = 128x128 tile, 4 = 256x256 tile, 5 = 256x320 tile (two staggered wave groups, gemm256.hip). */
+int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                     void* C, int ldc, const yat_gemm_epilogue* ep, int variant, yat_stream_t stream);
+
 /* out[c] (+)= sum_r x[r, c]  (bias gradients).  workspace: >= yat_colsum_workspace_bytes(rows, cols). */
 uint64_t yat_colsum_workspace_bytes(int rows, int cols);
 int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out_bf16, int accumulate, void* workspace,
@@ -113,16 +118,18 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
 /* ------------------------------------------------------------------------------------------ *
  * GLUMBConv middle: SiLU -> depthwise 3x3 (pad 1, bias) -> chunk2 -> a * SiLU(g)
  * (diffusers GLUMBConv called at patch_sana_attention_layers.py:110-113), on the token-major
- * layout z[B, h, w, 2*Hc] (no NCHW round trip).  z is the conv_inverted output (pre-SiLU).
- *   y[b,i,j,c] = u_c * silu(u_{c+Hc}),  u = bias + sum_taps wdw[c, tap] * silu(z[b,i+di,j+dj,c])
+ * layout [B, h, w, 2*Hc] (no NCHW round trip).  z is the conv_inverted output, s = bf16(SiLU(z)); both are written by
+ * the conv_inverted GEMM (activation = SiLU, aux_out = z), so SiLU is evaluated once per element.
+ *   y[b,i,j,c] = u_c * silu(u_{c+Hc}),  u = bias + sum_taps wdw[c, tap] * s[b,i+di,j+dj,c]
  * wdw: bf16 [2*Hc, 9] (diffusers conv_depth.weight [2Hc,1,3,3] flattened), bdw: bf16 [2*Hc].
  * bwd: dz (bf16, includes the SiLU derivative), dwdw / dbdw partial sums reduced via workspace.
  * ------------------------------------------------------------------------------------------ */
 uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc);
-int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* z, const void* wdw, const void* bdw, void* y,
+int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* wdw, const void* bdw, void* y,
                        yat_stream_t stream);
-int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* z, const void* wdw, const void* bdw, const void* dy,
-                       void* dz, void* dwdw_bf16, void* dbdw_bf16, int accumulate, void* workspace, yat_stream_t stream);
+int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z, const void* wdw, const void* bdw,
+                       const void* dy, void* dz, void* dwdw_bf16, void* dbdw_bf16, int accumulate, void* workspace,
+                       yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * gated residual backward: out = res + bf16(gate[b,:] * lin)   (patch_sana_attention_layers.py:95,113)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark over the SANA-1.6B shapes (B=8, N=1024, T=512): every tile variant, interleaved rounds in
+one process, random data (guide rule 24/25).  Prints TFLOP/s per (shape, layout, variant) and the policy's pick."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yat_amd import ops
+
+BF = torch.bfloat16
+dev = "cuda"
+M, Mt, D, Hc = 8192, 4096, 2240, 5600
+# (name, layout, M, N, K)   layout: nt fwd, nn dgrad, tn wgrad
+SHAPES = [
+    ("qkv_fwd", "nt", M, 3 * D, D), ("out_fwd", "nt", M, D, D), ("kv_fwd", "nt", Mt, 2 * D, D),
+    ("inv_fwd", "nt", M, 2 * Hc, D), ("point_fwd", "nt", M, D, Hc),
+    ("qkv_dgrad", "nn", M, D, 3 * D), ("out_dgrad", "nn", M, D, D), ("kv_dgrad", "nn", Mt, D, 2 * D),
+    ("inv_dgrad", "nn", M, D, 2 * Hc), ("point_dgrad", "nn", M, Hc, D),
+    ("qkv_wgrad", "tn", 3 * D, D, M), ("out_wgrad", "tn", D, D, M), ("kv_wgrad", "tn", 2 * D, D, Mt),
+    ("inv_wgrad", "tn", 2 * Hc, D, M), ("point_wgrad", "tn", D, Hc, M),
+]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+res = {}
+for name, lay, m, n, k in SHAPES:
+    a_t, b_t = lay == "tn", lay in ("nn", "tn")
+    a = (torch.randn((k, m) if a_t else (m, k), device=dev) * 0.5).to(BF)
+    b = (torch.randn((k, n) if b_t else (n, k), device=dev) * 0.05).to(BF)
+    out = torch.empty(m, n, dtype=BF, device=dev)
+    ref = None
+    times = {1: [], 4: [], 5: [], 0: []}
+    for r in range(rounds + 1):
+        for v in (1, 4, 5, 0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ops.gemm(a, b, out, a_t=a_t, b_t=b_t, M=m, N=n, K=k, variant=v)
+            e1.record()
+            torch.cuda.synchronize()
+            if r > 0:
+                times[v].append(e0.elapsed_time(e1) / 3)
+            if r == 0:
+                if ref is None:
+                    ref = out.float().clone()
+                else:
+                    err = ((out.float() - ref).norm() / ref.norm()).item()
+                    assert err < 2e-3, (name, v, err)
+    fl = 2.0 * m * n * k
+    line = {v: fl / (sorted(t)[len(t) // 2] * 1e-3) / 1e12 for v, t in times.items()}
+    res[name] = line
+    print(f"{name:12s} {lay} {m:6d}x{n:6d}x{k:6d}  v128={line[1]:7.1f}  v256={line[4]:7.1f}  v320={line[5]:7.1f}  auto={line[0]:7.1f} TF", flush=True)
+tot_fl = {v: 0.0 for v in (1, 4, 5, 0)}
+tot_t = {v: 0.0 for v in (1, 4, 5, 0)}
+mult = {"out_fwd": 3, "out_dgrad": 3, "out_wgrad": 3}
+for name, lay, m, n, k in SHAPES:
+    for v in tot_t:
+        c = mult.get(name, 1)
+        tot_t[v] += c * 2.0 * m * n * k / (res[name][v] * 1e12)
+        tot_fl[v] += c * 2.0 * m * n * k
+best = sum(mult.get(n_, 1) * 2.0 * m * n * k / (max(res[n_][v] for v in (1, 4, 5)) * 1e12) for n_, lay, m, n, k in SHAPES)
+print("per-block GEMM time (ms): " + "  ".join(f"v{v}={tot_t[v]*1e3:.2f}" for v in (1, 4, 5, 0)) + f"  best-per-shape={best*1e3:.2f}")
+print("aggregate TF: " + "  ".join(f"v{v}={tot_fl[v]/tot_t[v]/1e12:.0f}" for v in (1, 4, 5, 0)))
+json.dump(res, open("gpurun_out/gemm_bench.json", "w"), indent=1)

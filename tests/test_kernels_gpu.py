@@ -114,6 +114,53 @@ def test_gemm_tn_wgrad(ops, M, N, K):
     close(dw, (rb(ref) + rb(ref)).to(BF), f"gemm_tn_acc {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("M,N,K", [(256, 320, 64), (512, 640, 192), (300, 328, 96), (1024, 2240, 5600), (777, 1000, 264)])
+def test_gemm256_all_layouts(ops, variant, M, N, K):
+    """The 256-row staggered-wave-group kernel (gemm256.hip), every layout, ragged M/N/K tails."""
+    x, w = rnd(M, K, seed=80), rnd(N, K, scale=K ** -0.5, seed=81)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm(x, w, out, M=M, N=N, K=K, variant=variant)                                   # NT
+    close(out, (x.float() @ w.float().T).to(BF), f"gemm256v{variant}_nt {M}x{N}x{K}")
+    wt = w.T.contiguous()                                                                 # [K, N]
+    ops.gemm(x, wt, out, b_t=True, M=M, N=N, K=K, variant=variant)                        # NN
+    close(out, (x.float() @ wt.float()).to(BF), f"gemm256v{variant}_nn {M}x{N}x{K}")
+    if M % 8 == 0:
+        xt = x.T.contiguous()                                                             # [K, M]
+        ops.gemm(xt, wt, out, a_t=True, b_t=True, M=M, N=N, K=K, variant=variant)         # TN
+        close(out, (xt.float().T @ wt.float()).to(BF), f"gemm256v{variant}_tn {M}x{N}x{K}")
+        ops.gemm(xt, w, out, a_t=True, b_t=False, M=M, N=N, K=K, variant=variant)         # TT
+        close(out, (xt.float().T @ w.float().T).to(BF), f"gemm256v{variant}_tt {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+def test_gemm256_epilogue_and_identity(ops, variant):
+    n = 512
+    eye = torch.eye(n, dtype=BF, device=DEV)
+    b = (torch.arange(n * n, device=DEV).reshape(n, n) % 251).to(BF)
+    out = torch.empty(n, n, dtype=BF, device=DEV)
+    ops.gemm(eye, b, out, M=n, N=n, K=n, variant=variant)
+    assert torch.equal(out, b.T.contiguous())
+    ops.gemm(eye, b, out, b_t=True, M=n, N=n, K=n, variant=variant)
+    assert torch.equal(out, b)
+    ops.gemm(b, eye, out, a_t=True, b_t=True, M=n, N=n, K=n, variant=variant)
+    assert torch.equal(out, b.T.contiguous())
+    B, rows, D, K = 3, 200, 328, 128
+    M = B * rows
+    x, w, bias = rnd(M, K, seed=82), rnd(D, K, scale=K ** -0.5, seed=83), rnd(D, seed=84)
+    mod, res = rnd(B, 6, D, seed=85), rnd(M, D, seed=86)
+    lin = torch.empty(M, D, dtype=BF, device=DEV)
+    o = torch.empty(M, D, dtype=BF, device=DEV)
+    ops.gemm(x, w, o, M=M, N=D, K=K, bias=bias, aux_out=lin, gate=mod[:, 2], ld_gate=6 * D, residual=res,
+             rows_per_batch=rows, variant=variant)
+    linr = rb(x.float() @ w.float().T + bias.float())
+    close(lin, linr, f"gemm256v{variant}_epi_lin")
+    close(o, (res.float() + rb(mod[:, 2].float().repeat_interleave(rows, 0) * linr)).to(BF), f"gemm256v{variant}_epi_out")
+    s_out = torch.empty(M, D, dtype=BF, device=DEV)
+    ops.gemm(x, w, s_out, M=M, N=D, K=K, bias=bias, aux_out=lin, activation="silu", variant=variant)
+    close(s_out, F.silu(linr).to(BF), f"gemm256v{variant}_epi_silu")
+
+
 def test_gemm_asymmetric_identity(ops):
     """A = I with an asymmetric B catches a transposed C-write or a swapped fragment map."""
     n = 128
@@ -367,7 +414,8 @@ def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     z = rnd(M, 2 * Hc, seed=37)
     wdw, bdw = rnd(2 * Hc, 9, scale=1 / 3, seed=38), rnd(2 * Hc, scale=0.1, seed=39)
     y = torch.empty(M, Hc, dtype=BF, device=DEV)
-    ops.dwconv_glu_fwd(z, B, h, w, Hc, wdw, bdw, y)
+    s_act = F.silu(z.float()).to(BF)          # what the conv_inverted GEMM epilogue stores next to z
+    ops.dwconv_glu_fwd(s_act, B, h, w, Hc, wdw, bdw, y)
     close(y, _glu_ref(z, wdw, bdw, B, h, w, Hc).to(BF), f"dwconv_fwd {h}x{w}x{Hc}")
     # backward: torch autograd of diffusers GLUMBConv's op sequence in bf16 (the reference) and in fp32
     dy = rnd(M, Hc, seed=40)
@@ -383,7 +431,7 @@ def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     flow, truth = run(BF), run(torch.float32)
     dz, dw, db = torch.empty_like(z), torch.empty_like(wdw), torch.empty_like(bdw)
     ws = torch.empty(ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc), dtype=torch.uint8, device=DEV)
-    ops.dwconv_glu_bwd(z, B, h, w, Hc, wdw, bdw, dy, dz, dw, db, ws)
+    ops.dwconv_glu_bwd(s_act, z, B, h, w, Hc, wdw, bdw, dy, dz, dw, db, ws)
     as_good_as(dz, flow[0], truth[0], f"dwconv_dz {h}x{w}x{Hc}", tol_flow=1e-2)
     as_good_as(dw, flow[1], truth[1], f"dwconv_dw {h}x{w}x{Hc}", tol_flow=1e-2)
     as_good_as(db, flow[2], truth[2], f"dwconv_db {h}x{w}x{Hc}", tol_flow=1e-2)

@@ -1,5 +1,6 @@
 // GLUMBConv middle for gfx950, on the token-major (channels-last) layout:
-//   s = SiLU(z);  u = dwconv3x3(s) + bias;  y = u[:Hc] * SiLU(u[Hc:])
+//   s = SiLU(z) [fused into the conv_inverted GEMM epilogue, which stores both s and z];
+//   u = dwconv3x3(s) + bias;  y = u[:Hc] * SiLU(u[Hc:])
 // (diffusers GLUMBConv as called at /root/reference/utils/patch_sana_attention_layers.py:110-113;
 // z is the conv_inverted output, so the reference's NCHW permutes at :110,112 disappear).
 //
@@ -9,7 +10,8 @@
 // loaded once and scattered into the three output columns it touches, so no 3x3 window lives in
 // registers and each z element is fetched ~3.75x from L2 instead of 9x.  The next column's loads
 // are issued before the current column is consumed (register double buffer) so L2/HBM latency
-// hides under the SiLU + FMA work.  SiLU is fused on load.
+// hides under the FMA work.  (Recomputing SiLU on every load made the kernel VALU-bound: 3.75 SiLUs per
+// element; the producer GEMM now applies it once.)
 // Backward = two passes: (1) recompute u, emit du (bf16); (2) transposed conv of du -> dz (times
 // SiLU'(z)), with the weight / bias gradient partials accumulated in registers over ROWS x SEG
 // pixels, reduced across the block's segments in LDS, then across blocks by a small kernel.
@@ -32,7 +34,7 @@ __device__ __forceinline__ u32x2 ld_or_zero(const bf16_t* p, bool ok) {
 // MODE 0: forward (writes y).  MODE 1: backward pass 1 (reads dy, writes du for both halves).
 // grid = (ceil(Hc/4 / 256), h * nseg, B)
 template <int MODE>
-__global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, int nseg, const bf16_t* z,
+__global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, int nseg, const bf16_t* z /* = SiLU(conv_inverted) */,
                                                          const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
                                                          bf16_t* out) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;   // 4-channel group of the `a` half
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, i
             const int tr = r * 3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float sa = rbf(silu_f(za[e])), sg = rbf(silu_f(zg[e]));   // silu(0) = 0: padding is free
+                const float sa = za[e], sg = zg[e];   // already SiLU(z) in bf16; zero padding of s
                 aP[e] += wa[tr + 2][e] * sa; aC[e] += wa[tr + 1][e] * sa; aN[e] += wa[tr][e] * sa;
                 gP[e] += wg[tr + 2][e] * sg; gC[e] += wg[tr + 1][e] * sg; gN[e] += wg[tr][e] * sg;
             }
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, i
 //   dz[i,j] = SiLU'(z[i,j]) * bf16( sum_taps W[tap] du[i-di, j-dj] )
 //   dW[tap] += s(z[i,j]) * du[i-di, j-dj];   db += du[i,j]
 // partials: ws[((b*nrg + rg)*nsb + sb)][2Hc*10]  (10 = 9 taps + bias per channel)
-__global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, const bf16_t* z, const bf16_t* wdw,
-                                                          const bf16_t* du, bf16_t* dz, float* ws) {
+__global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, const bf16_t* sact, const bf16_t* z,
+                                                          const bf16_t* wdw, const bf16_t* du, bf16_t* dz, float* ws) {
     __shared__ float red[4][64][41];
     const int C2 = 2 * Hc;
     const int lg = threadIdx.x & 63, lseg = threadIdx.x >> 6;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, 
         for (int t = 0; t < 9; ++t) { wt[t][e] = bf2f(wdw[(c0 + e) * 9 + t]); dW[t][e] = 0.f; }
     }
     const bf16_t* zb = z + (int64_t)b * h * w * C2;
+    const bf16_t* sb_ = sact + (int64_t)b * h * w * C2;
     const bf16_t* dub = du + (int64_t)b * h * w * C2;
     bf16_t* dzb = dz + (int64_t)b * h * w * C2;
     if (active && j0 < w) {
@@ -151,23 +154,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, 
                 }
             };
             auto load_z = [&](int jj) { return ld_or_zero(zb + ((int64_t)i * w + jj) * C2 + c0, jj >= 0 && jj < w); };
+            auto load_s = [&](int jj) { return ld_or_zero(sb_ + ((int64_t)i * w + jj) * C2 + c0, jj >= 0 && jj < w); };
             float aP[4], aC[4], aN[4], sP[4], sC[4], sN[4], zP[4], zC[4], zN[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { aP[e] = aC[e] = aN[e] = 0.f; }
             // centre-row z window around input column jj: P = jj-1, C = jj, N = jj+1
             unpack4(load_z(j0 - 2), zP);
             unpack4(load_z(j0 - 1), zC);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sP[e] = rbf(silu_f(zP[e])); sC[e] = rbf(silu_f(zC[e])); }
+            unpack4(load_s(j0 - 2), sP);
+            unpack4(load_s(j0 - 1), sC);
             u32x2 dn[3];
             load_du(j0 - 1, dn);
-            u32x2 zn = load_z(j0);
+            u32x2 zn = load_z(j0), sn = load_s(j0);
             for (int jj = j0 - 1; jj <= j1; ++jj) {
                 u32x2 dc[3] = {dn[0], dn[1], dn[2]};
                 unpack4(zn, zN);
-                if (jj < j1) { load_du(jj + 1, dn); zn = load_z(jj + 2); }      // prefetch
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sN[e] = rbf(silu_f(zN[e]));
+                unpack4(sn, sN);
+                if (jj < j1) { load_du(jj + 1, dn); zn = load_z(jj + 2); sn = load_s(jj + 2); }      // prefetch
                 // only contributions to output columns inside [j0, j1) count for dW (each (pixel, tap) pair once)
                 const bool inP = jj - 1 >= j0 && jj - 1 < j1, inC = jj >= j0 && jj < j1, inN = jj + 1 >= j0 && jj + 1 < j1;
 #pragma unroll
@@ -239,8 +242,9 @@ inline int nrg_of(int h) { return (h + ROWS - 1) / ROWS; }
 
 extern "C" {
 
-int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* z, const void* wdw, const void* bdw, void* y,
+int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* wdw, const void* bdw, void* y,
                        yat_stream_t stream) {
+    const void* z = s;
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !z || !wdw || !bdw || !y) return YAT_EINVAL;
     if ((int64_t)h * nseg_of(w) > 65535 || B > 65535) return YAT_EINVAL;
     hipLaunchKernelGGL((dwconv_glu_kernel<0>), dim3((Hc / 4 + 255) / 256, h * nseg_of(w), B), dim3(256), 0,
@@ -256,9 +260,10 @@ uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc) {
     return du_bytes + (uint64_t)B * nrg_of(h) * nsb_of(w) * 2 * Hc * 10 * sizeof(float);
 }
 
-int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* z, const void* wdw, const void* bdw, const void* dy,
-                       void* dz, void* dwdw, void* dbdw, int accumulate, void* workspace, yat_stream_t stream) {
-    if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !z || !wdw || !bdw || !dy || !dz || !dwdw || !dbdw ||
+int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z, const void* wdw, const void* bdw,
+                       const void* dy, void* dz, void* dwdw, void* dbdw, int accumulate, void* workspace,
+                       yat_stream_t stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !s || !z || !wdw || !bdw || !dy || !dz || !dwdw || !dbdw ||
         !workspace)
         return YAT_EINVAL;
     if ((int64_t)h * nseg_of(w) > 65535 || B > 65535) return YAT_EINVAL;
@@ -268,11 +273,11 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* z, const void* w
     const uint64_t du_bytes = ((uint64_t)B * h * w * C2 * 2 + 255) & ~255ull;
     float* ws = (float*)((char*)workspace + du_bytes);
     hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3((Hc / 4 + 255) / 256, h * nseg_of(w), B), dim3(256), 0,
-                       (hipStream_t)stream, h, w, Hc, nseg_of(w), (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)bdw,
+                       (hipStream_t)stream, h, w, Hc, nseg_of(w), (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
                        (const bf16_t*)dy, du);
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dwconv_bwd2_kernel, dim3((C2 / 4 + 63) / 64, gy2, B), dim3(256), 0, (hipStream_t)stream, h, w, Hc,
-                       (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)du, (bf16_t*)dz, ws);
+                       (const bf16_t*)s, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)du, (bf16_t*)dz, ws);
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * 10 + 63) / 64), dim3(256), 0, (hipStream_t)stream, B * gy2, C2,
                        (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, accumulate);

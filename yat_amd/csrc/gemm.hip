@@ -20,7 +20,9 @@
 // MFMA operands are swapped (D = B_frag x A_frag) so a lane owns 4 consecutive n of one row m:
 // the epilogue loads/stores 8 B per lane.  Workgroups are remapped so each XCD (private L2)
 // works on a contiguous band of tiles.
+#include <math.h>
 #include "common.hpp"
+#include "gemm_common.hpp"
 #include "../../include/yat_hip.h"
 
 namespace {
@@ -29,18 +31,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;  // 32 KiB
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;            // 64 KiB -> 2 workgroups / CU
 
-struct GemmP {
-    const bf16_t* A; const bf16_t* B; bf16_t* C;
-    int M, N, K; int lda, ldb, ldc;
-    const bf16_t* bias;    // [N] or null
-    const bf16_t* gate;    // [M/rows_per_batch][gate_ld] or null
-    const bf16_t* res;     // [M, ldr] residual / accumulate input or null
-    bf16_t* aux;           // [M, ldaux] pre-activation / pre-gate linear output or null
-    int ldr, ldaux, gate_ld, rows_per_batch;
-    int act;               // 0 none, 1 silu, 2 gelu_tanh
-    int nbm, nbn;
-    uint64_t a_bytes, b_bytes;
-};
 
 __device__ __forceinline__ uint32_t trswz(uint32_t krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
 
@@ -157,46 +147,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
             if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                float bb[4];
-                unpack4(*reinterpret_cast<const u32x2*>(p.bias + n), bb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bb[e];
-            }
-            if (p.aux || p.act || p.res) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);  // the Linear's bf16 output
-            }
-            if (p.aux) *reinterpret_cast<u32x2*>(p.aux + (int64_t)m * p.ldaux + n) = pack4(v[0], v[1], v[2], v[3]);
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            } else if (p.act == 2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-            }
-            if (p.gate) {
-                float g[4];
-                unpack4(*reinterpret_cast<const u32x2*>(p.gate + (int64_t)b * p.gate_ld + n), g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rbf(g[e] * v[e]);
-            }
-            if (p.res) {
-                float r[4];
-                unpack4(*reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ldr + n), r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r[e];
-            }
-            *reinterpret_cast<u32x2*>(p.C + (int64_t)m * p.ldc + n) = pack4(v[0], v[1], v[2], v[3]);
+            gemm_epilogue_store(p, acc[i][j], m, n, b);
         }
     }
 }
 
 }  // namespace
 
-extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                             void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream_) {
+namespace {
+
+// Tile-shape policy.  Modelled per-CU rates (TFLOP/s per CU, measured on MI355X): the 128x128 kernel
+// runs 2 workgroups per CU, the 256-row kernels one.  Cost = rounds of workgroups x work per round.
+double est_time_128(int M, int N, int K) {
+    const double tiles = (double)((M + 127) / 128) * ((N + 127) / 128);
+    const double rounds = ceil(tiles / 512.0);
+    return rounds * 2.0 * (2.0 * 128 * 128 * (double)K) / 3.4e12;
+}
+double est_time_256(int M, int N, int K, int BNv) {
+    const double tiles = (double)((M + 255) / 256) * ((N + BNv - 1) / BNv);
+    const double rounds = ceil(tiles / 256.0);
+    return rounds * (2.0 * 256 * BNv * (double)K) / 5.0e12;
+}
+
+}  // namespace
+
+extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                void* C, int ldc, const yat_gemm_epilogue* ep, int variant, yat_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return YAT_EINVAL;
     if ((N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return YAT_EINVAL;
@@ -204,6 +180,7 @@ extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* 
     if (a_t && (M & 7)) return YAT_EINVAL;             // 16-B chunks along m
     if (b_t && (N & 7)) return YAT_EINVAL;
     if (!b_t && (K & 7)) return YAT_EINVAL;
+    if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
     GemmP p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -215,10 +192,20 @@ extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* 
         if (p.act < 0 || p.act > 2) return YAT_EINVAL;
         if (p.gate && (p.gate_ld & 3)) return YAT_EINVAL;
     }
-    p.nbm = (M + BM - 1) / BM; p.nbn = (N + BN - 1) / BN;
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
     if (p.a_bytes > 0x7fffffffull || p.b_bytes > 0x7fffffffull) return YAT_EINVAL;
+    if (variant == 0) {
+        variant = 1;
+        if (M >= 1024 && N >= 512 && K >= 256) {
+            double best = est_time_128(M, N, K);
+            const double t4 = est_time_256(M, N, K, 256), t5 = est_time_256(M, N, K, 320);
+            if (t4 < best) { best = t4; variant = 4; }
+            if (t5 < best) { best = t5; variant = 5; }
+        }
+    }
+    if (variant == 4 || variant == 5) return yat_gemm256_launch(a_t, b_t, variant, p, stream);
+    p.nbm = (M + BM - 1) / BM; p.nbn = (N + BN - 1) / BN;
     static bool attr_set = false;   // idempotent one-time launch attribute (64 KiB dynamic LDS)
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
@@ -235,4 +222,9 @@ extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* 
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, LDS_BYTES, stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
+}
+
+extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                             void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream) {
+    return yat_gemm_bf16_ex(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, ep, 0, stream);
 }

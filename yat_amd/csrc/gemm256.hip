@@ -1,0 +1,228 @@
+// gemm256: 256 x (256|320) x 64 tile bf16 MFMA GEMM for gfx950 with two staggered wave groups.
+//
+// Why a second kernel: the 128x128 kernel (gemm.hip) needs ~150 GB/s of L2->LDS traffic per CU at
+// full MFMA rate (38 TB/s chip-wide, above the ~34 TB/s aggregate L2 bandwidth); a 256-wide tile
+// halves the bytes per flop.  A 256x256 tile fills the LDS of a CU (2 x 64..72 KiB), so there is
+// one workgroup per CU and nothing from a neighbouring workgroup to hide its barriers; the overlap
+// has to come from inside the workgroup:
+//
+//   8 waves = 2 groups (g = wave>>2, rows [128g,128g+128)) x 4 column slices.  Waves w and w+4 land
+//   on the same SIMD.  Every K-tile is split into two 32-deep sub-steps, each a LOAD segment (12+
+//   ds_reads of the fragments, LDS-DMA issue for the next tile) followed by a COMPUTE segment (32..40
+//   MFMA 16x16x32 on registers only), separated by raw s_barriers.  Group 1 executes one extra
+//   barrier before its loop (group 0 one after), so on each SIMD one wave computes while the other
+//   loads: the matrix pipe sees back-to-back MFMA segments.
+//
+// LDS-DMA protocol (the only ordering for a DMA'd tile is the issuing wave's vmcnt + a barrier the
+// reader has passed):  tile t+1 is issued at the top of a wave's iteration t into the stage that
+// held tile t-1 (all its reads retired by lgkmcnt(0) before the barrier every wave has passed by
+// then), is waited for with vmcnt(0) before the wave's 3rd barrier of iteration t, and is first
+// read after the 4th.  Barrier bookkeeping (n-th barrier of every wave is one rendezvous):
+//   group 0, iteration t: barriers 4t+1..4t+4;  group 1: 4t+2..4t+5.
+//
+// Operand layouts, swizzles, swapped-operand MFMA and epilogue are those of gemm.hip.
+#include "common.hpp"
+#include "gemm_common.hpp"
+
+namespace {
+
+constexpr int BM = 256, BK = 64;
+
+template <int NT> struct Geo {
+    static constexpr int BN = 64 * NT;                 // 4 column slices x NT tiles of 16
+    static constexpr int A_BYTES = BM * BK * 2;        // 32 KiB
+    static constexpr int B_BYTES = BN * BK * 2;        // 32 / 40 KiB
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int LDS = 2 * STAGE;              // 128 / 144 KiB
+    static constexpr int PA = A_BYTES / 1024 / 8;      // DMA pieces per wave per tile (A): 4
+    static constexpr int PB = B_BYTES / 1024 / 8;      // (B): 4 / 5
+};
+
+__device__ __forceinline__ uint32_t trswz2(uint32_t krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+// loop-invariant part of one DMA piece: byte offset of this lane's 16-B chunk at k-tile 0 (or OOB),
+// and (row-mode only) the source chunk index inside the 64-wide k-tile for the ragged-K check.
+struct Piece { uint32_t voff; uint32_t kchunk; };
+
+template <bool KSTRIDED, int ROWS_OR_COLS>
+__device__ __forceinline__ Piece make_piece(int piece, int lane, int ld, int idx0, int idx_max) {
+    Piece pc;
+    if (!KSTRIDED) {
+        const int r = piece * 8 + (lane >> 3);
+        const int c = swz128(r, lane & 7);
+        const int gi = idx0 + r;
+        pc.kchunk = c;
+        pc.voff = gi < idx_max ? (uint32_t)(((int64_t)gi * ld + c * 8) * 2) : YAT_OOB;
+    } else {
+        constexpr int ROWB = ROWS_OR_COLS * 2;                 // bytes per k-row of the LDS image
+        const uint32_t o = piece * 1024 + lane * 16;
+        const uint32_t r = o / ROWB, slot = (o % ROWB) >> 4;
+        const uint32_t c = slot ^ trswz2(r);
+        const int gi = idx0 + c * 8;
+        pc.kchunk = 0;
+        pc.voff = gi < idx_max ? (uint32_t)(((int64_t)r * ld + gi) * 2) : YAT_OOB;   // k-rows past K: buffer range check
+    }
+    return pc;
+}
+
+template <bool KSTRIDED, int COLS>
+__device__ __forceinline__ bf16x8 frag256(const char* lds, int idx0, int kk, int lane) {
+    if (!KSTRIDED) {
+        const uint32_t r = idx0 + (lane & 15);
+        const uint32_t c = swz128(r, kk * 4 + (lane >> 4));
+        return lds_read8(lds, r * 128 + c * 16);
+    } else {
+        constexpr uint32_t ROWB = COLS * 2;
+        const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const uint32_t col = idx0 + 4 * p;
+        const uint32_t r0 = kk * 32 + 8 * g + q, r1 = r0 + 4;
+        const uint32_t c0 = (col >> 3) ^ trswz2(r0), c1 = (col >> 3) ^ trswz2(r1);
+        return cat4(lds_read_tr4(lds, r0 * ROWB + c0 * 16 + (p & 1) * 8), lds_read_tr4(lds, r1 * ROWB + c1 * 16 + (p & 1) * 8));
+    }
+}
+
+#define YAT_PHASE_BARRIER()                  \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+template <bool A_T, bool B_T, int NT>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
+    using G = Geo<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+
+    const int nwg = p.nbm * p.nbn;
+    int id;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int GROUP = 4;
+    const int per_group = GROUP * p.nbn;
+    const int gid = id / per_group, first_m = gid * GROUP;
+    const int gsz = min(p.nbm - first_m, GROUP);
+    const int tm = first_m + (id % per_group) % gsz;
+    const int tn = (id % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * G::BN;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+    // this wave's DMA pieces (loop invariant): A pieces wave + 8j, B pieces wave + 8j
+    Piece pa[G::PA], pb[G::PB];
+#pragma unroll
+    for (int j = 0; j < G::PA; ++j) pa[j] = make_piece<A_T, BM>(wave + 8 * j, lane, p.lda, m0, p.M);
+#pragma unroll
+    for (int j = 0; j < G::PB; ++j) pb[j] = make_piece<B_T, G::BN>(wave + 8 * j, lane, p.ldb, n0, p.N);
+    const uint32_t a_kstep = A_T ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
+    const uint32_t b_kstep = B_T ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
+    const int nt = (p.K + BK - 1) / BK;
+    const bool ragged = (p.K & (BK - 1)) != 0;
+
+    auto issue = [&](int t, char* stage) {
+        const bool tail = ragged && t == nt - 1;
+        const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;     // valid 16-B chunks in this k-tile (row-mode)
+#pragma unroll
+        for (int j = 0; j < G::PA; ++j) {
+            uint32_t v = pa[j].voff + (uint32_t)t * a_kstep;
+            if (!A_T && tail && pa[j].kchunk >= kvalid) v = YAT_OOB;
+            lds_dma16(ra, (YAT_LDS void*)(stage + (wave + 8 * j) * 1024), v);
+        }
+#pragma unroll
+        for (int j = 0; j < G::PB; ++j) {
+            uint32_t v = pb[j].voff + (uint32_t)t * b_kstep;
+            if (!B_T && tail && pb[j].kchunk >= kvalid) v = YAT_OOB;
+            lds_dma16(rb, (YAT_LDS void*)(stage + G::A_BYTES + (wave + 8 * j) * 1024), v);
+        }
+    };
+
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
+    if (grp == 1) YAT_PHASE_BARRIER();         // stagger: group 1 runs one segment behind group 0
+
+    bf16x8 af[8], bfr[NT];
+    for (int t = 0; t < nt; ++t) {
+        const char* cur = smem + (t & 1) * G::STAGE;
+        if (t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * G::STAGE);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // ---- LOAD segment
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = frag256<A_T, BM>(cur, grp * 128 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = frag256<B_T, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (kk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t+1 landed (this wave's pieces)
+            YAT_PHASE_BARRIER();
+            // ---- COMPUTE segment (registers only)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
+            __builtin_amdgcn_s_setprio(0);
+            YAT_PHASE_BARRIER();
+        }
+    }
+    if (grp == 0) YAT_PHASE_BARRIER();         // pair group 1's last barrier
+
+    // ---- epilogue: lane owns row m = ..+(lane&15), cols n = ..+4*(lane>>4) + 0..3
+    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + grp * 128 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / rpb;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wc * 16 * NT + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            gemm_epilogue_store(p, acc[i][j], m, n, b);
+        }
+    }
+}
+
+template <bool A_T, bool B_T, int NT>
+int launch256(const GemmP& p0, hipStream_t stream) {
+    using G = Geo<NT>;
+    GemmP p = p0;
+    p.nbm = (p.M + BM - 1) / BM;
+    p.nbn = (p.N + G::BN - 1) / G::BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm256_kernel<A_T, B_T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS) != hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<A_T, B_T, NT>), dim3(p.nbm * p.nbn), dim3(512), G::LDS, stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? YAT_OK : (int)e;
+}
+
+}  // namespace
+
+// variant: 4 -> BN=256, 5 -> BN=320
+int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream) {
+#define YAT_CASE(AT, BT)                                                     \
+    if (a_t == AT && b_t == BT)                                              \
+        return nt_variant == 5 ? launch256<AT, BT, 5>(p, stream) : launch256<AT, BT, 4>(p, stream);
+    YAT_CASE(false, false)
+    YAT_CASE(false, true)
+    YAT_CASE(true, true)
+    YAT_CASE(true, false)
+#undef YAT_CASE
+    return YAT_EINVAL;
+}

@@ -1,0 +1,56 @@
+// Shared by gemm.hip (128x128 tile) and gemm256.hip (256-row tile): launch parameters and the fused epilogue.
+#pragma once
+#include "common.hpp"
+
+struct GemmP {
+    const bf16_t* A; const bf16_t* B; bf16_t* C;
+    int M, N, K; int lda, ldb, ldc;
+    const bf16_t* bias;    // [N] or null
+    const bf16_t* gate;    // [M/rows_per_batch][gate_ld] or null
+    const bf16_t* res;     // [M, ldr] residual / accumulate input or null
+    bf16_t* aux;           // [M, ldaux] pre-activation / pre-gate linear output or null
+    int ldr, ldaux, gate_ld, rows_per_batch;
+    int act;               // 0 none, 1 silu, 2 gelu_tanh
+    int nbm, nbn;
+    uint64_t a_bytes, b_bytes;
+};
+
+// One lane's 4 consecutive output columns of row m (swapped-operand MFMA result):
+// +bias -> round bf16 (the Linear's output) -> aux store -> activation -> *gate (rounded) -> +residual -> store.
+__device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4& a, int m, int n, int b) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+        float bb[4];
+        unpack4(*reinterpret_cast<const u32x2*>(p.bias + n), bb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bb[e];
+    }
+    if (p.aux || p.act || p.res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+    }
+    if (p.aux) *reinterpret_cast<u32x2*>(p.aux + (int64_t)m * p.ldaux + n) = pack4(v[0], v[1], v[2], v[3]);
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+    }
+    if (p.gate) {
+        float g[4];
+        unpack4(*reinterpret_cast<const u32x2*>(p.gate + (int64_t)b * p.gate_ld + n), g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(g[e] * v[e]);
+    }
+    if (p.res) {
+        float r[4];
+        unpack4(*reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    *reinterpret_cast<u32x2*>(p.C + (int64_t)m * p.ldc + n) = pack4(v[0], v[1], v[2], v[3]);
+}
+
+// gemm256.hip
+int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream);

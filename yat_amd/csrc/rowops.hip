@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int ROWS_PER_WAVE = 8;     // rows a wave walks in the backward kernels
+constexpr int ROWS_PER_WAVE = 4;     // rows a wave walks in the backward kernels
 constexpr int WAVES = 4;             // 256-thread blocks
 
 template <int MAXV>
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(int M, int D, int rpb, 
 }
 
 // ------------------------------------------------------------------ LN + modulate backward
-// grid = (ceil(rpb / 32), B); wave w of block handles rows chunk*32 + w*8 .. +8 of batch b.
+// grid = (ceil(rpb / 16), B); wave w of block handles rows chunk*16 + w*4 .. +4 of batch b.
 // partial rows: ws[((b*nchunks + chunk)*4 + wave)][2][D]
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(int D, int rpb, const bf16_t* x, const float* mean_in,
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(int M, int D, float ep
     }
 }
 
-// grid.x = ceil(M / 32); partial rows ws[(blk*4 + wave)][D] hold dw partials
+// grid.x = ceil(M / 16); partial rows ws[(blk*4 + wave)][D] hold dw partials
 template <int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int M, int D, const bf16_t* x, const bf16_t* w,
                                                           const float* rstd_in, const bf16_t* dy, bf16_t* dx,
@@ -420,13 +420,13 @@ int yat_rmsnorm_fwd(int M, int D, float eps, const void* x, const void* w, void*
 }
 
 uint64_t yat_rmsnorm_bwd_workspace_bytes(int M, int D) {
-    return (uint64_t)((M + 31) / 32) * WAVES * D * sizeof(float);
+    return (uint64_t)((M + WAVES * ROWS_PER_WAVE - 1) / (WAVES * ROWS_PER_WAVE)) * WAVES * D * sizeof(float);
 }
 
 int yat_rmsnorm_bwd(int M, int D, const void* x, const void* w, const float* rstd, const void* dy, void* dx,
                     void* dw, int accumulate_dw, void* workspace, yat_stream_t stream) {
     if (M <= 0 || !x || !w || !rstd || !dy || !dx || !dw || !workspace) return YAT_EINVAL;
-    const int nblk = (M + 31) / 32;
+    const int nblk = (M + WAVES * ROWS_PER_WAVE - 1) / (WAVES * ROWS_PER_WAVE);
     int rc = dispatch_maxv(D, [&](auto mv) {
         constexpr int MV = decltype(mv)::value;
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<MV>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, M, D,

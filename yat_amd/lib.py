@@ -24,6 +24,7 @@ class GemmEpilogue(C.Structure):
 SIGNATURES = {
     "yat_version": (I, []),
     "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
+    "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P]),
     "yat_colsum_workspace_bytes": (U64, [I, I]),
     "yat_colsum_bf16": (I, [I, I, P, I, P, I, P, P]),
     "yat_modulation_fwd": (I, [I, I, I, P, P, I, I, P, P]),
@@ -41,7 +42,7 @@ SIGNATURES = {
     "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P]),
     "yat_dwconv_glu_bwd_workspace_bytes": (U64, [I, I, I, I]),
     "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P]),
-    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, I, P, P]),
+    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, I, P, P]),
     "yat_gate_bwd_workspace_bytes": (U64, [I, I, I]),
     "yat_gate_bwd": (I, [I, I, I, P, P, P, I, P, P, I, P, P]),
     "yat_act_fwd": (I, [I64, I, P, P, P]),

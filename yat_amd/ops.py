@@ -44,7 +44,7 @@ def _chk_bf16(*ts):
 
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
-         activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0):
+         activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0):
     """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
     _chk_bf16(a, b, out, bias, aux_out, gate, residual)
     lda = lda if lda is not None else (M if a_t else K)
@@ -58,8 +58,8 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _lib().yat_gemm_bf16(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
-                              C.byref(ep) if ep is not None else None, _stream())
+    rc = _lib().yat_gemm_bf16_ex(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
+                                 C.byref(ep) if ep is not None else None, variant, _stream())
     if timer is not None:
         e1.record()
         timer.append((2.0 * M * N * K, e0, e1))
@@ -201,8 +201,9 @@ def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, 
 
 
 # ----------------------------------------------------------------------------------------------- GLUMBConv middle
-def dwconv_glu_fwd(z, B, h, w, Hc, wdw, bdw, y):
-    rc = _lib().yat_dwconv_glu_fwd(B, h, w, Hc, _p(z), _p(wdw), _p(bdw), _p(y), _stream())
+def dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y):
+    """s = bf16(SiLU(conv_inverted output)) as written by the GEMM epilogue."""
+    rc = _lib().yat_dwconv_glu_fwd(B, h, w, Hc, _p(s), _p(wdw), _p(bdw), _p(y), _stream())
     _l.check(rc, "yat_dwconv_glu_fwd")
     return y
 
@@ -211,8 +212,8 @@ def dwconv_glu_bwd_workspace_bytes(B, h, w, Hc):
     return int(_lib().yat_dwconv_glu_bwd_workspace_bytes(B, h, w, Hc))
 
 
-def dwconv_glu_bwd(z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False):
-    rc = _lib().yat_dwconv_glu_bwd(B, h, w, Hc, _p(z), _p(wdw), _p(bdw), _p(dy), _p(dz), _p(dwdw), _p(dbdw),
+def dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False):
+    rc = _lib().yat_dwconv_glu_bwd(B, h, w, Hc, _p(s), _p(z), _p(wdw), _p(bdw), _p(dy), _p(dz), _p(dwdw), _p(dbdw),
                                    int(accumulate), _p(workspace), _stream())
     _l.check(rc, "yat_dwconv_glu_bwd")
 

@@ -338,9 +338,11 @@ class SanaTransformer2DModelHIP(nn.Module):
             A.h2, A.mean2, A.rstd2 = ops.ln_modulate_fwd(
                 A.x2, mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, buf(f"b{i}.h2", (M, D)),
                 buf(f"b{i}.mean2", (M,), torch.float32), buf(f"b{i}.rstd2", (M,), torch.float32))
-            A.z = ops.linear_fwd(A.h2, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D),
-                                 P[pre + "ff.conv_inverted.bias"], out=buf(f"b{i}.z", (M, 2 * Hc)))
-            A.y = ops.dwconv_glu_fwd(A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
+            A.z = buf(f"b{i}.z", (M, 2 * Hc))                 # pre-activation (for SiLU' in backward)
+            A.s = ops.linear_fwd(A.h2, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D),
+                                 P[pre + "ff.conv_inverted.bias"], out=buf(f"b{i}.s", (M, 2 * Hc)),
+                                 activation="silu", aux_out=A.z)
+            A.y = ops.dwconv_glu_fwd(A.s, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                      P[pre + "ff.conv_depth.bias"], buf(f"b{i}.y", (M, Hc)))
             A.lin3 = buf(f"b{i}.lin3", (M, D))
             x = ops.linear_fwd(A.y, P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=buf(f"b{i}.x3", (M, D)),
@@ -412,7 +414,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             wgrad(dlin, A.y, pre + "ff.conv_point.weight", (D, Hc))
             dy = ops.linear_dgrad(dlin, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
             dz = buf("dz", (M, 2 * Hc))
-            ops.dwconv_glu_bwd(A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
+            ops.dwconv_glu_bwd(A.s, A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc)
             wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D))
