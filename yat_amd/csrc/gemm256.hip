@@ -38,7 +38,17 @@ template <int NT> struct Geo {
     static constexpr int PB = B_BYTES / 1024 / 8;      // (B): 4 / 5
 };
 
-__device__ __forceinline__ uint32_t trswz2(uint32_t krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+// Swizzle of the k-strided image (XOR on the 16-B chunk index of k-row `krow`; bit 0 untouched so a 32-B block of
+// ds_read_b64_tr_b16 stays together).  The 8 rows one 32-lane half reads ({0..3, 8..11} + 4n) must land on 8 distinct
+// 32-B blocks of the 256-B bank row:
+//  * row stride = 0 mod 256 B (256 columns): every row starts on the same bank -> XOR 3 bits (closed over 16 chunks);
+//  * row stride = 128 mod 256 B (320 columns, 40 chunks per row): odd rows are already offset by 128 B, so XOR only
+//    2 bits (closed over groups of 8 chunks -- a 4-bit XOR would leave the 40-chunk row).
+template <int COLS>
+__device__ __forceinline__ uint32_t trswz2(uint32_t krow) {
+    if ((COLS * 2) % 256 == 0) return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
+    return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
+}
 
 // loop-invariant part of one DMA piece: byte offset of this lane's 16-B chunk at k-tile 0 (or OOB),
 // and (row-mode only) the source chunk index inside the 64-wide k-tile for the ragged-K check.
@@ -57,7 +67,7 @@ __device__ __forceinline__ Piece make_piece(int piece, int lane, int ld, int idx
         constexpr int ROWB = ROWS_OR_COLS * 2;                 // bytes per k-row of the LDS image
         const uint32_t o = piece * 1024 + lane * 16;
         const uint32_t r = o / ROWB, slot = (o % ROWB) >> 4;
-        const uint32_t c = slot ^ trswz2(r);
+        const uint32_t c = slot ^ trswz2<ROWS_OR_COLS>(r);
         const int gi = idx0 + c * 8;
         pc.kchunk = 0;
         pc.voff = gi < idx_max ? (uint32_t)(((int64_t)r * ld + gi) * 2) : YAT_OOB;   // k-rows past K: buffer range check
@@ -76,7 +86,7 @@ __device__ __forceinline__ bf16x8 frag256(const char* lds, int idx0, int kk, int
         const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const uint32_t col = idx0 + 4 * p;
         const uint32_t r0 = kk * 32 + 8 * g + q, r1 = r0 + 4;
-        const uint32_t c0 = (col >> 3) ^ trswz2(r0), c1 = (col >> 3) ^ trswz2(r1);
+        const uint32_t c0 = (col >> 3) ^ trswz2<COLS>(r0), c1 = (col >> 3) ^ trswz2<COLS>(r1);
         return cat4(lds_read_tr4(lds, r0 * ROWB + c0 * 16 + (p & 1) * 8), lds_read_tr4(lds, r1 * ROWB + c1 * 16 + (p & 1) * 8));
     }
 }
