@@ -98,8 +98,10 @@ int yat_rmsnorm_bwd(int M, int D, const void* x, const void* w, const float* rst
 uint64_t yat_linear_attn_workspace_bytes(int B, int N, int H);
 int yat_linear_attn_fwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, void* out, int ld_out,
                         void* workspace, yat_stream_t stream);
+/* state: the forward's per-head state = the first B*H*33*32 floats of the forward workspace if the caller kept it
+ * (saves recomputing it), or NULL to recompute. */
 int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, const void* dout,
-                        int ld_dout, void* dqkv, int ld_dqkv, void* workspace, yat_stream_t stream);
+                        int ld_dout, void* dqkv, int ld_dqkv, const float* state, void* workspace, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Masked softmax cross-attention (attn2 = AttnProcessor2_0 / F.scaled_dot_product_attention,

@@ -349,6 +349,11 @@ def test_linear_attn_fwd_bwd(ops, B, N, H):
     dqkv = torch.empty_like(qkv)
     ops.linear_attn_bwd(qkv, B, N, H, D, 2 * D, dout, dqkv, ws)
     close(dqkv, qr.grad.to(BF), f"linattn_bwd N={N}", tol=4e-3, ulps=3, atol=1e-4)
+    # with the forward's state handed back (what the model does) the result is bit-identical
+    state = ws.view(torch.float32)[: B * H * 33 * 32].clone()
+    dqkv2 = torch.empty_like(qkv)
+    ops.linear_attn_bwd(qkv, B, N, H, D, 2 * D, dout, dqkv2, ws, state=state)
+    assert torch.equal(dqkv, dqkv2)
 
 
 def _sdpa_ref(q, k, v, bias, B, N, T, H, dh, scale):

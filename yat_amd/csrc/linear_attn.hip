@@ -242,7 +242,7 @@ int yat_linear_attn_fwd(int B, int N, int H, const void* qkv, int ld, int k_off,
 }
 
 int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, const void* dout, int ld_dout,
-                        void* dqkv, int ld_dqkv, void* workspace, yat_stream_t stream) {
+                        void* dqkv, int ld_dqkv, const float* state, void* workspace, yat_stream_t stream) {
     if (B <= 0 || N <= 0 || H <= 0 || (ld & 7) || (k_off & 7) || (v_off & 7) || (ld_dout & 7) || (ld_dqkv & 7) || !qkv ||
         !dout || !dqkv || !workspace)
         return YAT_EINVAL;
@@ -251,8 +251,12 @@ int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off,
     float* dS = S + (int64_t)B * H * SS;
     float* part = dS + (int64_t)B * H * SS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(la_state_kv_kernel, dim3(H, B), dim3(256), 0, st, N, (const bf16_t*)qkv, ld, k_off, v_off, S);
-    YAT_CHECK_LAUNCH();
+    if (state) {
+        S = const_cast<float*>(state);          // the forward's state (first B*H*33*32 floats of its workspace), kept by the caller
+    } else {
+        hipLaunchKernelGGL(la_state_kv_kernel, dim3(H, B), dim3(256), 0, st, N, (const bf16_t*)qkv, ld, k_off, v_off, S);
+        YAT_CHECK_LAUNCH();
+    }
     constexpr int BQ_LDS = TB * (36 + C) * (int)sizeof(float);
     static bool attr_set = false;   // idempotent one-time launch attribute (LDS > 64 KiB)
     if (!attr_set) {

@@ -147,7 +147,7 @@ int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_
     a.zero_grad = zero_grad;
     const int64_t nvec = n >> 3;
     int64_t nb = (nvec + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, nvec, (bf16_t*)param,
                        (bf16_t*)grad, (bf16_t*)exp_avg, (bf16_t*)exp_avg_sq, clip_coef, (bf16_t*)ema_shadow, a);
     YAT_CHECK_LAUNCH();

@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int TILE = 16384;  // one [64][128] bf16 image
+constexpr int DKV_STAGE = 4 * TILE + 512;   // one query-tile stage of the dK/dV kernel
 
 enum { IMG_ROW = 0, IMG_TR = 1 };
 
@@ -262,12 +263,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qs = smem;               // ROW image of Q
-    char* Os = smem + TILE;        // ROW image of dO
-    char* Qt = smem + 2 * TILE;    // TR image of Q
-    char* Ot = smem + 3 * TILE;    // TR image of dO
-    float* lse_s = reinterpret_cast<float*>(smem + 4 * TILE);   // [64]
-    float* del_s = lse_s + 64;                                  // [64]
+    // stage layout: ROW image of Q | ROW image of dO | TR image of Q | TR image of dO | lse[64] | delta[64]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -307,21 +303,33 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) { adk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    for (int q0 = 0; q0 < p.N; q0 += 64) {
-        __syncthreads();
+    // double-buffered query tiles: tile qt+1 is DMA'd while tile qt is consumed
+    auto stage_q = [&](int q0, char* base) {
         const int64_t r0 = (int64_t)b * p.N + q0, rl = (int64_t)b * p.N + p.N;
-        stage64x128<IMG_ROW>(rq, Qs, r0, rl, p.ldq, col0, p.dh, wave, lane);
-        stage64x128<IMG_ROW>(rdo, Os, r0, rl, p.lddo, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rq, Qt, r0, rl, p.ldq, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rdo, Ot, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        stage64x128<IMG_ROW>(rq, base, r0, rl, p.ldq, col0, p.dh, wave, lane);
+        stage64x128<IMG_ROW>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rq, base + 2 * TILE, r0, rl, p.ldq, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rdo, base + 3 * TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
         if (threadIdx.x < 64) {
+            float* ls = reinterpret_cast<float*>(base + 4 * TILE);
             const int qi = q0 + threadIdx.x;
             const int64_t si = ((int64_t)b * p.H + h) * p.N + qi;
-            lse_s[threadIdx.x] = qi < p.N ? p.lse[si] : 1e30f;
-            del_s[threadIdx.x] = qi < p.N ? p.delta[si] : 0.f;
+            ls[threadIdx.x] = qi < p.N ? p.lse[si] : 1e30f;
+            ls[64 + threadIdx.x] = qi < p.N ? p.delta[si] : 0.f;
         }
+    };
+    stage_q(0, smem);
+    for (int q0 = 0, it = 0; q0 < p.N; q0 += 64, ++it) {
+        char* cur = smem + (it & 1) * DKV_STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();      // tile `it` landed everywhere; every wave is done with the other stage
+        if (q0 + 64 < p.N) stage_q(q0 + 64, smem + ((it + 1) & 1) * DKV_STAGE);
+        const char* Qs = cur;
+        const char* Os = cur + TILE;
+        const char* Qt = cur + 2 * TILE;
+        const char* Ot = cur + 3 * TILE;
+        const float* lse_s = reinterpret_cast<const float*>(cur + 4 * TILE);
+        const float* del_s = lse_s + 64;
 
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     }
 }
 
-constexpr int FWD_LDS = 2 * TILE, DQ_LDS = 3 * TILE, DKV_LDS = 4 * TILE + 512;
+constexpr int FWD_LDS = 2 * TILE, DQ_LDS = 3 * TILE, DKV_LDS = 2 * (4 * TILE + 512);
 
 int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv) {
     if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7)) return YAT_EINVAL;

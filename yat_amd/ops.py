@@ -176,9 +176,9 @@ def linear_attn_fwd(qkv2d, B, N, H, k_off, v_off, out, workspace):
     return out
 
 
-def linear_attn_bwd(qkv2d, B, N, H, k_off, v_off, dout, dqkv, workspace):
+def linear_attn_bwd(qkv2d, B, N, H, k_off, v_off, dout, dqkv, workspace, state=None):
     rc = _lib().yat_linear_attn_bwd(B, N, H, _p(qkv2d), qkv2d.stride(0), k_off, v_off, _p(dout), dout.stride(0),
-                                    _p(dqkv), dqkv.stride(0), _p(workspace), _stream())
+                                    _p(dqkv), dqkv.stride(0), _p(state), _p(workspace), _stream())
     _l.check(rc, "yat_linear_attn_bwd")
     return dqkv
 

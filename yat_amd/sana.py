@@ -307,7 +307,6 @@ class SanaTransformer2DModelHIP(nn.Module):
                               out=buf("cap_c2", (Mt, D)))
         S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, buf("cap_n", (Mt, D)),
                                              buf("cap_rstd", (Mt,), torch.float32))
-        la_ws = buf("la_ws", (ops.linear_attn_workspace_bytes(B, N, H1),), torch.uint8)
         scale2 = 1.0 / math.sqrt(dh2)
         # 4. transformer blocks
         for i in range(cfg.num_layers):
@@ -320,7 +319,8 @@ class SanaTransformer2DModelHIP(nn.Module):
                 buf(f"b{i}.mean1", (M,), torch.float32), buf(f"b{i}.rstd1", (M,), torch.float32))
             wqkv, _ = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
             A.qkv = ops.linear_fwd(A.h1, wqkv, out=buf(f"b{i}.qkv", (M, 3 * D)))
-            A.attn = ops.linear_attn_fwd(A.qkv, B, N, H1, D, 2 * D, buf(f"b{i}.attn", (M, D)), la_ws)
+            A.la_state = buf(f"b{i}.la_state", (B * H1 * 33 * 32,), torch.float32)     # kept for the backward
+            A.attn = ops.linear_attn_fwd(A.qkv, B, N, H1, D, 2 * D, buf(f"b{i}.attn", (M, D)), A.la_state)
             A.lin1 = buf(f"b{i}.lin1", (M, D))
             A.x1 = ops.linear_fwd(A.attn, P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"],
                                   out=buf(f"b{i}.x1", (M, D)), aux_out=A.lin1, gate=mod2d[:, 2 * D:3 * D],
@@ -446,7 +446,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             bgrad(dlin, pre + "attn1.to_out.0.bias")
             dattn = ops.linear_dgrad(dlin, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf("dqkv", (M, 3 * D))
-            ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws)
+            ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
             ops.linear_wgrad(dqkv, A.h1, gqkv, accumulate=acc)
             dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf("dh", (M, D)))
