@@ -14,11 +14,13 @@
 //   loads: the matrix pipe sees back-to-back MFMA segments.
 //
 // LDS-DMA protocol (the only ordering for a DMA'd tile is the issuing wave's vmcnt + a barrier the
-// reader has passed):  tile t+1 is issued at the top of a wave's iteration t into the stage that
-// held tile t-1 (all its reads retired by lgkmcnt(0) before the barrier every wave has passed by
-// then), is waited for with vmcnt(0) before the wave's 3rd barrier of iteration t, and is first
-// read after the 4th.  Barrier bookkeeping (n-th barrier of every wave is one rendezvous):
-//   group 0, iteration t: barriers 4t+1..4t+4;  group 1: 4t+2..4t+5.
+// reader has passed).  Barrier bookkeeping: the n-th barrier of every wave is one rendezvous; group 0's
+// iteration t spans rendezvous 4t+1..4t+4, group 1's 4t+2..4t+5; tile u (stage u&1) is first read after
+// rendezvous 4u and last read before 4u+4.  DMA pieces are issued INSIDE compute segments, between
+// groups of four MFMAs (measured: with the issue in a load segment that segment outlasts the partner's
+// compute segment and the matrix pipe idles ~30 %): group 0 issues tile t+1 in COMPUTE(t,ks0) and waits
+// before its 4th barrier of iteration t; group 1 issues tile t+2 in COMPUTE(t,ks1) and waits for tile
+// t+1 before its 3rd barrier of iteration t -- both waits precede rendezvous 4t+4.
 //
 // Operand layouts, swizzles, swapped-operand MFMA and epilogue are those of gemm.hip.
 #include "common.hpp"
@@ -157,15 +159,63 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    bf16x8 af[8], bfr[NT];
+    // one DMA piece of tile t (j < PA: operand A, else operand B)
+    auto issue_piece = [&](int t, char* stage, int j) {
+        const bool tail = ragged && t == nt - 1;
+        const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
+        if (j < G::PA) {
+            uint32_t v = pa[j].voff + (uint32_t)t * a_kstep;
+            if (!A_T && tail && pa[j].kchunk >= kvalid) v = YAT_OOB;
+            lds_dma16(ra, (YAT_LDS void*)(stage + (wave + 8 * j) * 1024), v);
+        } else {
+            const int jb = j - G::PA;
+            uint32_t v = pb[jb].voff + (uint32_t)t * b_kstep;
+            if (!B_T && tail && pb[jb].kchunk >= kvalid) v = YAT_OOB;
+            lds_dma16(rb, (YAT_LDS void*)(stage + G::A_BYTES + (wave + 8 * jb) * 1024), v);
+        }
+    };
+    constexpr int NPIECE = G::PA + G::PB;        // 8 or 9 pieces per wave per tile
+
+    // COMPUTE segment: 8 x NT MFMAs on registers; when dma_tile >= 0 this wave's DMA pieces for that tile are
+    // issued between groups of 4 MFMAs (the matrix pipe keeps draining queued MFMAs while the wave issues a DMA),
+    // so the LOAD segments carry only the fragment reads and stay shorter than the partner's COMPUTE segment.
+    auto compute = [&](int dma_tile) {
+        char* dst = smem + (dma_tile & 1) * G::STAGE;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
+                const int idx = i * NT + j;
+                if (idx % 4 == 3 && idx / 4 < NPIECE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma_tile >= 0) issue_piece(dma_tile, dst, idx / 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
     issue(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
-    if (grp == 1) YAT_PHASE_BARRIER();         // stagger: group 1 runs one segment behind group 0
+    if (grp == 1) {
+        // group 1 issues tile t+2 inside its COMPUTE(t, ks1), so its share of tile 1 goes out here
+        if (nt > 1) issue(1, smem + G::STAGE);
+        YAT_PHASE_BARRIER();                   // stagger: group 1 runs one segment behind group 0
+    }
 
-    bf16x8 af[8], bfr[NT];
+    // DMA protocol (n-th barrier of every wave is one rendezvous; group 0's iteration t spans 4t+1..4t+4, group 1's
+    // 4t+2..4t+5).  Tile u lives in stage u&1 and is first read after rendezvous 4u.
+    //   group 0 issues its pieces of tile t+1 in COMPUTE(t,ks0)  [after 4t+1 > 4t: stage free] and waits for them
+    //           before its 4th barrier of iteration t (= 4t+4);
+    //   group 1 issues its pieces of tile t+2 in COMPUTE(t,ks1)  [after 4t+4: every read of tile t retired] and waits
+    //           for tile t+1's pieces before its 3rd barrier of iteration t (= 4t+4).
     for (int t = 0; t < nt; ++t) {
         const char* cur = smem + (t & 1) * G::STAGE;
-        if (t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * G::STAGE);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
@@ -174,15 +224,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) bfr[j] = frag256<B_T, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (kk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t+1 landed (this wave's pieces)
+            if (kk == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 (group 1's pieces)
             YAT_PHASE_BARRIER();
-            // ---- COMPUTE segment (registers only)
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
-            __builtin_amdgcn_s_setprio(0);
+            // ---- COMPUTE segment
+            int dma_tile = -1;
+            if (kk == 0 && grp == 0 && t + 1 < nt) dma_tile = t + 1;
+            if (kk == 1 && grp == 1 && t + 2 < nt) dma_tile = t + 2;
+            compute(dma_tile);
+            if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 (group 0's pieces)
             YAT_PHASE_BARRIER();
         }
     }
