@@ -180,6 +180,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
     // COMPUTE segment: 8 x NT MFMAs on registers; when dma_tile >= 0 this wave's DMA pieces for that tile are
     // issued between groups of 4 MFMAs (the matrix pipe keeps draining queued MFMAs while the wave issues a DMA),
     // so the LOAD segments carry only the fragment reads and stay shorter than the partner's COMPUTE segment.
+    constexpr bool DIC_ = A_T || B_T;
     auto compute = [&](int dma_tile) {
         char* dst = smem + (dma_tile & 1) * G::STAGE;
         __builtin_amdgcn_s_setprio(1);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
             for (int j = 0; j < NT; ++j) {
                 acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
                 const int idx = i * NT + j;
-                if (idx % 4 == 3 && idx / 4 < NPIECE) {
+                if (DIC_ && idx % 4 == 3 && idx / 4 < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (dma_tile >= 0) issue_piece(dma_tile, dst, idx / 4);
                     __builtin_amdgcn_sched_barrier(0);
@@ -199,12 +200,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // Where the DMA issue goes is a measured choice (gemm micro-benchmark, SANA shapes): with both operands
+    // k-contiguous the load segment is short (12-13 ds_read_b128) and absorbs the issue for free, while DMA between
+    // MFMAs costs 15-20 %; with a k-strided operand (twice the LDS read instructions + swizzle arithmetic) the load
+    // segment is the long pole and the issue belongs in the compute segment (+12..20 %).
+    constexpr bool DIC = A_T || B_T;           // DMA In Compute segment
+
     issue(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
     if (grp == 1) {
-        // group 1 issues tile t+2 inside its COMPUTE(t, ks1), so its share of tile 1 goes out here
-        if (nt > 1) issue(1, smem + G::STAGE);
+        // (DIC) group 1 issues tile t+2 inside its COMPUTE(t, ks1), so its share of tile 1 goes out here
+        if (DIC && nt > 1) issue(1, smem + G::STAGE);
         YAT_PHASE_BARRIER();                   // stagger: group 1 runs one segment behind group 0
     }
 
@@ -214,8 +221,11 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
     //           before its 4th barrier of iteration t (= 4t+4);
     //   group 1 issues its pieces of tile t+2 in COMPUTE(t,ks1)  [after 4t+4: every read of tile t retired] and waits
     //           for tile t+1's pieces before its 3rd barrier of iteration t (= 4t+4).
+    //   (!DIC) every wave issues tile t+1 at the top of LOAD(t,ks0) [after its 4th barrier of iteration t-1 >= 4t]
+    //           and waits before its 3rd barrier of iteration t (<= 4t+4).
     for (int t = 0; t < nt; ++t) {
         const char* cur = smem + (t & 1) * G::STAGE;
+        if (!DIC && t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * G::STAGE);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
@@ -224,21 +234,60 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) bfr[j] = frag256<B_T, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (kk == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 (group 1's pieces)
+            if (kk == 1 && (!DIC || grp == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
             YAT_PHASE_BARRIER();
             // ---- COMPUTE segment
             int dma_tile = -1;
-            if (kk == 0 && grp == 0 && t + 1 < nt) dma_tile = t + 1;
-            if (kk == 1 && grp == 1 && t + 2 < nt) dma_tile = t + 2;
+            if (DIC && kk == 0 && grp == 0 && t + 1 < nt) dma_tile = t + 1;
+            if (DIC && kk == 1 && grp == 1 && t + 2 < nt) dma_tile = t + 2;
             compute(dma_tile);
-            if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 (group 0's pieces)
+            if (DIC && kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 (group 0's pieces)
             YAT_PHASE_BARRIER();
         }
     }
     if (grp == 0) YAT_PHASE_BARRIER();         // pair group 1's last barrier
 
-    // ---- epilogue: lane owns row m = ..+(lane&15), cols n = ..+4*(lane>>4) + 0..3
+    // ---- epilogue.  The MFMA layout gives a lane 4 columns of 16 different rows (8-B accesses in 32-B runs).  When
+    // everything is 16-B aligned the accumulators go through the (now free) LDS instead: each wave transposes 32 rows
+    // at a time in a private padded fp32 slab and reads back 8 consecutive columns per lane, so bias / gate / residual
+    // loads and C / aux stores are 16 B per lane over whole 128..160-B row segments.
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+    const bool wide = !(p.N & 7) && !(p.ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
+                      !(p.gate && (p.gate_ld & 7));
+    if (wide) {
+        constexpr int WCOLS = 16 * NT;             // columns per wave
+        constexpr int LDW = WCOLS + 4;             // padded fp32 row (conflict-free ds_write_b128)
+        constexpr int CPR = WCOLS / 8;             // 8-column chunks per row
+        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * LDW);
+        const int g4 = lane >> 4, li = lane & 15;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    *reinterpret_cast<f32x4*>(slab + (ii * 16 + li) * LDW + j * 16 + 4 * g4) = acc[pass * 2 + ii][j];
+            // wave-private slab: the wave's own LDS writes are ordered before its reads by lgkmcnt; no barrier needed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < (32 * CPR + 63) / 64; ++k) {
+                const int u = lane + 64 * k;
+                if (u < 32 * CPR) {
+                    const int row = u / CPR, ch = u % CPR;
+                    const int m = m0 + grp * 128 + pass * 32 + row;
+                    const int n = n0 + wc * WCOLS + ch * 8;
+                    if (m < p.M && n < p.N) {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8 + 4);
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        gemm_epilogue_store8(p, v, m, n, m / rpb);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next pass overwrites the slab
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + grp * 128 + i * 16 + (lane & 15);

@@ -52,5 +52,40 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4&
     *reinterpret_cast<u32x2*>(p.C + (int64_t)m * p.ldc + n) = pack4(v[0], v[1], v[2], v[3]);
 }
 
+// Same for 8 consecutive columns (16-B accesses; n % 8 == 0 and every leading dimension % 8 == 0).
+__device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[8], int m, int n, int b) {
+    if (p.bias) {
+        float bb[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+    }
+    if (p.aux || p.act || p.res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]);
+    }
+    if (p.aux) *reinterpret_cast<u32x4*>(p.aux + (int64_t)m * p.ldaux + n) = pack8(v);
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+    }
+    if (p.gate) {
+        float g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.gate + (int64_t)b * p.gate_ld + n), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(g[e] * v[e]);
+    }
+    if (p.res) {
+        float r[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.res + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    *reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + n) = pack8(v);
+}
+
 // gemm256.hip
 int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream);
