@@ -47,10 +47,14 @@ typedef struct yat_gemm_epilogue {
 int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                   void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream);
 
-/* Same, with an explicit tile variant for tests / tuning: 0 = automatic policy (what yat_gemm_bf16 uses),
- * 1 = 128x128 tile, 4 = 256x256 tile, 5 = 256x320 tile (two staggered wave groups, gemm256.hip). */
+/* Same, with an optional split-K workspace and an explicit tile variant for tests / tuning.
+ * variant: 0 = automatic policy, 1 = 128x128 tile, 4 = 256x256 tile, 5 = 256x320 tile (two staggered wave groups,
+ * gemm256.hip); 100*s + v forces split-K factor s (2 or 4) on variant v (4 or 5).
+ * workspace (fp32, >= ksplit*M*N*4 bytes) lets the policy split K for shapes that leave CUs idle (small outputs with a
+ * long reduction: weight gradients); with workspace == NULL K is never split. */
 int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                     void* C, int ldc, const yat_gemm_epilogue* ep, int variant, yat_stream_t stream);
+                     void* C, int ldc, const yat_gemm_epilogue* ep, int variant, void* workspace,
+                     uint64_t workspace_bytes, yat_stream_t stream);
 
 /* out[c] (+)= sum_r x[r, c]  (bias gradients).  workspace: >= yat_colsum_workspace_bytes(rows, cols). */
 uint64_t yat_colsum_workspace_bytes(int rows, int cols);

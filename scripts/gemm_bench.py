@@ -26,9 +26,10 @@ for name, lay, m, n, k in SHAPES:
     b = (torch.randn((k, n) if b_t else (n, k), device=dev) * 0.05).to(BF)
     out = torch.empty(m, n, dtype=BF, device=dev)
     ref = None
-    times = {1: [], 4: [], 5: [], 0: []}
+    VARS = (1, 4, 5, 204, 205, 405, 0)
+    times = {v: [] for v in VARS}
     for r in range(rounds + 1):
-        for v in (1, 4, 5, 0):
+        for v in VARS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
@@ -46,7 +47,8 @@ for name, lay, m, n, k in SHAPES:
     fl = 2.0 * m * n * k
     line = {v: fl / (sorted(t)[len(t) // 2] * 1e-3) / 1e12 for v, t in times.items()}
     res[name] = line
-    print(f"{name:12s} {lay} {m:6d}x{n:6d}x{k:6d}  v128={line[1]:7.1f}  v256={line[4]:7.1f}  v320={line[5]:7.1f}  auto={line[0]:7.1f} TF", flush=True)
+    print(f"{name:12s} {lay} {m:6d}x{n:6d}x{k:6d}  v128={line[1]:7.1f}  v256={line[4]:7.1f}  v320={line[5]:7.1f}  "
+          f"2x256={line[204]:7.1f}  2x320={line[205]:7.1f}  4x320={line[405]:7.1f}  auto={line[0]:7.1f} TF", flush=True)
 tot_fl = {v: 0.0 for v in (1, 4, 5, 0)}
 tot_t = {v: 0.0 for v in (1, 4, 5, 0)}
 mult = {"out_fwd": 3, "out_dgrad": 3, "out_wgrad": 3}
@@ -55,7 +57,7 @@ for name, lay, m, n, k in SHAPES:
         c = mult.get(name, 1)
         tot_t[v] += c * 2.0 * m * n * k / (res[name][v] * 1e12)
         tot_fl[v] += c * 2.0 * m * n * k
-best = sum(mult.get(n_, 1) * 2.0 * m * n * k / (max(res[n_][v] for v in (1, 4, 5)) * 1e12) for n_, lay, m, n, k in SHAPES)
+best = sum(mult.get(n_, 1) * 2.0 * m * n * k / (max(res[n_][v] for v in res[n_] if v != 0) * 1e12) for n_, lay, m, n, k in SHAPES)
 print("per-block GEMM time (ms): " + "  ".join(f"v{v}={tot_t[v]*1e3:.2f}" for v in (1, 4, 5, 0)) + f"  best-per-shape={best*1e3:.2f}")
 print("aggregate TF: " + "  ".join(f"v{v}={tot_fl[v]/tot_t[v]/1e12:.0f}" for v in (1, 4, 5, 0)))
 json.dump(res, open("gpurun_out/gemm_bench.json", "w"), indent=1)

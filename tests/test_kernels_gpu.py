@@ -161,6 +161,25 @@ def test_gemm256_epilogue_and_identity(ops, variant):
     close(s_out, F.silu(linr).to(BF), f"gemm256v{variant}_epi_silu")
 
 
+@pytest.mark.parametrize("code", [204, 405, 205])
+def test_gemm256_split_k(ops, code):
+    """Split-K (fp32 slabs + reduce kernel with the fused epilogue), forced via variant = 100*ksplit + tile."""
+    M, N, K = 520, 648, 2048 + 96                     # ragged everything; K tail lands in the last slice
+    dy, x = rnd(K, M, scale=K ** -0.5, seed=90), rnd(K, N, seed=91)            # wgrad layout: both k-strided
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm(dy, x, out, a_t=True, b_t=True, M=M, N=N, K=K, variant=code)
+    ref = dy.float().T @ x.float()
+    close(out, ref.to(BF), f"splitk{code}_tn")
+    ops.gemm(dy, x, out, a_t=True, b_t=True, M=M, N=N, K=K, variant=code, residual=out)      # accumulate
+    close(out, (rb(ref) + rb(ref)).to(BF), f"splitk{code}_tn_acc")
+    a, w, bias = rnd(M, K, seed=92), rnd(N, K, scale=K ** -0.5, seed=93), rnd(N, seed=94)
+    z = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm(a, w, out, M=M, N=N, K=K, variant=code, bias=bias, activation="silu", aux_out=z)
+    zr = rb(a.float() @ w.float().T + bias.float())
+    close(z, zr, f"splitk{code}_nt_preact")
+    close(out, F.silu(zr).to(BF), f"splitk{code}_nt_silu")
+
+
 def test_gemm_asymmetric_identity(ops):
     """A = I with an asymmetric B catches a transposed C-write or a swapped fragment map."""
     n = 128

@@ -163,16 +163,19 @@ double est_time_128(int M, int N, int K) {
     const double rounds = ceil(tiles / 512.0);
     return rounds * 2.0 * (2.0 * 128 * 128 * (double)K) / 3.4e12;
 }
-double est_time_256(int M, int N, int K, int BNv) {
-    const double tiles = (double)((M + 255) / 256) * ((N + BNv - 1) / BNv);
+double est_time_256(int M, int N, int K, int BNv, int ksplit) {
+    const double tiles = (double)((M + 255) / 256) * ((N + BNv - 1) / BNv) * ksplit;
     const double rounds = ceil(tiles / 256.0);
-    return rounds * (2.0 * 256 * BNv * (double)K) / 5.0e12;
+    double t = rounds * ((2.0 * 256 * BNv * (double)K / ksplit) / 5.0e12 + 8e-6);   // + per-workgroup fixed cost
+    if (ksplit > 1) t += (ksplit + 0.5) * (double)M * N * 4.0 / 4.0e12 + 3e-6;      // slab write + reduce pass
+    return t;
 }
 
 }  // namespace
 
 extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                                void* C, int ldc, const yat_gemm_epilogue* ep, int variant, yat_stream_t stream_) {
+                                void* C, int ldc, const yat_gemm_epilogue* ep, int variant, void* workspace,
+                                uint64_t workspace_bytes, yat_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return YAT_EINVAL;
     if ((N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return YAT_EINVAL;
@@ -180,7 +183,10 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     if (a_t && (M & 7)) return YAT_EINVAL;             // 16-B chunks along m
     if (b_t && (N & 7)) return YAT_EINVAL;
     if (!b_t && (K & 7)) return YAT_EINVAL;
+    int ksplit = 1;
+    if (variant >= 100) { ksplit = variant / 100; variant %= 100; }     // tests / tuning: 100*ksplit + variant
     if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) return YAT_EINVAL;
     GemmP p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -195,16 +201,29 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
     if (p.a_bytes > 0x7fffffffull || p.b_bytes > 0x7fffffffull) return YAT_EINVAL;
+    const bool wide_ok = !(N & 7) && !(ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
+                         !(p.gate && (p.gate_ld & 7));
     if (variant == 0) {
         variant = 1;
         if (M >= 1024 && N >= 512 && K >= 256) {
             double best = est_time_128(M, N, K);
-            const double t4 = est_time_256(M, N, K, 256), t5 = est_time_256(M, N, K, 320);
-            if (t4 < best) { best = t4; variant = 4; }
-            if (t5 < best) { best = t5; variant = 5; }
+            for (int v = 4; v <= 5; ++v)
+                for (int s = 1; s <= 4; s *= 2) {
+                    if (s > 1 && (!workspace || !wide_ok || (uint64_t)s * M * N * 4 > workspace_bytes || K / s < 512)) continue;
+                    const double t = est_time_256(M, N, K, v == 4 ? 256 : 320, s);
+                    if (t < best) { best = t; variant = v; ksplit = s; }
+                }
         }
     }
-    if (variant == 4 || variant == 5) return yat_gemm256_launch(a_t, b_t, variant, p, stream);
+    if (variant == 4 || variant == 5) {
+        if (ksplit > 1 && (!workspace || !wide_ok || (uint64_t)ksplit * M * N * 4 > workspace_bytes)) return YAT_EINVAL;
+        p.ksplit = ksplit;
+        p.partial = (float*)workspace;
+        const int rc = yat_gemm256_launch(a_t, b_t, variant, p, stream);
+        if (rc || ksplit == 1) return rc;
+        return yat_gemm_splitk_reduce(p, stream);
+    }
+    if (ksplit != 1) return YAT_EINVAL;
     p.nbm = (M + BM - 1) / BM; p.nbn = (N + BN - 1) / BN;
     static bool attr_set = false;   // idempotent one-time launch attribute (64 KiB dynamic LDS)
     if (!attr_set) {
@@ -226,5 +245,5 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
 
 extern "C" int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                              void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream) {
-    return yat_gemm_bf16_ex(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, ep, 0, stream);
+    return yat_gemm_bf16_ex(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, ep, 0, nullptr, 0, stream);
 }

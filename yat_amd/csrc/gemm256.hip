@@ -108,12 +108,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wc = wave & 3;
 
-    const int nwg = p.nbm * p.nbn;
+    const int nwg = p.nbm * p.nbn * p.ksplit;
     int id;
     {
         const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
+    const int ksl = id % p.ksplit;             // K slice of this workgroup (slices of one tile are neighbours -> same XCD)
+    id /= p.ksplit;
     const int GROUP = 4;
     const int per_group = GROUP * p.nbn;
     const int gid = id / per_group, first_m = gid * GROUP;
@@ -133,11 +135,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
     for (int j = 0; j < G::PB; ++j) pb[j] = make_piece<B_T, G::BN>(wave + 8 * j, lane, p.ldb, n0, p.N);
     const uint32_t a_kstep = A_T ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
     const uint32_t b_kstep = B_T ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
-    const int nt = (p.K + BK - 1) / BK;
+    const int nt_all = (p.K + BK - 1) / BK;
+    const int kt0 = (int)(((int64_t)nt_all * ksl) / p.ksplit);                 // this slice: k-tiles [kt0, kt0 + nt)
+    const int nt = (int)(((int64_t)nt_all * (ksl + 1)) / p.ksplit) - kt0;
     const bool ragged = (p.K & (BK - 1)) != 0;
 
-    auto issue = [&](int t, char* stage) {
-        const bool tail = ragged && t == nt - 1;
+    auto issue = [&](int tl, char* stage) {
+        const int t = kt0 + tl;                                      // global k-tile
+        const bool tail = ragged && t == nt_all - 1;
         const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;     // valid 16-B chunks in this k-tile (row-mode)
 #pragma unroll
         for (int j = 0; j < G::PA; ++j) {
@@ -161,8 +166,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
 
     bf16x8 af[8], bfr[NT];
     // one DMA piece of tile t (j < PA: operand A, else operand B)
-    auto issue_piece = [&](int t, char* stage, int j) {
-        const bool tail = ragged && t == nt - 1;
+    auto issue_piece = [&](int tl, char* stage, int j) {
+        const int t = kt0 + tl;
+        const bool tail = ragged && t == nt_all - 1;
         const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
         if (j < G::PA) {
             uint32_t v = pa[j].voff + (uint32_t)t * a_kstep;
@@ -254,7 +260,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
     const bool wide = !(p.N & 7) && !(p.ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
                       !(p.gate && (p.gate_ld & 7));
-    if (wide) {
+    const bool split = p.ksplit > 1;           // host guarantees `wide` alignment when splitting
+    if (wide || split) {
         constexpr int WCOLS = 16 * NT;             // columns per wave
         constexpr int LDW = WCOLS + 4;             // padded fp32 row (conflict-free ds_write_b128)
         constexpr int CPR = WCOLS / 8;             // 8-column chunks per row
@@ -279,8 +286,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
                     if (m < p.M && n < p.N) {
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8);
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8 + 4);
-                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        gemm_epilogue_store8(p, v, m, n, m / rpb);
+                        if (split) {               // fp32 partial slab [ksl][m][n]; epilogue runs in the reduce kernel
+                            float* dst = p.partial + ((int64_t)ksl * p.M + m) * p.N + n;
+                            *reinterpret_cast<f32x4*>(dst) = lo;
+                            *reinterpret_cast<f32x4*>(dst + 4) = hi;
+                        } else {
+                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            gemm_epilogue_store8(p, v, m, n, m / rpb);
+                        }
                     }
                 }
             }
@@ -315,12 +328,39 @@ int launch256(const GemmP& p0, hipStream_t stream) {
             return YAT_EINVAL;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<A_T, B_T, NT>), dim3(p.nbm * p.nbn), dim3(512), G::LDS, stream, p);
+    if (p.ksplit < 1) p.ksplit = 1;
+    hipLaunchKernelGGL((gemm256_kernel<A_T, B_T, NT>), dim3(p.nbm * p.nbn * p.ksplit), dim3(512), G::LDS, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? YAT_OK : (int)e;
 }
 
 }  // namespace
+
+// out[m, n..n+7] = epilogue( sum_s partial[s][m][n..] ): one thread per 8 columns, 16-B accesses
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
+    const int64_t nchunk = (int64_t)p.M * (p.N >> 3);
+    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < nchunk; u += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(u / (p.N >> 3)), n = (int)(u % (p.N >> 3)) * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float* src = p.partial + ((int64_t)s * p.M + m) * p.N + n;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3];
+            v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
+        }
+        gemm_epilogue_store8(p, v, m, n, m / rpb);
+    }
+}
+
+int yat_gemm_splitk_reduce(const GemmP& p, hipStream_t stream) {
+    const int64_t nchunk = (int64_t)p.M * (p.N >> 3);
+    int64_t nb = (nchunk + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? YAT_OK : (int)e;
+}
 
 // variant: 4 -> BN=256, 5 -> BN=320
 int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream) {

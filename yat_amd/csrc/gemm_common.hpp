@@ -13,6 +13,8 @@ struct GemmP {
     int act;               // 0 none, 1 silu, 2 gelu_tanh
     int nbm, nbn;
     uint64_t a_bytes, b_bytes;
+    int ksplit;            // gemm256 only: > 1 -> each workgroup reduces K/ksplit and stores an fp32 partial slab
+    float* partial;        // [ksplit][M][N] fp32 (caller workspace)
 };
 
 // One lane's 4 consecutive output columns of row m (swapped-operand MFMA result):
@@ -89,3 +91,5 @@ __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[
 
 // gemm256.hip
 int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream);
+// sums the ksplit fp32 slabs and applies the fused epilogue
+int yat_gemm_splitk_reduce(const GemmP& p, hipStream_t stream);

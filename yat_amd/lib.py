@@ -24,7 +24,7 @@ class GemmEpilogue(C.Structure):
 SIGNATURES = {
     "yat_version": (I, []),
     "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
-    "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P]),
+    "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P, U64, P]),
     "yat_colsum_workspace_bytes": (U64, [I, I]),
     "yat_colsum_bf16": (I, [I, I, P, I, P, I, P, P]),
     "yat_modulation_fwd": (I, [I, I, I, P, P, I, I, P, P]),

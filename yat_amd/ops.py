@@ -15,6 +15,19 @@ from . import lib as _l
 BF16 = torch.bfloat16
 ACT = {"none": 0, "silu": 1, "gelu_tanh": 2}
 
+# Split-K workspace for the GEMM policy (fp32 partial slabs), one per device, allocated on first use.
+_GEMM_WS = {}
+GEMM_WS_BYTES = 96 << 20
+
+
+def _gemm_ws(device):
+    ws = _GEMM_WS.get(device)
+    if ws is None:
+        ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        _GEMM_WS[device] = ws
+    return ws
+
+
 # Optional live profiler for bench.py: when set to a list, every GEMM launch appends
 # (flops, start_event, end_event) recorded on the launch stream.
 GEMM_TIMER = None
@@ -58,8 +71,9 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = _gemm_ws(out.device)
     rc = _lib().yat_gemm_bf16_ex(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
-                                 C.byref(ep) if ep is not None else None, variant, _stream())
+                                 C.byref(ep) if ep is not None else None, variant, _p(ws), ws.numel(), _stream())
     if timer is not None:
         e1.record()
         timer.append((2.0 * M * N * K, e0, e1))
