@@ -1,19 +1,25 @@
-// ReLU linear attention (SANA self-attention, head dim 32) forward + backward for gfx950.
+// ReLU linear attention (SANA self-attention, head dim 32) forward + backward on MFMA for gfx950.
 //
 // Restates diffusers SanaLinearAttnProcessor2_0 (imported at
 // /root/reference/utils/patch_sana_attention_layers.py:7; stock attn1 processor of the model that
-// train_sana.py:210 trains):  q,k <- ReLU;  fp32:  S = [V;1] K   (33x32 per head),
-// U = S Q (33 x N),  out = U[:32] / (U[32] + 1e-15).
+// train_sana.py:210 trains):  q,k <- ReLU;  fp32:  S = [V;1]^T K  (33x32 per head),
+// U = Q S^T (N x 33),  out = U[:, :32] / (U[:, 32] + 1e-15).
 //
-// Two kinds of kernels:
-//  * state kernels, one workgroup per (batch, head): the token reduction S = A^T B runs
-//    register-tiled over LDS-staged token chunks (each thread owns a 4x1 strip of the 33x32 state:
-//    one ds_read_b128 broadcast + one ds_read_b32 per 4 FMAs) and lands in a global fp32 workspace;
-//  * apply kernels, one thread per token, grid (token chunks, heads, batch): the 33x32 state is
-//    wave-uniform, so it is read through the scalar cache (s_load) and every product
-//    (U = S q, dq = S^T dU, dv = dS k, dk = dS^T v') is a VALU FMA with an SGPR operand --
-//    no LDS traffic, no register blow-up.
-// fp32 throughout, as the reference up-casts q/k/v (0.2 % of block FLOPs; HBM/LDS-bound).
+// The reference up-casts q/k/v to fp32.  q, relu(k), v ARE bf16 values, so products with them are
+// exact in the fp32 accumulator of a bf16 MFMA; the fp32 state S (and dS, dU) is fed as a bf16
+// hi + lo pair (x = hi + lo + O(2^-17 x)), i.e. 2-3 MFMAs per product instead of an fp32 pipeline
+// at 1/16 of the rate.  All kernels are HBM-bound after that (0.2 % of the block's FLOPs).
+//
+//  state   : S[b,h] = sum_n [v_n;1] relu(k_n)^T.  Tokens are the contraction index, so both operands
+//            must be transposed: 64-token tiles of k and v are LDS-DMA'd (wave-private, 64-B rows)
+//            and fetched with ds_read_b64_tr_b16.  One workgroup per (b,h), 4 waves split the tokens.
+//  fwd     : per 16 tokens 6 MFMAs: U^T = [S_hi + S_lo] relu(q)^T, swapped so a lane owns 4 consecutive
+//            c' of one token (8-B stores); the denominator row is broadcast with one shuffle.
+//  bwd q   : recompute U, dU = dO/den, dU[32] = -(dO.O)/den, dq = dU S (accumulator-as-operand, S^T
+//            fragments in the accumulator's k order), and the partial dS = dU^T relu(q) of the
+//            workgroup's 256 tokens (dU goes through a wave-private LDS image to get tokens onto k).
+//  bwd kv  : dv = relu(k) dS[:32]^T, dk = [v;1] dS masked by k > 0.
+// (An earlier VALU version with the state read through the scalar cache took 9 ms per SANA-1.6B step.)
 #include "common.hpp"
 #include "../../include/yat_hip.h"
 
@@ -21,168 +27,338 @@ namespace {
 
 constexpr int C = 32;          // head dim
 constexpr int SS = 33 * C;     // floats per state
-constexpr int CH = 128;        // tokens per staging chunk in the state kernel
-constexpr int TB = 256;        // tokens per workgroup in the apply kernels
+constexpr int TB = 256;        // tokens per workgroup in the apply kernels (4 waves x 64)
 
-__device__ __forceinline__ void load32(const bf16_t* p, float* o) {
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) unpack8(*reinterpret_cast<const u32x4*>(p + j * 8), o + j * 8);
+    for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+    return z;
 }
-__device__ __forceinline__ void store32(bf16_t* p, const float* o) {
+__device__ __forceinline__ bf16x8 relu8(bf16x8 v) {
+    u32x4 u = __builtin_bit_cast(u32x4, v);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(p + j * 8) = pack8(o + j * 8);
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t neg = (u[i] >> 15) & 0x00010001u;       // sign bits of the two halves
+        u[i] &= ~(neg * 0xffffu);
+    }
+    return __builtin_bit_cast(bf16x8, u);
 }
-
-// s[c'][c] += sum_n a[n][c'] * b[n][c] over an LDS chunk; a rows have stride 36 floats (slot 32 =
-// the "ones" row), b rows stride 32.  Thread (c = t&31, g = t>>5) owns c' = 4g..4g+3; g == 0 also c' = 32.
-__device__ __forceinline__ void accum_state(const float* a_s, const float* b_s, int cnt, int c, int g, float (&s)[5]) {
-    for (int n = 0; n < cnt; ++n) {
-        const float bv = b_s[n * C + c];
-        const f32x4 av = *reinterpret_cast<const f32x4*>(a_s + n * 36 + 4 * g);
-        s[0] += av[0] * bv; s[1] += av[1] * bv; s[2] += av[2] * bv; s[3] += av[3] * bv;
-        if (g == 0) s[4] += a_s[n * 36 + 32] * bv;
+// fp32 x[8] -> bf16 hi and lo fragments with hi + lo ~= x
+__device__ __forceinline__ void split8(const float* x, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
     }
 }
-__device__ __forceinline__ void store_state(float* S, int c, int g, const float (&s)[5]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) S[(4 * g + i) * C + c] = s[i];
-    if (g == 0) S[32 * C + c] = s[4];
-}
-
-// S[b,h] = [V;1]^T relu(K), grid (H, B)
-__global__ __launch_bounds__(256) void la_state_kv_kernel(int N, const bf16_t* qkv, int ld, int k_off, int v_off,
-                                                          float* S_out) {
-    __shared__ __attribute__((aligned(16))) float a_s[CH * 36];
-    __shared__ __attribute__((aligned(16))) float b_s[CH * C];
-    const int t = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
-    const int c = t & 31, g = t >> 5;
-    const bf16_t* kb = qkv + (int64_t)b * N * ld + h * C + k_off;
-    const bf16_t* vb = qkv + (int64_t)b * N * ld + h * C + v_off;
-    float s[5] = {0, 0, 0, 0, 0};
-    const int tok = t >> 1, half = t & 1;   // staging: 2 threads per token, 16 channels each
-    for (int n0 = 0; n0 < N; n0 += CH) {
-        const int n = n0 + tok;
-        float kk[16], vv[16];
-        if (n < N) {
-            unpack8(*reinterpret_cast<const u32x4*>(kb + (int64_t)n * ld + half * 16), kk);
-            unpack8(*reinterpret_cast<const u32x4*>(kb + (int64_t)n * ld + half * 16 + 8), kk + 8);
-            unpack8(*reinterpret_cast<const u32x4*>(vb + (int64_t)n * ld + half * 16), vv);
-            unpack8(*reinterpret_cast<const u32x4*>(vb + (int64_t)n * ld + half * 16 + 8), vv + 8);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { kk[e] = 0.f; vv[e] = 0.f; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            b_s[tok * C + half * 16 + e] = fmaxf(kk[e], 0.f);
-            a_s[tok * 36 + half * 16 + e] = vv[e];
-        }
-        if (half == 0) a_s[tok * 36 + 32] = (n < N) ? 1.0f : 0.f;
-        __syncthreads();
-        accum_state(a_s, b_s, CH, c, g, s);
-    }
-    store_state(S_out + ((int64_t)b * gridDim.x + h) * SS, c, g, s);
-}
-
-// u[c'] = sum_c S[c'][c] x[c], c' < NR   (S wave-uniform -> scalar loads)
-template <int NR>
-__device__ __forceinline__ void state_times_vec(const float* __restrict__ S, const float* x, float* u) {
-#pragma unroll
-    for (int cp = 0; cp < NR; ++cp) {
-        float a = 0.f;
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) a += S[cp * C + cc] * x[cc];
-        u[cp] = a;
-        // keep at most two state rows (64 SGPRs) in flight: stops the scheduler from hoisting all
-        // 1056 scalar loads to the top and spilling them
-        if (cp & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-// y[c] = sum_{c' < NR} w[c'] S[c'][c]
-template <int NR>
-__device__ __forceinline__ void vec_times_state(const float* __restrict__ S, const float* w, float* y) {
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) y[cc] = 0.f;
-#pragma unroll
-    for (int cp = 0; cp < NR; ++cp) {
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) y[cc] += w[cp] * S[cp * C + cc];
-        if (cp & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// forward apply: grid (ceil(N/256), H, B)
-__global__ __launch_bounds__(256) void la_apply_fwd_kernel(int N, int H, const bf16_t* __restrict__ qkv, int ld,
-                                                           const float* __restrict__ S_all, bf16_t* __restrict__ out,
-                                                           int ld_out) {
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int n = blockIdx.x * TB + threadIdx.x;
-    const float* __restrict__ S = S_all + ((int64_t)b * H + h) * SS;
-    if (n >= N) return;
-    float q[C], u[33];
-    load32(qkv + ((int64_t)b * N + n) * ld + h * C, q);
-#pragma unroll
-    for (int e = 0; e < C; ++e) q[e] = fmaxf(q[e], 0.f);
-    state_times_vec<33>(S, q, u);
-    const float inv = 1.0f / (u[32] + 1e-15f);
-#pragma unroll
-    for (int e = 0; e < C; ++e) u[e] *= inv;
-    store32(out + ((int64_t)b * N + n) * ld_out + h * C, u);
-}
-
-// backward apply 1: per token dU, dq; per workgroup partial dS slab = dU^T relu(Q)
-// grid (nchunks, H, B); slabs dS_part[((b*H + h)*nchunks + chunk)][33*32]
-__global__ __launch_bounds__(256) void la_apply_bwd_q_kernel(int N, int H, const bf16_t* __restrict__ qkv, int ld,
-                                                             const bf16_t* __restrict__ dout, int ld_do,
-                                                             const float* __restrict__ S_all,
-                                                             const float* __restrict__ S_all_again,
-                                                             bf16_t* __restrict__ dqkv, int ld_dq,
-                                                             float* __restrict__ dS_part) {
-    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
-    float* a_s = dyn_lds;               // [TB][36]
-    float* b_s = dyn_lds + TB * 36;     // [TB][32]
-    const int t = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int n = blockIdx.x * TB + t;
-    const float* __restrict__ S = S_all + ((int64_t)b * H + h) * SS;
-    float q[C], du[33];
-    if (n < N) {
-        float dO[C];
-        load32(qkv + ((int64_t)b * N + n) * ld + h * C, q);
-        load32(dout + ((int64_t)b * N + n) * ld_do + h * C, dO);
-#pragma unroll
-        for (int e = 0; e < C; ++e) q[e] = fmaxf(q[e], 0.f);
-        state_times_vec<33>(S, q, du);                 // du <- U
-        const float inv = 1.0f / (du[32] + 1e-15f);
-        float dot = 0.f;
-#pragma unroll
-        for (int e = 0; e < C; ++e) {
-            dot += dO[e] * (du[e] * inv);              // dO . O
-            du[e] = dO[e] * inv;                       // dU[e]
-        }
-        du[32] = -dot * inv;
-        float dq[C];
-        // second sweep through a second (equal) kernel argument: the compiler cannot merge the two
-        // sweeps' loads, so the 33x32 state is re-read from the scalar cache instead of being kept
-        // live in (spilled) SGPRs
-        vec_times_state<33>(S_all_again + ((int64_t)b * H + h) * SS, du, dq);
-#pragma unroll
-        for (int e = 0; e < C; ++e) dq[e] = q[e] > 0.f ? dq[e] : 0.f;
-        store32(dqkv + ((int64_t)b * N + n) * ld_dq + h * C, dq);
+// rows of a [33][32] fp32 state as an operand fragment with NATURAL k order:
+// idx = row0 + (lane & 15) (zero beyond `nrows`), k = 8*(lane>>4) + j.
+__device__ __forceinline__ void state_frag_rows(const float* S, int row0, int nrows, int lane, bf16x8& hi, bf16x8& lo) {
+    float x[8];
+    const int r = row0 + (lane & 15);
+    if (r < nrows) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(S + r * C + 8 * (lane >> 4));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(S + r * C + 8 * (lane >> 4) + 4);
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
     } else {
 #pragma unroll
-        for (int e = 0; e < C; ++e) q[e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 33; ++e) du[e] = 0.f;
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
     }
+    split8(x, hi, lo);
+}
+// columns of the state (S^T) as an operand fragment: idx = c = col0 + (lane & 15); the contraction index is
+// the state ROW c' in {acc order: 4g+j (j<4), 16+4g+(j-4)} or {natural order: 8g+j}, rows >= 32 excluded.
+template <bool ACC_ORDER>
+__device__ __forceinline__ void state_frag_cols(const float* S, int col0, int lane, bf16x8& hi, bf16x8& lo) {
+    float x[8];
+    const int c = col0 + (lane & 15), g = lane >> 4;
 #pragma unroll
-    for (int e = 0; e < 33; ++e) a_s[t * 36 + e] = du[e];
+    for (int j = 0; j < 8; ++j) {
+        const int cp = ACC_ORDER ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j;
+        x[j] = S[cp * C + c];
+    }
+    split8(x, hi, lo);
+}
+__device__ __forceinline__ void acc2frag_hilo(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    split8(x, hi, lo);
+}
+// row-operand fragment of a token-major [n][32] head slice straight from global: idx = token, k = channel
+__device__ __forceinline__ bf16x8 tok_frag(const bf16_t* base, int ld, int tok, int N, int lane) {
+    bf16x8 z = zero8();
+    if (tok < N) z = *reinterpret_cast<const bf16x8*>(base + (int64_t)tok * ld + 8 * (lane >> 4));
+    return z;
+}
+// 4 consecutive channels (c0..c0+3) of token `tok` as floats (output layout of the swapped MFMA)
+__device__ __forceinline__ void tok4(const bf16_t* base, int ld, int tok, int N, int c0, float* o) {
+    if (tok < N) unpack4(*reinterpret_cast<const u32x2*>(base + (int64_t)tok * ld + c0), o);
+    else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+}
+
+// ------------------------------------------------------------------------------------------ state
+// grid (H, B); 4 waves, wave w reduces tokens [w*per, (w+1)*per) in 64-token tiles.
+// wave-private LDS: K tile [64][32] and V tile [64][32] (64-B rows, 32-B halves swapped on rows with bit 3 set).
+__global__ __launch_bounds__(256) void la_state_kernel(int N, const bf16_t* qkv, int ld, int k_off, int v_off,
+                                                       uint64_t bytes, float* S_out) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * 8192 + 4 * 6 * 64 * 16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.x, b = blockIdx.y;
+    char* kt = lds + wave * 8192;
+    char* vt = kt + 4096;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, bytes);
+    const int per = ((N + 3) / 4 + 63) / 64 * 64;           // tokens per wave, multiple of 64
+    const int n_begin = wave * per, n_end = min(N, n_begin + per);
+    const int64_t head_off = (int64_t)b * N * ld + h * C;
+
+    f32x4 acc[2][3];
 #pragma unroll
-    for (int e = 0; e < C; ++e) b_s[t * C + e] = q[e];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones = zero8();
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    }
+    const uint32_t g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+        // DMA: 4 pieces per tile, piece = 16 tokens x 64 B; lane -> (token = l>>2, 16-B slot = l&3)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int r = pc * 16 + (lane >> 2);
+            const int slot = lane & 3;
+            const int chunk = slot ^ (((r >> 3) & 1) << 1);
+            const int n = n0 + r;
+            const uint32_t vk = n < N ? (uint32_t)((head_off + (int64_t)n * ld + k_off + chunk * 8) * 2) : YAT_OOB;
+            const uint32_t vv = n < N ? (uint32_t)((head_off + (int64_t)n * ld + v_off + chunk * 8) * 2) : YAT_OOB;
+            lds_dma16(rs, (YAT_LDS void*)(kt + pc * 1024), vk);
+            lds_dma16(rs, (YAT_LDS void*)(vt + pc * 1024), vv);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave-private tiles: the issuing wave's wait is the ordering
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                       // 32 tokens per MFMA k-step
+            bf16x8 kf[2], vf[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const uint32_t col = ct * 16 + 4 * p4;
+                const uint32_t r0 = ks * 32 + 8 * g + q4, r1 = r0 + 4;
+                const uint32_t c0 = (col >> 3) ^ (((r0 >> 3) & 1) << 1), c1 = (col >> 3) ^ (((r1 >> 3) & 1) << 1);
+                kf[ct] = relu8(cat4(lds_read_tr4(kt, r0 * 64 + c0 * 16 + (p4 & 1) * 8), lds_read_tr4(kt, r1 * 64 + c1 * 16 + (p4 & 1) * 8)));
+                vf[ct] = cat4(lds_read_tr4(vt, r0 * 64 + c0 * 16 + (p4 & 1) * 8), lds_read_tr4(vt, r1 * 64 + c1 * 16 + (p4 & 1) * 8));
+            }
+            // tokens past N were zero-filled in K, so the ones row needs no mask
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {                   // D[c][c'] += sum_n relu(k)[n][c] * v'[n][c']
+                acc[ct][0] = mfma16(kf[ct], vf[0], acc[ct][0]);
+                acc[ct][1] = mfma16(kf[ct], vf[1], acc[ct][1]);
+                acc[ct][2] = mfma16(kf[ct], ones, acc[ct][2]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads retired before the next DMA overwrites the tiles
+    }
+    // cross-wave reduction through LDS, fixed order
+    float* red = reinterpret_cast<float*>(lds + 4 * 8192);     // [4 waves][6 tiles][64 lanes][4]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(red + ((wave * 6 + ct * 3 + j) * 64 + lane) * 4) = acc[ct][j];
     __syncthreads();
-    float ds[5] = {0, 0, 0, 0, 0};
-    accum_state(a_s, b_s, TB, t & 31, t >> 5, ds);
-    store_state(dS_part + (((int64_t)b * H + h) * gridDim.x + blockIdx.x) * SS, t & 31, t >> 5, ds);
+    if (wave == 0) {
+        float* S = S_out + ((int64_t)b * gridDim.x + h) * SS;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(red + ((w * 6 + ct * 3 + j) * 64 + lane) * 4);
+                    s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+                }
+                const int cp = j * 16 + (lane & 15);           // D[row = c = ct*16 + 4g + r][col = c']
+                if (cp < 33) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[cp * C + ct * 16 + 4 * g + r] = s[r];
+                }
+            }
+    }
+}
+
+// U^T tiles for 16 tokens: ut[t][r] = U[n = lane&15][c' = 16t + 4(lane>>4) + r]; 6 MFMAs
+__device__ __forceinline__ void u_tiles(const bf16x8 (&shi)[3], const bf16x8 (&slo)[3], bf16x8 qf, f32x4 (&ut)[3]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        ut[t] = mfma16(shi[t], qf, f32x4{0.f, 0.f, 0.f, 0.f});
+        ut[t] = mfma16(slo[t], qf, ut[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward apply
+// grid (ceil(N/256), H, B); wave = 64 tokens = 4 groups of 16
+__global__ __launch_bounds__(256) void la_fwd_kernel(int N, int H, const bf16_t* qkv, int ld, const float* S_all,
+                                                     bf16_t* out, int ld_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const float* S = S_all + ((int64_t)b * H + h) * SS;
+    bf16x8 shi[3], slo[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) state_frag_rows(S, t * 16, 33, lane, shi[t], slo[t]);
+    const bf16_t* qb = qkv + (int64_t)b * N * ld + h * C;
+    bf16_t* ob = out + (int64_t)b * N * ld_out + h * C;
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int n0 = blockIdx.x * TB + wave * 64 + grp * 16;
+        if (n0 >= N) break;
+        const int n = n0 + li;
+        f32x4 ut[3];
+        u_tiles(shi, slo, relu8(tok_frag(qb, ld, n, N, lane)), ut);
+        const float den = __shfl(ut[2][0], li, 64) + 1e-15f;     // U[32] sits on lanes 0..15 (g = 0, r = 0)
+        const float inv = 1.0f / den;
+        if (n < N) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                *reinterpret_cast<u32x2*>(ob + (int64_t)n * ld_out + t * 16 + 4 * g) =
+                    pack4(ut[t][0] * inv, ut[t][1] * inv, ut[t][2] * inv, ut[t][3] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward apply (q side)
+// grid (nchunks, H, B).  Per wave: 64 tokens.  dS partial slab per workgroup.
+__global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_t* qkv, int ld, const bf16_t* dout, int ld_do,
+                                                       const float* S_all, bf16_t* dqkv, int ld_dq, float* dS_part) {
+    // wave-private: dU image [32 tokens][64 c'] bf16 (128-B rows) + q image [32 tokens][32 c] bf16 (64-B rows)
+    __shared__ __attribute__((aligned(16))) char lds[4 * (4096 + 2048) + 4 * 6 * 64 * 16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = lane & 3;
+    const float* S = S_all + ((int64_t)b * H + h) * SS;
+    char* du_img = lds + wave * 6144;
+    char* q_img = du_img + 4096;
+    bf16x8 shi[3], slo[3], xhi[2], xlo[2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) state_frag_rows(S, t * 16, 33, lane, shi[t], slo[t]);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) state_frag_cols<true>(S, ct * 16, lane, xhi[ct], xlo[ct]);
+    float s32[2][4];                                             // S[32][c] for the lane's output channels
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s32[ct][r] = S[32 * C + ct * 16 + 4 * g + r];
+    const bf16_t* qb = qkv + (int64_t)b * N * ld + h * C;
+    const bf16_t* dob = dout + (int64_t)b * N * ld_do + h * C;
+    bf16_t* dqb = dqkv + (int64_t)b * N * ld_dq + h * C;
+
+    f32x4 ds[3][2];                                              // dS tiles D[c' = 16t + 4g + r][c = 16ct + li]
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) ds[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                       // 32 tokens per dS k-step
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int n0 = blockIdx.x * TB + wave * 64 + half * 32 + sub * 16;
+            const int n = n0 + li;
+            const bf16x8 qf = relu8(tok_frag(qb, ld, n, N, lane));
+            f32x4 ut[3];
+            u_tiles(shi, slo, qf, ut);
+            const float den = __shfl(ut[2][0], li, 64) + 1e-15f;
+            const float inv = 1.0f / den;
+            float dot = 0.f;
+            f32x4 du[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float d4[4];
+                tok4(dob, ld_do, n, N, t * 16 + 4 * g, d4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dot += d4[r] * (ut[t][r] * inv);             // dO . O
+                    du[t][r] = d4[r] * inv;
+                }
+            }
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            const float du32 = -dot * inv;                       // dU[n][32], known to every lane of token n
+            // dq^T[c][n] = sum_{c' < 32} S[c'][c] dU[n][c']  (accumulator as B operand, hi/lo on both sides) + S[32][c] dU[n][32]
+            bf16x8 dhi, dlo;
+            acc2frag_hilo(du[0], du[1], dhi, dlo);
+            const bool valid = n < N;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x4 dq = mfma16(xhi[ct], dhi, f32x4{0.f, 0.f, 0.f, 0.f});
+                dq = mfma16(xhi[ct], dlo, dq);
+                dq = mfma16(xlo[ct], dhi, dq);
+                float q4v[4];
+                tok4(qb, ld, n, N, ct * 16 + 4 * g, q4v);
+                if (valid) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = q4v[r] > 0.f ? dq[r] + s32[ct][r] * du32 : 0.f;
+                    *reinterpret_cast<u32x2*>(dqb + (int64_t)n * ld_dq + ct * 16 + 4 * g) = pack4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            // stash bf16 dU (64 c' per token; c' = 32 holds dU32, the rest of 33..63 zero) and relu(q) for the dS product
+            const int trow = sub * 16 + li;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                *reinterpret_cast<u32x2*>(du_img + trow * 128 + (t * 16 + 4 * g) * 2) =
+                    valid ? pack4(du[t][0], du[t][1], du[t][2], du[t][3]) : u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(du_img + trow * 128 + (32 + 4 * g) * 2) =
+                (valid && g == 0) ? pack4(du32, 0.f, 0.f, 0.f) : u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(du_img + trow * 128 + (48 + 4 * g) * 2) = u32x2{0u, 0u};
+            *reinterpret_cast<bf16x8*>(q_img + trow * 64 + g * 16) = qf;       // lane holds channels 8g..8g+7 of token li
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private images written
+        // dS[c'][c] += sum_n dU[n][c'] relu(q)[n][c]: tokens on k via transposed reads (natural k order both sides)
+        bf16x8 af[3], bfr[2];
+        const uint32_t r0 = 8 * g + q4, r1 = r0 + 4;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint32_t off = (t * 16 + 4 * p4) * 2;
+            af[t] = cat4(lds_read_tr4(du_img, r0 * 128 + off), lds_read_tr4(du_img, r1 * 128 + off));
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const uint32_t off = (ct * 16 + 4 * p4) * 2;
+            bfr[ct] = cat4(lds_read_tr4(q_img, r0 * 64 + off), lds_read_tr4(q_img, r1 * 64 + off));
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) ds[t][ct] = mfma16(af[t], bfr[ct], ds[t][ct]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // workgroup partial: sum the 4 waves in LDS (fixed order), write slab [33][32]
+    float* red = reinterpret_cast<float*>(lds + 4 * 6144);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 6 + t * 2 + ct) * 64 + lane) * 4) = ds[t][ct];
+    __syncthreads();
+    if (wave == 0) {
+        float* slab = dS_part + (((int64_t)b * H + h) * gridDim.x + blockIdx.x) * SS;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((w * 6 + t * 2 + ct) * 64 + lane) * 4);
+                    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cp = t * 16 + 4 * g + r;
+                    if (cp < 33) slab[cp * C + ct * 16 + li] = s[r];
+                }
+            }
+    }
 }
 
 // dS[bh] = sum_chunks dS_part[bh][chunk]
@@ -195,27 +371,53 @@ __global__ void la_reduce_slabs_kernel(int nbh, int nchunks, const float* part, 
     dS[i] = s;
 }
 
-// backward apply 2: dv = dS[:32] relu(k), dk = dS^T [v;1] masked by k > 0
-__global__ __launch_bounds__(256) void la_apply_bwd_kv_kernel(int N, int H, const bf16_t* __restrict__ qkv, int ld,
-                                                              int k_off, int v_off, const float* __restrict__ dS_all,
-                                                              const float* __restrict__ dS_all_again,
-                                                              bf16_t* __restrict__ dqkv, int ld_dq) {
+// ------------------------------------------------------------------------------------------ backward apply (k, v side)
+__global__ __launch_bounds__(256) void la_bwd_kv_kernel(int N, int H, const bf16_t* qkv, int ld, int k_off, int v_off,
+                                                        const float* dS_all, bf16_t* dqkv, int ld_dq) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int n = blockIdx.x * TB + threadIdx.x;
-    const float* __restrict__ dS = dS_all + ((int64_t)b * H + h) * SS;
-    if (n >= N) return;
-    float k[C], kr[C], v[33], dv[C], dk[C];
-    load32(qkv + ((int64_t)b * N + n) * ld + h * C + k_off, k);
-    load32(qkv + ((int64_t)b * N + n) * ld + h * C + v_off, v);
-    v[32] = 1.0f;
+    const int g = lane >> 4, li = lane & 15;
+    const float* dS = dS_all + ((int64_t)b * H + h) * SS;
+    bf16x8 rhi[2], rlo[2], chi[2], clo[2];
 #pragma unroll
-    for (int e = 0; e < C; ++e) kr[e] = fmaxf(k[e], 0.f);
-    state_times_vec<32>(dS, kr, dv);
-    vec_times_state<33>(dS_all_again + ((int64_t)b * H + h) * SS, v, dk);
+    for (int t = 0; t < 2; ++t) state_frag_rows(dS, t * 16, 32, lane, rhi[t], rlo[t]);       // dv: rows c' < 32, k = c
 #pragma unroll
-    for (int e = 0; e < C; ++e) dk[e] = k[e] > 0.f ? dk[e] : 0.f;
-    store32(dqkv + ((int64_t)b * N + n) * ld_dq + h * C + v_off, dv);
-    store32(dqkv + ((int64_t)b * N + n) * ld_dq + h * C + k_off, dk);
+    for (int ct = 0; ct < 2; ++ct) state_frag_cols<false>(dS, ct * 16, lane, chi[ct], clo[ct]);   // dk: cols c, k = c' < 32
+    float s32[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s32[ct][r] = dS[32 * C + ct * 16 + 4 * g + r];
+    const bf16_t* kb = qkv + (int64_t)b * N * ld + h * C + k_off;
+    const bf16_t* vb = qkv + (int64_t)b * N * ld + h * C + v_off;
+    bf16_t* dkb = dqkv + (int64_t)b * N * ld_dq + h * C + k_off;
+    bf16_t* dvb = dqkv + (int64_t)b * N * ld_dq + h * C + v_off;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int n0 = blockIdx.x * TB + wave * 64 + grp * 16;
+        if (n0 >= N) break;
+        const int n = n0 + li;
+        const bf16x8 kf = relu8(tok_frag(kb, ld, n, N, lane));
+        const bf16x8 vf = tok_frag(vb, ld, n, N, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // dv^T[c'][n] = sum_c dS[c'][c] relu(k)[n][c]
+            f32x4 dv = mfma16(rhi[t], kf, f32x4{0.f, 0.f, 0.f, 0.f});
+            dv = mfma16(rlo[t], kf, dv);
+            // dk^T[c][n] = sum_{c' < 32} dS[c'][c] v[n][c'] + dS[32][c]
+            f32x4 dk = mfma16(chi[t], vf, f32x4{0.f, 0.f, 0.f, 0.f});
+            dk = mfma16(clo[t], vf, dk);
+            float k4[4];
+            tok4(kb, ld, n, N, t * 16 + 4 * g, k4);
+            if (n < N) {
+                *reinterpret_cast<u32x2*>(dvb + (int64_t)n * ld_dq + t * 16 + 4 * g) = pack4(dv[0], dv[1], dv[2], dv[3]);
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = k4[r] > 0.f ? dk[r] + s32[t][r] : 0.f;
+                *reinterpret_cast<u32x2*>(dkb + (int64_t)n * ld_dq + t * 16 + 4 * g) = pack4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -227,15 +429,20 @@ uint64_t yat_linear_attn_workspace_bytes(int B, int N, int H) {
     return (uint64_t)B * H * SS * sizeof(float) * (2 + nchunks);
 }
 
+static int la_check(int B, int N, int H, int ld, int k_off, int v_off) {
+    if (B <= 0 || N <= 0 || H <= 0 || (ld & 7) || (k_off & 7) || (v_off & 7)) return YAT_EINVAL;
+    if ((uint64_t)B * N * ld * 2 > 0x7fffffffull) return YAT_EINVAL;
+    return YAT_OK;
+}
+
 int yat_linear_attn_fwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, void* out, int ld_out,
                         void* workspace, yat_stream_t stream) {
-    if (B <= 0 || N <= 0 || H <= 0 || (ld & 7) || (k_off & 7) || (v_off & 7) || (ld_out & 7) || !qkv || !out || !workspace)
-        return YAT_EINVAL;
+    if (la_check(B, N, H, ld, k_off, v_off) || (ld_out & 7) || !qkv || !out || !workspace) return YAT_EINVAL;
     float* S = (float*)workspace;
-    hipLaunchKernelGGL(la_state_kv_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, N, (const bf16_t*)qkv, ld, k_off,
-                       v_off, S);
+    hipLaunchKernelGGL(la_state_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, N, (const bf16_t*)qkv, ld, k_off, v_off,
+                       (uint64_t)B * N * ld * 2, S);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(la_apply_fwd_kernel, dim3((N + TB - 1) / TB, H, B), dim3(256), 0, (hipStream_t)stream, N, H,
+    hipLaunchKernelGGL(la_fwd_kernel, dim3((N + TB - 1) / TB, H, B), dim3(256), 0, (hipStream_t)stream, N, H,
                        (const bf16_t*)qkv, ld, (const float*)S, (bf16_t*)out, ld_out);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
@@ -243,8 +450,7 @@ int yat_linear_attn_fwd(int B, int N, int H, const void* qkv, int ld, int k_off,
 
 int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off, int v_off, const void* dout, int ld_dout,
                         void* dqkv, int ld_dqkv, const float* state, void* workspace, yat_stream_t stream) {
-    if (B <= 0 || N <= 0 || H <= 0 || (ld & 7) || (k_off & 7) || (v_off & 7) || (ld_dout & 7) || (ld_dqkv & 7) || !qkv ||
-        !dout || !dqkv || !workspace)
+    if (la_check(B, N, H, ld, k_off, v_off) || (ld_dout & 7) || (ld_dqkv & 7) || !qkv || !dout || !dqkv || !workspace)
         return YAT_EINVAL;
     const int nchunks = (N + TB - 1) / TB;
     float* S = (float*)workspace;
@@ -254,26 +460,19 @@ int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off,
     if (state) {
         S = const_cast<float*>(state);          // the forward's state (first B*H*33*32 floats of its workspace), kept by the caller
     } else {
-        hipLaunchKernelGGL(la_state_kv_kernel, dim3(H, B), dim3(256), 0, st, N, (const bf16_t*)qkv, ld, k_off, v_off, S);
+        hipLaunchKernelGGL(la_state_kernel, dim3(H, B), dim3(256), 0, st, N, (const bf16_t*)qkv, ld, k_off, v_off,
+                           (uint64_t)B * N * ld * 2, S);
         YAT_CHECK_LAUNCH();
     }
-    constexpr int BQ_LDS = TB * (36 + C) * (int)sizeof(float);
-    static bool attr_set = false;   // idempotent one-time launch attribute (LDS > 64 KiB)
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)la_apply_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS) !=
-            hipSuccess)
-            return YAT_EINVAL;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(la_apply_bwd_q_kernel, dim3(nchunks, H, B), dim3(256), BQ_LDS, st, N, H, (const bf16_t*)qkv, ld,
-                       (const bf16_t*)dout, ld_dout, (const float*)S, (const float*)S, (bf16_t*)dqkv, ld_dqkv, part);
+    hipLaunchKernelGGL(la_bwd_q_kernel, dim3(nchunks, H, B), dim3(256), 0, st, N, H, (const bf16_t*)qkv, ld,
+                       (const bf16_t*)dout, ld_dout, (const float*)S, (bf16_t*)dqkv, ld_dqkv, part);
     YAT_CHECK_LAUNCH();
     const int64_t tot = (int64_t)B * H * SS;
     hipLaunchKernelGGL(la_reduce_slabs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B * H, nchunks,
                        (const float*)part, dS);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(la_apply_bwd_kv_kernel, dim3(nchunks, H, B), dim3(256), 0, st, N, H, (const bf16_t*)qkv, ld, k_off,
-                       v_off, (const float*)dS, (const float*)dS, (bf16_t*)dqkv, ld_dqkv);
+    hipLaunchKernelGGL(la_bwd_kv_kernel, dim3(nchunks, H, B), dim3(256), 0, st, N, H, (const bf16_t*)qkv, ld, k_off, v_off,
+                       (const float*)dS, (bf16_t*)dqkv, ld_dqkv);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

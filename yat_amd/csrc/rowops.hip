@@ -76,83 +76,100 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(int M, int D, int rpb, 
 }
 
 // ------------------------------------------------------------------ LN + modulate backward
-// grid = (ceil(rpb / 16), B); wave w of block handles rows chunk*16 + w*4 .. +4 of batch b.
-// partial rows: ws[((b*nchunks + chunk)*4 + wave)][2][D]
+// Two light kernels instead of one register-heavy one (the fused version held x, dy, (1+scale) and both column
+// accumulators per lane: ~230 VGPRs, 1-2 waves/SIMD, 2 TB/s):
+//  (a) row pass, one wave per row, two streaming sweeps (the second one hits L1/L2): dx = dres + LN'(dy * (1+scale));
+//  (b) column pass (strip layout: a lane owns 8 columns and walks 32 rows, row statistics are wave-uniform scalars):
+//      dshift += sum_n dy, dscale += sum_n dy * bf16(xhat).  x and dy come back from L2 / Infinity Cache.
 template <int MAXV>
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(int D, int rpb, const bf16_t* x, const float* mean_in,
-                                                         const float* rstd_in, const bf16_t* scale, int mod_ld,
-                                                         const bf16_t* dy, const bf16_t* dres, bf16_t* dx,
-                                                         float* ws) {
+__global__ __launch_bounds__(256) void ln_mod_bwd_rows_kernel(int M, int D, int rpb, const bf16_t* x, const float* mean_in,
+                                                              const float* rstd_in, const bf16_t* scale, int mod_ld,
+                                                              const bf16_t* dy, const bf16_t* dres, bf16_t* dx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, chunkid = blockIdx.x, nchunk = D >> 3;
-    float gsc[MAXV][8], ash[MAXV][8], asc[MAXV][8];
-    {
-        const bf16_t* sc = scale + (int64_t)b * mod_ld;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            float g[8];
-            if (c < nchunk) unpack8(*reinterpret_cast<const u32x4*>(sc + c * 8), g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                gsc[i][e] = (c < nchunk) ? rbf(1.0f + g[e]) : 0.f;
-                ash[i][e] = 0.f; asc[i][e] = 0.f;
-            }
-        }
-    }
-    const int r_begin = chunkid * (WAVES * ROWS_PER_WAVE) + wave * ROWS_PER_WAVE;
-    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-        const int rl = r_begin + rr;
-        if (rl >= rpb) break;
-        const int64_t row = (int64_t)b * rpb + rl;
-        float v[MAXV][8], g[MAXV][8];
-        load_row<MAXV>(x + row * D, nchunk, lane, v);
-        load_row<MAXV>(dy + row * D, nchunk, lane, g);
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xh = (v[i][e] - mean) * rstd;
-                const float xhb = rbf(xh);
-                ash[i][e] += g[i][e];
-                asc[i][e] += g[i][e] * xhb;
-                const float gg = rbf(g[i][e] * gsc[i][e]);          // grad wrt LN output
-                v[i][e] = xh; g[i][e] = gg;
-                s1 += gg; s2 += gg * xh;
-            }
-        s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk) {
-                float o[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - s1 - v[i][e] * s2);
-                if (dres) {
-                    float r[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(dres + row * D + c * 8), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) + r[e];
-                }
-                *reinterpret_cast<u32x4*>(dx + row * D + c * 8) = pack8(o);
-            }
-        }
-    }
-    float* wp = ws + ((int64_t)(b * gridDim.x + chunkid) * WAVES + wave) * 2 * D;
+    const int row = blockIdx.x * WAVES + wave;
+    if (row >= M) return;
+    const int nchunk = D >> 3;
+    const bf16_t* sc = scale + (int64_t)(row / rpb) * mod_ld;
+    const bf16_t* xr = x + (int64_t)row * D;
+    const bf16_t* gr = dy + (int64_t)row * D;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    // pass 1: the two row reductions (streamed, nothing kept)
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
+            float xv[8], gv[8], sv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(xr + c * 8), xv);
+            unpack8(*reinterpret_cast<const u32x4*>(gr + c * 8), gv);
+            unpack8(*reinterpret_cast<const u32x4*>(sc + c * 8), sv);
 #pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                *reinterpret_cast<f32x4*>(wp + c * 8 + e) = f32x4{ash[i][e], ash[i][e + 1], ash[i][e + 2], ash[i][e + 3]};
-                *reinterpret_cast<f32x4*>(wp + D + c * 8 + e) = f32x4{asc[i][e], asc[i][e + 1], asc[i][e + 2], asc[i][e + 3]};
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[e] - mean) * rstd;
+                const float gg = rbf(gv[e] * rbf(1.0f + sv[e]));       // grad wrt the LN output (bf16 mul in autograd)
+                s1 += gg;
+                s2 += gg * xh;
             }
         }
     }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    // pass 2: re-read the row (L1/L2 hit) rather than holding 80 floats across the reduction -- this kernel lives on
+    // occupancy.  The empty asm keeps the compiler from merging the two passes' loads.
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float xv[8], gv[8], sv[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(xr + c * 8), xv);
+            unpack8(*reinterpret_cast<const u32x4*>(gr + c * 8), gv);
+            unpack8(*reinterpret_cast<const u32x4*>(sc + c * 8), sv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[e] - mean) * rstd;
+                const float gg = rbf(gv[e] * rbf(1.0f + sv[e]));
+                o[e] = rstd * (gg - s1 - xh * s2);
+            }
+            if (dres) {
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4*>(dres + (int64_t)row * D + c * 8), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) + r[e];
+            }
+            *reinterpret_cast<u32x4*>(dx + (int64_t)row * D + c * 8) = pack8(o);
+        }
+    }
+}
+
+// grid = (ceil(D/512), ceil(rpb/128), B); partial rows ws[(b*ngroups + rg)][2][D]
+__global__ __launch_bounds__(256) void ln_mod_bwd_cols_kernel(int rpb, int D, const bf16_t* x, const float* mean_in,
+                                                              const float* rstd_in, const bf16_t* dy, float* ws) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    const int b = blockIdx.z;
+    const int rg = blockIdx.y * WAVES + wave, ngroups = gridDim.y * WAVES;
+    if (c0 >= D) return;
+    float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int rr = 0; rr < 32; ++rr) {
+        const int rl = rg * 32 + rr;
+        if (rl >= rpb) break;
+        const int64_t row = (int64_t)b * rpb + rl;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xv[8], gv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + row * D + c0), xv);
+        unpack8(*reinterpret_cast<const u32x4*>(dy + row * D + c0), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a1[e] += gv[e];
+            a2[e] += gv[e] * rbf((xv[e] - mean) * rstd);
+        }
+    }
+    float* wp = ws + ((int64_t)b * ngroups + rg) * 2 * D + c0;
+    *reinterpret_cast<f32x4*>(wp) = f32x4{a1[0], a1[1], a1[2], a1[3]};
+    *reinterpret_cast<f32x4*>(wp + 4) = f32x4{a1[4], a1[5], a1[6], a1[7]};
+    *reinterpret_cast<f32x4*>(wp + D) = f32x4{a2[0], a2[1], a2[2], a2[3]};
+    *reinterpret_cast<f32x4*>(wp + D + 4) = f32x4{a2[4], a2[5], a2[6], a2[7]};
 }
 
 // Partial-row reductions: a 256-thread block owns 64 columns; 4 thread rows split the G partial rows and meet in LDS
@@ -382,8 +399,8 @@ int yat_ln_modulate_fwd(int M, int D, int rpb, float eps, const void* x, const v
 
 uint64_t yat_ln_bwd_workspace_bytes(int M, int D, int rpb) {
     if (M <= 0 || rpb <= 0) return 0;
-    const uint64_t nchunks = (rpb + WAVES * ROWS_PER_WAVE - 1) / (WAVES * ROWS_PER_WAVE);
-    return (uint64_t)(M / rpb) * nchunks * WAVES * 2 * D * sizeof(float);
+    const uint64_t gy = (rpb + WAVES * 32 - 1) / (WAVES * 32);
+    return (uint64_t)(M / rpb) * gy * WAVES * 2 * D * sizeof(float);
 }
 
 int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean, const float* rstd, const void* scale,
@@ -391,17 +408,21 @@ int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean,
                         int acc_ld, void* workspace, yat_stream_t stream) {
     if (M <= 0 || rpb <= 0 || M % rpb || (mod_ld & 7) || !x || !dy || !dx || !workspace || !dshift_acc || !dscale_acc)
         return YAT_EINVAL;
-    const int B = M / rpb, nchunks = (rpb + WAVES * ROWS_PER_WAVE - 1) / (WAVES * ROWS_PER_WAVE);
+    const int B = M / rpb;
     int rc = dispatch_maxv(D, [&](auto mv) {
         constexpr int MV = decltype(mv)::value;
-        hipLaunchKernelGGL((ln_mod_bwd_kernel<MV>), dim3(nchunks, B), dim3(256), 0, (hipStream_t)stream, D, rpb,
-                           (const bf16_t*)x, mean, rstd, (const bf16_t*)scale, mod_ld, (const bf16_t*)dy,
-                           (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace);
+        hipLaunchKernelGGL((ln_mod_bwd_rows_kernel<MV>), dim3((M + WAVES - 1) / WAVES), dim3(256), 0, (hipStream_t)stream, M,
+                           D, rpb, (const bf16_t*)x, mean, rstd, (const bf16_t*)scale, mod_ld, (const bf16_t*)dy,
+                           (const bf16_t*)dres, (bf16_t*)dx);
         YAT_CHECK_LAUNCH();
         return YAT_OK;
     });
     if (rc) return rc;
-    const int W = 2 * D, G = nchunks * WAVES;
+    const int gy = (rpb + WAVES * 32 - 1) / (WAVES * 32);
+    hipLaunchKernelGGL(ln_mod_bwd_cols_kernel, dim3((D + 511) / 512, gy, B), dim3(256), 0, (hipStream_t)stream, rpb, D,
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)dy, (float*)workspace);
+    YAT_CHECK_LAUNCH();
+    const int W = 2 * D, G = gy * WAVES;
     hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((W + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, B, G, W,
                        (const float*)workspace, dshift_acc, dscale_acc, D, acc_ld);
     YAT_CHECK_LAUNCH();
