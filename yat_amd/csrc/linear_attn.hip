@@ -230,14 +230,15 @@ __global__ __launch_bounds__(256) void la_fwd_kernel(int N, int H, const bf16_t*
 // grid (nchunks, H, B).  Per wave: 64 tokens.  dS partial slab per workgroup.
 __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_t* qkv, int ld, const bf16_t* dout, int ld_do,
                                                        const float* S_all, bf16_t* dqkv, int ld_dq, float* dS_part) {
-    // wave-private: dU image [32 tokens][64 c'] bf16 (128-B rows) + q image [32 tokens][32 c] bf16 (64-B rows)
-    __shared__ __attribute__((aligned(16))) char lds[4 * (4096 + 2048) + 4 * 6 * 64 * 16];
+    // wave-private: dU hi and lo images [32 tokens][64 c'] bf16 (128-B rows) + q image [32 tokens][32 c] bf16 (64-B rows)
+    __shared__ __attribute__((aligned(16))) char lds[4 * (2 * 4096 + 2048) + 4 * 6 * 64 * 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.y, b = blockIdx.z;
     const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = lane & 3;
     const float* S = S_all + ((int64_t)b * H + h) * SS;
-    char* du_img = lds + wave * 6144;
-    char* q_img = du_img + 4096;
+    char* du_img = lds + wave * 10240;
+    char* du_lo = du_img + 4096;
+    char* q_img = du_img + 8192;
     bf16x8 shi[3], slo[3], xhi[2], xlo[2];
 #pragma unroll
     for (int t = 0; t < 3; ++t) state_frag_rows(S, t * 16, 33, lane, shi[t], slo[t]);
@@ -305,22 +306,31 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
             // stash bf16 dU (64 c' per token; c' = 32 holds dU32, the rest of 33..63 zero) and relu(q) for the dS product
             const int trow = sub * 16 + li;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                *reinterpret_cast<u32x2*>(du_img + trow * 128 + (t * 16 + 4 * g) * 2) =
-                    valid ? pack4(du[t][0], du[t][1], du[t][2], du[t][3]) : u32x2{0u, 0u};
-            *reinterpret_cast<u32x2*>(du_img + trow * 128 + (32 + 4 * g) * 2) =
-                (valid && g == 0) ? pack4(du32, 0.f, 0.f, 0.f) : u32x2{0u, 0u};
+            for (int t = 0; t < 2; ++t) {
+                float hi4[4], lo4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hi4[r] = valid ? rbf(du[t][r]) : 0.f; lo4[r] = valid ? du[t][r] - hi4[r] : 0.f; }
+                *reinterpret_cast<u32x2*>(du_img + trow * 128 + (t * 16 + 4 * g) * 2) = pack4(hi4[0], hi4[1], hi4[2], hi4[3]);
+                *reinterpret_cast<u32x2*>(du_lo + trow * 128 + (t * 16 + 4 * g) * 2) = pack4(lo4[0], lo4[1], lo4[2], lo4[3]);
+            }
+            {
+                const float h32 = (valid && g == 0) ? rbf(du32) : 0.f, l32 = (valid && g == 0) ? du32 - h32 : 0.f;
+                *reinterpret_cast<u32x2*>(du_img + trow * 128 + (32 + 4 * g) * 2) = pack4(h32, 0.f, 0.f, 0.f);
+                *reinterpret_cast<u32x2*>(du_lo + trow * 128 + (32 + 4 * g) * 2) = pack4(l32, 0.f, 0.f, 0.f);
+            }
             *reinterpret_cast<u32x2*>(du_img + trow * 128 + (48 + 4 * g) * 2) = u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(du_lo + trow * 128 + (48 + 4 * g) * 2) = u32x2{0u, 0u};
             *reinterpret_cast<bf16x8*>(q_img + trow * 64 + g * 16) = qf;       // lane holds channels 8g..8g+7 of token li
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private images written
         // dS[c'][c] += sum_n dU[n][c'] relu(q)[n][c]: tokens on k via transposed reads (natural k order both sides)
-        bf16x8 af[3], bfr[2];
+        bf16x8 af[3], al[3], bfr[2];
         const uint32_t r0 = 8 * g + q4, r1 = r0 + 4;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const uint32_t off = (t * 16 + 4 * p4) * 2;
             af[t] = cat4(lds_read_tr4(du_img, r0 * 128 + off), lds_read_tr4(du_img, r1 * 128 + off));
+            al[t] = cat4(lds_read_tr4(du_lo, r0 * 128 + off), lds_read_tr4(du_lo, r1 * 128 + off));
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -330,11 +340,14 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) ds[t][ct] = mfma16(af[t], bfr[ct], ds[t][ct]);
+            for (int ct = 0; ct < 2; ++ct) {
+                ds[t][ct] = mfma16(af[t], bfr[ct], ds[t][ct]);
+                ds[t][ct] = mfma16(al[t], bfr[ct], ds[t][ct]);
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // workgroup partial: sum the 4 waves in LDS (fixed order), write slab [33][32]
-    float* red = reinterpret_cast<float*>(lds + 4 * 6144);
+    float* red = reinterpret_cast<float*>(lds + 4 * 10240);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
