@@ -176,7 +176,8 @@ def main():
         for L in lens:
             offs.append(offs[-1] + L)
         src = torch.randn(offs[-1], Cc, generator=g, device=dev).to(torch.bfloat16)
-        batches.append(dict(h=h, w=w, lat=lat, src=src, offsets=torch.tensor(offs, dtype=torch.int32, device=dev)))
+        batches.append(dict(h=h, w=w, lat=lat, src=src, offsets=torch.tensor(offs, dtype=torch.int32, device=dev),
+                            work=ops.kv_work_list(lens, T, dev)))
     enc = torch.empty(B, T, Cc, dtype=torch.bfloat16, device=dev)
     mask = torch.empty(B, T, dtype=torch.int64, device=dev)
     bias = torch.empty(B, T, dtype=torch.float32, device=dev)
@@ -191,7 +192,7 @@ def main():
         noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)  # :183
         _, t_host, sig_host = recipe.scheduler.sample(B, ts_gen)                                    # :185-204
         t_dev, sig_dev = t_host.to(dev, non_blocking=True), sig_host.to(dev, non_blocking=True)
-        recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, sig_dev, loss_dev)      # :206-218 + backward
+        recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, sig_dev, loss_dev, kv_work=b["work"])  # :206-218 + bwd
         if ddp:
             ddp.wait()
         opt.step()                                                                                  # trainer.py:347-356

@@ -117,9 +117,13 @@ int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off,
  * ------------------------------------------------------------------------------------------ */
 int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream);
+/* work_list (optional, device int32 [n_work][2] = (batch, key tile) for every key tile with tile*64 < kv_len[batch], n_work
+ * known on the host from the embedding lengths): the dK/dV kernel then launches only those workgroups; NULL = dense
+ * grid over all T/64 tiles with early exit (correct, but idle LDS-heavy workgroups cost ~0.24 us each). */
 int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
-                 const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, yat_stream_t stream);
+                 const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,
+                 int n_work, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * GLUMBConv middle: SiLU -> depthwise 3x3 (pad 1, bias) -> chunk2 -> a * SiLU(g)

@@ -417,6 +417,11 @@ def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
     dkv = torch.full_like(kv, float("nan"))
     delta = torch.empty(B, H, N, dtype=torch.float32, device=DEV)
     ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:])
+    # the compact (batch, key tile) work list must give bit-identical gradients to the dense grid
+    dq2, dkv2 = torch.empty_like(q), torch.full_like(kv, float("nan"))
+    ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, dout, lse, delta, dq2, dkv2[:, :D], dkv2[:, D:],
+                 work=ops.kv_work_list(lens, T, DEV))
+    assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2)
     as_good_as(dq, fl[0], qr.grad, f"sdpa_dq T={T}", tol_flow=1e-2)
     as_good_as(dkv[:, :D], fl[1], kr.grad, f"sdpa_dk T={T}", tol_flow=1e-2)
     as_good_as(dkv[:, D:], fl[2], vr.grad, f"sdpa_dv T={T}", tol_flow=1e-2)

@@ -206,11 +206,18 @@ def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse):
     return out
 
 
-def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv):
+def kv_work_list(lens, T, device):
+    """Compact (batch, key tile) list for yat_sdpa_bwd from HOST-known key lengths (0 = all T keys attend)."""
+    pairs = [(b, t) for b, L in enumerate(lens) for t in range(((L if L > 0 else T) + 63) // 64)]
+    return torch.tensor(pairs, dtype=torch.int32).to(device, non_blocking=True)
+
+
+def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv, work=None):
     assert k2d.stride(0) == v2d.stride(0) and dk.stride(0) == dv.stride(0)
     rc = _lib().yat_sdpa_bwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                              _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
-                             _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0), _stream())
+                             _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0), _p(work),
+                             0 if work is None else work.shape[0], _stream())
     _l.check(rc, "yat_sdpa_bwd")
 
 

@@ -71,6 +71,7 @@ class SanaRecipe:
         bias = torch.empty(B, T, dtype=torch.float32, device=self.dev)
         kvl = torch.empty(B, dtype=torch.int32, device=self.dev)
         ops.pad_mask(src, offsets, B, T, C, enc, mask, bias, kvl)
+        self.kv_work = ops.kv_work_list(lens, T, self.dev)     # lengths are host data: compact dK/dV work list
         return enc, mask, bias, kvl
 
     def draw(self, shape, generator):
@@ -92,16 +93,17 @@ class SanaRecipe:
         latents = latents.to(device=self.dev, dtype=BF16).contiguous()
         noise, timesteps, sigmas = self.draw(latents.shape, generator)
         noisy, target = ops.flow_mix(latents, noise, sigmas)
+        self.model.next_kv_work = self.kv_work
         pred = self.model(noisy, encoder_hidden_states=enc, timestep=timesteps, encoder_attention_mask=mask).sample
         loss = _MseLoss.apply(pred, target, self._mse_ws)
         return (loss, pred, target) if return_pred else loss
 
-    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out):
+    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out, kv_work=None):
         """Graph-friendly straight-line step on device-resident inputs: forward, loss+dL/dpred, backward.
         Used by bench.py and the trainer fast path (no autograd objects, no allocation besides pred)."""
         bias, kvl = mask_bias_kvl
         noisy, target = ops.flow_mix(latents, noise, sigmas, self._noisy(latents), self._target(latents))
-        pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl)
+        pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
         dpred = self._dpred(pred)
         ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws)
         self.model.backward_impl(dpred)

@@ -125,7 +125,8 @@ class _WholeModel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, latents, enc, timestep, mask):
         ctx.model = model
-        return model.forward_impl(latents, enc, timestep, mask)
+        work, model.next_kv_work = getattr(model, "next_kv_work", None), None      # one-shot hint from the recipe
+        return model.forward_impl(latents, enc, timestep, mask, kv_work=work)
 
     @staticmethod
     def backward(ctx, dout):
@@ -258,7 +259,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
     # ------------------------------------------------------------------ forward
-    def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None):
+    def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None, kv_work=None):
         cfg, P = self.cfg, self.P
         D, Hc, H1, H2, dh2 = cfg.inner_dim, cfg.ffn_hidden, cfg.num_attention_heads, cfg.num_cross_attention_heads, \
             cfg.cross_attention_head_dim
@@ -281,7 +282,8 @@ class SanaTransformer2DModelHIP(nn.Module):
                 key_bias = ((1 - mdev.to(BF16)) * -10000.0).float().contiguous()
                 idx = torch.arange(1, T + 1, device=dev, dtype=torch.int32)
                 kv_len = (mdev.to(torch.int32) * idx).amax(dim=1).to(torch.int32).contiguous()
-        S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, key_bias=key_bias, kv_len=kv_len, enc2d=enc2d, blocks=[])
+        S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, key_bias=key_bias, kv_len=kv_len, kv_work=kv_work,
+                            enc2d=enc2d, blocks=[])
         buf = self._buf
 
         # 1. patch embed (1x1 conv == Linear over channels) on token-major rows
@@ -431,7 +433,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             dkv2 = buf("dkv2", (Mt, 2 * D))
             delta = buf("delta", (B, H2, N), f32)
             ops.sdpa_bwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse,
-                         delta, dq2, dkv2[:, :D], dkv2[:, D:])
+                         delta, dq2, dkv2[:, :D], dkv2[:, D:], work=S.kv_work)
             wgrad(dq2, A.x1, pre + "attn2.to_q.weight", (D, D))
             bgrad(dq2, pre + "attn2.to_q.bias")
             dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=dx2, residual=dx2)      # dx1 = dx2 + dq2 Wq
