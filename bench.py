@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--layers", type=int, default=20, help="debug only; anything but 20 is not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
+    ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the serialized GEMM-timing pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,7 +160,8 @@ def main():
     cfg = SanaConfig(num_layers=args.layers)
     log(f"rank {rank}/{world}: building SANA ({args.layers} blocks) on {dev}")
     model = SanaTransformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
-    opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
+    opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
+                    overlap_update=os.environ.get("YAT_OVERLAP_ADAMW", "1") != "0")
     ddp = HipDDP(model) if world > 1 else None
     if ddp:
         ddp.broadcast_parameters()
@@ -210,23 +213,46 @@ def main():
             torch.cuda.synchronize()
             log(f"first step done, loss={loss_dev.item():.4f}")
     barrier()
+    th = time.perf_counter()
+    step(args.warmup)                          # host cost of one step: enqueue from an idle GPU, before it can push back
+    host_ms = 1e3 * (time.perf_counter() - th)
+    barrier()
+    log(f"host enqueue of one step from idle: {host_ms:.1f} ms")
     log(f"timing {args.steps} steps")
-    timer = None if args.no_gemm_timer else []
-    ops.GEMM_TIMER = timer
     t0 = time.perf_counter()
     flops = 0.0
     for i in range(args.steps):
         ntok = step(args.warmup + i)
         flops += B * train_flops_per_image(cfg, ntok, T)
+    issue = time.perf_counter() - t0          # host time to enqueue all steps (the host runs ahead of the GPU)
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.GEMM_TIMER = None
+    log(f"host enqueue time {1e3 * issue / args.steps:.1f} ms/step")
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     loss_val = loss_dev.item()
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps, loss={loss_val:.4f}")
+
+    # ---- roofline pass (after the timed region): per-launch GEMM durations by HIP events on the launch stream.
+    # The step overlaps independent GEMMs on two streams, so in the timed region two kernels share the CUs and
+    # their individual durations overlap; the per-kernel figure is therefore taken with the streams serialized
+    # (YAT_SIDE_WGRAD=0 behaviour), same kernels, same shapes, same inputs.
+    timer = None
+    if not args.no_gemm_timer:          # every rank runs it (the DDP collectives need all of them); rank 0 reports
+        saved = (model.side_wgrad, opt.overlap_update)
+        model.side_wgrad, opt.overlap_update = False, False
+        step(0)
+        torch.cuda.synchronize()
+        timer = []
+        ops.GEMM_TIMER = timer
+        for i in range(args.roofline_steps):
+            step(1 + i)
+        torch.cuda.synchronize()
+        ops.GEMM_TIMER = None
+        model.side_wgrad, opt.overlap_update = saved
+        barrier()
 
     if rank == 0:
         img_s = world * B * args.steps / elapsed
@@ -250,8 +276,22 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN, all epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "mode": f"serialized-stream pass of {args.roofline_steps} steps after the timed region",
                                "launches": len(timer), "avg_launch_us": 1e3 * gms / len(timer),
-                               "gemm_share_of_step": gms / (1e3 * elapsed)}
+                               "gemm_ms_per_step_serialized": gms / args.roofline_steps}
+        if timer and args.gemm_detail:
+            agg = {}
+            for fl, e0, e1, key in timer:
+                a = agg.setdefault(key, [0, 0.0, fl])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+            with open(args.gemm_detail, "w") as f:
+                f.write("layout      M      N      K  act gate res aux  calls/step   avg_us    TFLOP/s   ms/step\n")
+                for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    lay, M_, N_, K_, act, gt, rs, ax = key
+                    f.write(f"{lay:4s} {M_:7d} {N_:6d} {K_:6d} {act:>5s} {int(gt):3d} {int(rs):3d} {int(ax):3d} "
+                            f"{n / args.roofline_steps:9.1f} {1e3 * ms / n:9.1f} {fl * n / (ms * 1e-3) / 1e12:9.1f} "
+                            f"{ms / args.roofline_steps:9.3f}\n")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()

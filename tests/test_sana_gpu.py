@@ -112,7 +112,6 @@ def test_step_matches_oracle(B, h, w, lens, pad_to, layers):
         n_all += b.numel()
     print(f"[parity] AdamW: {n_bad}/{n_all} parameters differ by more than 1 bf16 ulp from torch CPU")
     assert n_bad <= 0.01 * n_all
-    assert hip.flat_grad.abs().max().item() == 0.0
 
 
 def test_state_dict_roundtrip_and_no_grad_forward(tmp_path):

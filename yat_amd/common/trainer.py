@@ -192,7 +192,8 @@ class Model:
         if getattr(p, "lora_rank", None) is not None:
             raise NotImplementedError("PEFT adapters (lora/loha/lokr) are a later row of the scope table")
         self.optimizer = FlatAdamW(self.model, lr=p.learning_rate, weight_decay=p.weight_decay, max_grad_norm=1.0,
-                                   use_ema=bool(getattr(p, "use_ema", False)), ema_decay=0.999)
+                                   use_ema=bool(getattr(p, "use_ema", False)), ema_decay=0.999,
+                                   overlap_update=True)
         self.accelerator.prepare(self.model)
         self.lr_scheduler = None
         if getattr(p, "warmup_steps", None) is not None:
@@ -230,7 +231,7 @@ class Model:
                     self.accelerator.backward(loss)
                     if self.accelerator.sync_gradients:
                         self.accelerator.clip_grad_norm_(None, max_norm=1.0)  # fused below
-                        self.optimizer.step()                                 # clip + AdamW + EMA + zero_grad
+                        self.optimizer.step()                                 # clip + AdamW + EMA (fused)
                         if self.lr_scheduler is not None:
                             self.lr_scheduler.step()
                 if self.accelerator.sync_gradients:
@@ -255,6 +256,7 @@ class Model:
         """:371-401: EMA mean across ranks, then rank 0 swaps EMA weights in, validates, saves, swaps back."""
         with torch.no_grad():
             opt = self.optimizer
+            self.model.join_pending_update()               # the overlapped AdamW/EMA update must have landed
             if opt.ema_shadow is not None and self.accelerator.num_processes > 1:
                 dist.all_reduce(opt.ema_shadow)            # one flat all-reduce instead of ~600 per-tensor calls
                 opt.ema_shadow /= self.accelerator.num_processes

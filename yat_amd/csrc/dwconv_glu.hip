@@ -31,15 +31,29 @@ __device__ __forceinline__ u32x2 ld_or_zero(const bf16_t* p, bool ok) {
     return z;
 }
 
+// Work-unit order for a 1-D grid: workgroups are dealt round-robin to the 8 XCDs (each with a private L2), so unit
+// u = xcd * ceil(total/8) + slot gives every XCD one contiguous run of units.  With (segment, row) fastest inside a
+// (channel chunk, image) the three-row halo a unit re-reads was fetched by its neighbour on the SAME L2 moments before.
+__device__ __forceinline__ int xcd_unit(int total) {
+    const int per = (total + 7) >> 3;
+    return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
 // MODE 0: forward (writes y).  MODE 1: backward pass 1 (reads dy, writes du for both halves).
-// grid = (ceil(Hc/4 / 256), h * nseg, B)
+// grid = 8 * ceil(nx * h * nseg * B / 8), nx = ceil(Hc/4 / 256)
 template <int MODE>
-__global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, int nseg, const bf16_t* z /* = SiLU(conv_inverted) */,
+__global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, int nseg, int nx, int B,
+                                                         const bf16_t* z /* = SiLU(conv_inverted) */,
                                                          const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
                                                          bf16_t* out) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;   // 4-channel group of the `a` half
+    const int total = nx * h * nseg * B;
+    int u = xcd_unit(total);
+    if (u >= total) return;
+    const int seg = u % nseg; u /= nseg;
+    const int i = u % h; u /= h;
+    const int q = (u % nx) * 256 + threadIdx.x;            // 4-channel group of the `a` half
+    const int b = u / nx;
     if (q * 4 >= Hc) return;
-    const int i = blockIdx.y / nseg, seg = blockIdx.y % nseg, b = blockIdx.z;
     const int j0 = seg * SEG, j1 = min(w, j0 + SEG);
     const int C2 = 2 * Hc;
     const int ca = q * 4, cg = Hc + q * 4;
@@ -121,16 +135,21 @@ __global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, i
 //   dz[i,j] = SiLU'(z[i,j]) * bf16( sum_taps W[tap] du[i-di, j-dj] )
 //   dW[tap] += s(z[i,j]) * du[i-di, j-dj];   db += du[i,j]
 // partials: ws[((b*nrg + rg)*nsb + sb)][2Hc*10]  (10 = 9 taps + bias per channel)
-__global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, const bf16_t* sact, const bf16_t* z,
+__global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, int nx, int nrg, int B, const bf16_t* sact, const bf16_t* z,
                                                           const bf16_t* wdw, const bf16_t* du, bf16_t* dz, float* ws) {
     __shared__ float red[4][64][41];
     const int C2 = 2 * Hc;
     const int lg = threadIdx.x & 63, lseg = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + lg;
+    const int nsb = (w + 4 * SEG - 1) / (4 * SEG);           // segment-blocks per row
+    const int total = nx * nrg * nsb * B;
+    int u = xcd_unit(total);
+    if (u >= total) return;                                   // whole block leaves together (before any barrier)
+    const int sb = u % nsb; u /= nsb;
+    const int rg = u % nrg; u /= nrg;
+    const int bx = u % nx, b = u / nx;
+    const int q = bx * 64 + lg;
     const bool active = q * 4 < C2;
     const int c0 = active ? q * 4 : 0;
-    const int nsb = (w + 4 * SEG - 1) / (4 * SEG);           // segment-blocks per row
-    const int rg = blockIdx.y / nsb, sb = blockIdx.y % nsb, b = blockIdx.z;
     const int j0 = (sb * 4 + lseg) * SEG, j1 = min(w, j0 + SEG);
     float wt[9][4], dW[9][4], db[4];
 #pragma unroll
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, 
     }
     __syncthreads();
     if (lseg == 0 && active) {
-        float* wp = ws + (((int64_t)b * gridDim.y + blockIdx.y)) * C2 * 10 + (int64_t)c0 * 10;
+        float* wp = ws + (((int64_t)b * nrg * nsb + rg * nsb + sb)) * C2 * 10 + (int64_t)c0 * 10;
 #pragma unroll
         for (int k = 0; k < 40; ++k) wp[k] = red[0][lg][k] + red[1][lg][k] + red[2][lg][k] + red[3][lg][k];
     }
@@ -237,6 +256,7 @@ __global__ void dwconv_reduce_kernel(int P, int C2, const float* ws, bf16_t* dw,
 inline int nseg_of(int w) { return (w + SEG - 1) / SEG; }
 inline int nsb_of(int w) { return (w + 4 * SEG - 1) / (4 * SEG); }
 inline int nrg_of(int h) { return (h + ROWS - 1) / ROWS; }
+inline unsigned grid8(int64_t total) { return (unsigned)(((total + 7) / 8) * 8); }
 
 }  // namespace
 
@@ -246,10 +266,11 @@ int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* w
                        yat_stream_t stream) {
     const void* z = s;
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !z || !wdw || !bdw || !y) return YAT_EINVAL;
-    if ((int64_t)h * nseg_of(w) > 65535 || B > 65535) return YAT_EINVAL;
-    hipLaunchKernelGGL((dwconv_glu_kernel<0>), dim3((Hc / 4 + 255) / 256, h * nseg_of(w), B), dim3(256), 0,
-                       (hipStream_t)stream, h, w, Hc, nseg_of(w), (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)bdw,
-                       (const bf16_t*)nullptr, (bf16_t*)y);
+    if ((int64_t)h * nseg_of(w) * B * ((Hc / 4 + 63) / 64) * 2 > 0x7fffff00ll) return YAT_EINVAL;
+    const int nx = (Hc / 4 + 255) / 256;
+    hipLaunchKernelGGL((dwconv_glu_kernel<0>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
+                       (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)z, (const bf16_t*)wdw,
+                       (const bf16_t*)bdw, (const bf16_t*)nullptr, (bf16_t*)y);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
@@ -266,18 +287,20 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !s || !z || !wdw || !bdw || !dy || !dz || !dwdw || !dbdw ||
         !workspace)
         return YAT_EINVAL;
-    if ((int64_t)h * nseg_of(w) > 65535 || B > 65535) return YAT_EINVAL;
+    if ((int64_t)h * nseg_of(w) * B * ((Hc / 4 + 63) / 64) * 2 > 0x7fffff00ll) return YAT_EINVAL;
     const int C2 = 2 * Hc;
     const int gy2 = nrg_of(h) * nsb_of(w);
     bf16_t* du = (bf16_t*)workspace;
     const uint64_t du_bytes = ((uint64_t)B * h * w * C2 * 2 + 255) & ~255ull;
     float* ws = (float*)((char*)workspace + du_bytes);
-    hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3((Hc / 4 + 255) / 256, h * nseg_of(w), B), dim3(256), 0,
-                       (hipStream_t)stream, h, w, Hc, nseg_of(w), (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
-                       (const bf16_t*)dy, du);
+    const int nx = (Hc / 4 + 255) / 256, nx2 = (C2 / 4 + 63) / 64;
+    hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
+                       (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
+                       (const bf16_t*)bdw, (const bf16_t*)dy, du);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dwconv_bwd2_kernel, dim3((C2 / 4 + 63) / 64, gy2, B), dim3(256), 0, (hipStream_t)stream, h, w, Hc,
-                       (const bf16_t*)s, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)du, (bf16_t*)dz, ws);
+    hipLaunchKernelGGL(dwconv_bwd2_kernel, dim3(grid8((int64_t)nx2 * gy2 * B)), dim3(256), 0, (hipStream_t)stream, h, w,
+                       Hc, nx2, nrg_of(h), B, (const bf16_t*)s, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)du,
+                       (bf16_t*)dz, ws);
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * 10 + 63) / 64), dim3(256), 0, (hipStream_t)stream, B * gy2, C2,
                        (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, accumulate);

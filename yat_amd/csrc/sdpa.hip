@@ -90,6 +90,7 @@ struct SdpaP {
     // backward
     const bf16_t* dout; int lddo; float* delta; bf16_t* dq; int lddq; bf16_t* dk; bf16_t* dv; int lddkv;
     uint64_t q_bytes, kv_bytes, do_bytes;
+    uint64_t stat_bytes;             // bytes of the lse / delta arrays (B*H*N*4)
     const int* work; int n_work;     // dK/dV kernel: compact list of (batch, key tile) pairs, or null for the dense grid
 };
 
@@ -300,6 +301,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
         }
     }
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes), rdo = make_rsrc(p.dout, p.do_bytes);
+    const uint64_t stat_bytes = p.stat_bytes;
+    const __amdgpu_buffer_rsrc_t rlse = make_rsrc(p.lse, stat_bytes), rdel = make_rsrc(p.delta, stat_bytes);
     const int64_t krow = (int64_t)b * p.T + key, klimrow = (int64_t)b * p.T + p.T;
     bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -321,12 +324,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
         stage64x128<IMG_ROW>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
         stage64x128<IMG_TR>(rq, base + 2 * TILE, r0, rl, p.ldq, col0, p.dh, wave, lane);
         stage64x128<IMG_TR>(rdo, base + 3 * TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
-        if (threadIdx.x < 64) {
-            float* ls = reinterpret_cast<float*>(base + 4 * TILE);
-            const int qi = q0 + threadIdx.x;
+        // lse / delta rows by 4-byte LDS-DMA as well: an ordinary VGPR load here would make the compiler wait
+        // vmcnt(0) for it -- draining the 16 tile DMAs just issued and undoing the double buffering.  Rows past N read
+        // as 0 (range check); their Q and dO rows are zero too, so P stays finite and dS = P * (0 - 0) = 0.
+        if (wave < 2) {
+            const int qi = q0 + lane;
             const int64_t si = ((int64_t)b * p.H + h) * p.N + qi;
-            ls[threadIdx.x] = qi < p.N ? p.lse[si] : 1e30f;
-            ls[64 + threadIdx.x] = qi < p.N ? p.delta[si] : 0.f;
+            const uint32_t voff = qi < p.N ? (uint32_t)(si * 4) : YAT_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? rlse : rdel, (YAT_LDS void*)(base + 4 * TILE + wave * 256), 4,
+                                                     voff, 0, 0, 0);
         }
     };
     stage_q(0, smem);
@@ -432,6 +438,7 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.dout = (const bf16_t*)dout; p.lddo = lddo; p.delta = delta; p.dq = (bf16_t*)dq; p.lddq = lddq;
     p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lddkv = lddkv;
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
+    p.stat_bytes = (uint64_t)B * H * N * 4;
     hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), DQ_LDS, (hipStream_t)stream, p);
     YAT_CHECK_LAUNCH();
     if (work_list && n_work > 0) {

@@ -21,10 +21,12 @@ GEMM_WS_BYTES = 96 << 20
 
 
 def _gemm_ws(device):
-    ws = _GEMM_WS.get(device)
+    # one split-K workspace per (device, stream): GEMMs on different streams may run concurrently
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _GEMM_WS.get(key)
     if ws is None:
         ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
-        _GEMM_WS[device] = ws
+        _GEMM_WS[key] = ws
     return ws
 
 
@@ -76,7 +78,8 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
                                  C.byref(ep) if ep is not None else None, variant, _p(ws), ws.numel(), _stream())
     if timer is not None:
         e1.record()
-        timer.append((2.0 * M * N * K, e0, e1))
+        timer.append((2.0 * M * N * K, e0, e1, ("tn"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
+                      gate is not None, residual is not None, aux_out is not None)))
     _l.check(rc, "yat_gemm_bf16")
     return out
 

@@ -16,7 +16,7 @@ BF16 = torch.bfloat16
 
 class FlatAdamW:
     def __init__(self, model, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, use_ema=False,
-                 ema_decay=0.999):
+                 ema_decay=0.999, overlap_update=False):
         self.model = model
         dev = model.flat_param.device
         self.param_groups = [dict(lr=lr, initial_lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
@@ -32,6 +32,11 @@ class FlatAdamW:
         self.ema_shadow = model.flat_param.clone() if use_ema else None
         self.ema_decay = ema_decay
         self.ema_steps = 0
+        # overlap_update: the update runs bucket by bucket (forward order) on its own stream and hands the model one
+        # event per bucket; the next forward waits per bucket, so this HBM-bound pass hides under the forward GEMMs.
+        # Anything else that reads parameters first calls model.join_pending_update().
+        self.overlap_update = overlap_update and dev.type == "cuda"
+        self._stream = None
 
     def _ema_decay_now(self):
         """[RECALL] diffusers EMAModel.get_decay (use_ema_warmup=False): min(decay, (1+s)/(10+s)), 0 on the first call."""
@@ -53,9 +58,31 @@ class FlatAdamW:
         if self.ema_shadow is not None:
             self.ema_steps += 1
             ema_decay = self._ema_decay_now()
-        ops.adamw_step(m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, coef, g["lr"], g["betas"][0],
-                       g["betas"][1], g["eps"], g["weight_decay"], self.step_count, zero_grad=True,
-                       ema_shadow=self.ema_shadow, ema_decay=ema_decay)
+
+        def update(lo, hi):
+            # no gradient clear: every backward overwrites the whole flat gradient (accumulate_grads=False on the
+            # first micro-step), like the reference's zero_grad(set_to_none=True) which writes nothing either
+            ops.adamw_step(m.flat_param[lo:hi], m.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], coef,
+                           g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
+                           zero_grad=False, ema_shadow=None if self.ema_shadow is None else self.ema_shadow[lo:hi],
+                           ema_decay=ema_decay)
+
+        if not self.overlap_update:
+            update(0, m.numel_flat)
+            return
+        m.join_pending_update()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=m.flat_param.device)
+        main = torch.cuda.current_stream()
+        self._stream.wait_stream(main)
+        events = []
+        with torch.cuda.stream(self._stream):
+            for lo, hi in m.bucket_bounds:
+                update(lo, hi)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+                events.append(ev)
+        m.param_events = events
 
     def zero_grad(self, set_to_none=False):
         # the gradient clear is fused into step(); explicit calls (e.g. before the first step) still work

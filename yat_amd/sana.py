@@ -28,6 +28,7 @@ gradient buffer (``p.grad`` are views of it).
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field, asdict
 from types import SimpleNamespace
 
@@ -163,6 +164,9 @@ class SanaTransformer2DModelHIP(nn.Module):
         # bucket boundaries for data parallel reduction: head | one per block (+tail on the last)
         self.bucket_bounds = self._make_buckets(specs, offs, off)
         self.grad_ready = None            # callable(bucket_index) set by HipDDP
+        self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"   # weight gradients on a second stream
+        self._side = None
+        self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
         self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
         self._arena = {}
         self._saved = None
@@ -285,6 +289,45 @@ class SanaTransformer2DModelHIP(nn.Module):
         S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, key_bias=key_bias, kv_len=kv_len, kv_work=kv_work,
                             enc2d=enc2d, blocks=[])
         buf = self._buf
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.side_wgrad else None
+        pev, self.param_events = self.param_events, None      # per-bucket events of an AdamW update still in flight
+
+        def params_ready(bucket, stream=main):
+            if pev is not None:
+                stream.wait_event(pev[bucket])
+
+        # The text branch (caption projection, RMSNorm, every block's K/V projection) does not depend on the latent
+        # stream until the first cross-attention: it runs on the second stream, filling CUs the single-round GEMMs of
+        # the main chain leave idle.
+        def text_branch():
+            S.zc1 = buf("cap_z1", (Mt, D))
+            S.c1 = ops.linear_fwd(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
+                                  out=buf("cap_c1", (Mt, D)), activation="gelu_tanh", aux_out=S.zc1)
+            S.c2 = ops.linear_fwd(S.c1, P["caption_projection.linear_2.weight"], P["caption_projection.linear_2.bias"],
+                                  out=buf("cap_c2", (Mt, D)))
+            S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, buf("cap_n", (Mt, D)),
+                                                 buf("cap_rstd", (Mt,), torch.float32))
+            S.kv2, S.kv_ready = [], []
+            cur = torch.cuda.current_stream()
+            for i in range(cfg.num_layers):
+                pre = f"transformer_blocks.{i}."
+                params_ready(i + 1, cur)
+                wkv, _ = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
+                bkv, _ = self._fused(pre + "attn2.to_k.bias", 2 * D)
+                S.kv2.append(ops.linear_fwd(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D))))
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    S.kv_ready.append(ev)
+
+        params_ready(0)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_branch()
+        else:
+            text_branch()
 
         # 1. patch embed (1x1 conv == Linear over channels) on token-major rows
         S.x_tok = ops.transpose(latents.view(B, Cin, N), buf("x_tok", (B, N, Cin))).view(M, Cin)
@@ -301,19 +344,13 @@ class SanaTransformer2DModelHIP(nn.Module):
         S.se = ops.act_fwd(S.embedded, "silu", buf("te_se", (B, D)))
         S.tmod = ops.linear_fwd(S.se, P["time_embed.linear.weight"], P["time_embed.linear.bias"],
                                 out=buf("te_tmod", (B, 6 * D)))
-        # 3. caption projection + RMSNorm
-        S.zc1 = buf("cap_z1", (Mt, D))
-        S.c1 = ops.linear_fwd(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
-                              out=buf("cap_c1", (Mt, D)), activation="gelu_tanh", aux_out=S.zc1)
-        S.c2 = ops.linear_fwd(S.c1, P["caption_projection.linear_2.weight"], P["caption_projection.linear_2.bias"],
-                              out=buf("cap_c2", (Mt, D)))
-        S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, buf("cap_n", (Mt, D)),
-                                             buf("cap_rstd", (Mt,), torch.float32))
+        # 3. caption projection + RMSNorm + K/V projections: text_branch() above
         scale2 = 1.0 / math.sqrt(dh2)
         # 4. transformer blocks
         for i in range(cfg.num_layers):
             pre = f"transformer_blocks.{i}."
             A = SimpleNamespace(x_in=x)
+            params_ready(i + 1)
             A.mod = ops.modulation_fwd(P[pre + "scale_shift_table"], S.tmod, D, buf(f"b{i}.mod", (B, 6, D)))
             mod2d = A.mod.view(B, 6 * D)
             A.h1, A.mean1, A.rstd1 = ops.ln_modulate_fwd(
@@ -329,9 +366,9 @@ class SanaTransformer2DModelHIP(nn.Module):
                                   ld_gate=6 * D, residual=x, rows_per_batch=N)
             A.q2 = ops.linear_fwd(A.x1, P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"],
                                   out=buf(f"b{i}.q2", (M, D)))
-            wkv, _ = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
-            bkv, _ = self._fused(pre + "attn2.to_k.bias", 2 * D)
-            A.kv2 = ops.linear_fwd(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D)))
+            A.kv2 = S.kv2[i]
+            if side is not None:
+                main.wait_event(S.kv_ready[i])
             A.o2 = buf(f"b{i}.o2", (M, D))
             A.lse = buf(f"b{i}.lse", (B, H2, N), torch.float32)
             ops.sdpa_fwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, key_bias, kv_len, A.o2, A.lse)
@@ -363,6 +400,19 @@ class SanaTransformer2DModelHIP(nn.Module):
         self._saved = S
         return pred.view(B, Cout, h, w)
 
+    def join_pending_update(self):
+        """Make the current stream wait for an optimizer update still running on the optimizer's stream."""
+        pev, self.param_events = self.param_events, None
+        if pev is not None:
+            cur = torch.cuda.current_stream()
+            for ev in pev:
+                cur.wait_event(ev)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat_param.device)
+        return self._side
+
     # ------------------------------------------------------------------ backward
     def backward_impl(self, dpred):
         S = self._saved
@@ -383,16 +433,41 @@ class SanaTransformer2DModelHIP(nn.Module):
         la_ws = buf("la_ws", (ops.linear_attn_workspace_bytes(B, N, H1),), u8)
         scale2 = 1.0 / math.sqrt(dh2)
 
-        def wgrad(dy, x, key, shape2d):
-            ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
+        # Weight/bias gradients are off the critical path (nothing in backward reads them): they go to a second
+        # stream so their blocks fill the CUs the single-round dgrad launches leave idle, and their prologue/epilogue
+        # phases overlap the other stream's MFMA phases.  ``pending`` maps a dy buffer to the event after which the
+        # main stream may overwrite it.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.side_wgrad else None
+        pending = {}
 
-        def bgrad(dy, key):
-            ops.colsum(dy, G[key], ws_col, accumulate=acc)
+        def on_side(dy_base, fn):
+            if side is None:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            pending[dy_base.data_ptr()] = ev
+
+        def writes(*ts):
+            for t in ts:
+                ev = pending.pop(t.data_ptr(), None)
+                if ev is not None:
+                    main.wait_event(ev)
+
+        def wgrad(dy, x, key, shape2d, bias_key=None):
+            def run():
+                ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
+                if bias_key is not None:
+                    ops.colsum(dy, G[bias_key], ws_col, accumulate=acc)
+            on_side(dy, run)
 
         # ---- output head
         d_out_tok = ops.transpose(dpred.to(BF16).contiguous().view(B, Cout, N), buf("d_out_tok", (B, N, Cout))).view(M, Cout)
-        wgrad(d_out_tok, S.hf, "proj_out.weight", (Cout, D))
-        bgrad(d_out_tok, "proj_out.bias")
+        wgrad(d_out_tok, S.hf, "proj_out.weight", (Cout, D), "proj_out.bias")
         dhf = ops.linear_dgrad(d_out_tok, P["proj_out.weight"], out=buf("dh", (M, D)))
         dmodf = buf("dmodf", (B, 2, D), f32).zero_()
         dtmod = buf("dtmod", (B, 6 * D), f32).zero_()
@@ -412,80 +487,87 @@ class SanaTransformer2DModelHIP(nn.Module):
             dmod2d = dmod.view(B, 6 * D)
             # x3 = x2 + gate_mlp * lin3
             dlin = buf("dlin", (M, D))
+            writes(dlin)
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
             wgrad(dlin, A.y, pre + "ff.conv_point.weight", (D, Hc))
             dy = ops.linear_dgrad(dlin, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
             dz = buf("dz", (M, 2 * Hc))
+            writes(dz)
             ops.dwconv_glu_bwd(A.s, A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc)
-            wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D))
-            bgrad(dz, pre + "ff.conv_inverted.bias")
+            wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D), pre + "ff.conv_inverted.bias")
             dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf("dh", (M, D)))
             other = dxb if dx is dxa else dxa
+            writes(other)
             dx2 = ops.ln_modulate_bwd(A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2_, dx, other,
                                       dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln)
             # x2 = x1 + to_out(o2)
-            wgrad(dx2, A.o2, pre + "attn2.to_out.0.weight", (D, D))
-            bgrad(dx2, pre + "attn2.to_out.0.bias")
+            wgrad(dx2, A.o2, pre + "attn2.to_out.0.weight", (D, D), pre + "attn2.to_out.0.bias")
             do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf("dh", (M, D)))
             dq2 = buf("dq2", (M, D))
             dkv2 = buf("dkv2", (Mt, 2 * D))
             delta = buf("delta", (B, H2, N), f32)
+            writes(dq2, dkv2)
             ops.sdpa_bwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse,
                          delta, dq2, dkv2[:, :D], dkv2[:, D:], work=S.kv_work)
-            wgrad(dq2, A.x1, pre + "attn2.to_q.weight", (D, D))
-            bgrad(dq2, pre + "attn2.to_q.bias")
+            wgrad(dq2, A.x1, pre + "attn2.to_q.weight", (D, D), pre + "attn2.to_q.bias")
+            writes(dx2)                                                                           # overwritten in place below
             dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=dx2, residual=dx2)      # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
-            ops.linear_wgrad(dkv2, S.encn, gkv, accumulate=acc)
-            ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
-            ops.linear_dgrad(dkv2, wkv, out=denc, residual=None if i == cfg.num_layers - 1 else denc)
+
+            def kv_grads(dkv2=dkv2, wkv=wkv, gkv=gkv, gbkv=gbkv, first=(i == cfg.num_layers - 1)):
+                # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
+                ops.linear_wgrad(dkv2, S.encn, gkv, accumulate=acc)
+                ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
+                ops.linear_dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
+            on_side(dkv2, kv_grads)
             # x1 = x + gate_msa * lin1
+            writes(dlin)
             ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate)
-            wgrad(dlin, A.attn, pre + "attn1.to_out.0.weight", (D, D))
-            bgrad(dlin, pre + "attn1.to_out.0.bias")
+            wgrad(dlin, A.attn, pre + "attn1.to_out.0.weight", (D, D), pre + "attn1.to_out.0.bias")
             dattn = ops.linear_dgrad(dlin, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf("dqkv", (M, 3 * D))
+            writes(dqkv)
             ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
-            ops.linear_wgrad(dqkv, A.h1, gqkv, accumulate=acc)
+            on_side(dqkv, lambda dqkv=dqkv, gqkv=gqkv, A=A: ops.linear_wgrad(dqkv, A.h1, gqkv, accumulate=acc))
             dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf("dh", (M, D)))
             other = dxb if dx1 is dxa else dxa
+            writes(other)
             dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1, dx1, other,
                                      dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln)
             ops.modulation_bwd(dmod, G[pre + "scale_shift_table"], dtmod, D, accumulate_table=acc)
             if self.grad_ready is not None:
+                if side is not None:
+                    main.wait_stream(side)
                 self.grad_ready(i + 1)
-        # ---- embedders
-        wgrad(dx, S.x_tok, "patch_embed.proj.weight", (D, Cin))
-        bgrad(dx, "patch_embed.proj.bias")
+        # ---- embedders (small: back on the main stream)
+        if side is not None:
+            main.wait_stream(side)
+            side = None
+        wgrad(dx, S.x_tok, "patch_embed.proj.weight", (D, Cin), "patch_embed.proj.bias")
         # caption branch
         dc2 = buf("dc2", (Mt, D))
         ws_rms = buf("ws_rms", (int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(Mt, D)),), u8)
         ops.rmsnorm_bwd(S.c2, P["caption_norm.weight"], S.enc_rstd, denc, dc2, G["caption_norm.weight"], ws_rms,
                         accumulate_dw=acc)
-        wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D))
-        bgrad(dc2, "caption_projection.linear_2.bias")
+        wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D), "caption_projection.linear_2.bias")
         dc1 = ops.linear_dgrad(dc2, P["caption_projection.linear_2.weight"], out=denc)
         dzc1 = ops.act_bwd(S.zc1, dc1, "gelu_tanh", dc2)
-        wgrad(dzc1, S.enc2d, "caption_projection.linear_1.weight", (D, cfg.caption_channels))
-        bgrad(dzc1, "caption_projection.linear_1.bias")
+        wgrad(dzc1, S.enc2d, "caption_projection.linear_1.weight", (D, cfg.caption_channels), "caption_projection.linear_1.bias")
         # timestep branch
         dtmod_b = ops.f32_to_bf16(dtmod, buf("dtmod_b", (B, 6 * D)))
-        wgrad(dtmod_b, S.se, "time_embed.linear.weight", (6 * D, D))
-        bgrad(dtmod_b, "time_embed.linear.bias")
+        wgrad(dtmod_b, S.se, "time_embed.linear.weight", (6 * D, D), "time_embed.linear.bias")
         dse = ops.linear_dgrad(dtmod_b, P["time_embed.linear.weight"], out=buf("te_d1", (B, D)))
         demb_a = ops.act_bwd(S.embedded, dse, "silu", buf("te_d2", (B, D)))
         demb_b = ops.f32_to_bf16(demb, buf("te_d3", (B, D)))
         d_emb = ops.add_bf16(demb_a, demb_b, buf("te_d1", (B, D)))
-        wgrad(d_emb, S.e1, "time_embed.emb.timestep_embedder.linear_2.weight", (D, D))
-        bgrad(d_emb, "time_embed.emb.timestep_embedder.linear_2.bias")
+        wgrad(d_emb, S.e1, "time_embed.emb.timestep_embedder.linear_2.weight", (D, D), "time_embed.emb.timestep_embedder.linear_2.bias")
         de1 = ops.linear_dgrad(d_emb, P["time_embed.emb.timestep_embedder.linear_2.weight"], out=buf("te_d2", (B, D)))
         dz1 = ops.act_bwd(S.z1, de1, "silu", buf("te_d3", (B, D)))
-        wgrad(dz1, S.tproj, "time_embed.emb.timestep_embedder.linear_1.weight", (D, 256))
-        bgrad(dz1, "time_embed.emb.timestep_embedder.linear_1.bias")
+        wgrad(dz1, S.tproj, "time_embed.emb.timestep_embedder.linear_1.weight", (D, 256), "time_embed.emb.timestep_embedder.linear_1.bias")
         if self.grad_ready is not None:
             self.grad_ready(0)
 
@@ -495,6 +577,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         import os
         from safetensors.torch import save_file
         os.makedirs(path, exist_ok=True)
+        self.join_pending_update()
         sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
         save_file(sd, os.path.join(path, "diffusion_pytorch_model.safetensors"))
         cfgd = asdict(self.cfg)
