@@ -130,6 +130,213 @@ __global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, i
     }
 }
 
+inline int nseg_of(int w) { return (w + SEG - 1) / SEG; }
+inline int nsb_of(int w) { return (w + 4 * SEG - 1) / (4 * SEG); }
+inline int nrg_of(int h) { return (h + ROWS - 1) / ROWS; }
+inline unsigned grid8(int64_t total) { return (unsigned)(((total + 7) / 8) * 8); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-tiled version (w <= 64, Hc % 8 == 0): the kernels above issue one guarded 8-byte global load per (row, column,
+// half) and keep the loads in flight in VGPRs, which caps occupancy at 3 waves/SIMD and leaves them latency-bound at
+// ~2.5 TB/s.  Here a workgroup stages a whole (R+2)-row x w-column x 32-channel tile of both halves with LDS-DMA
+// (16 B/lane, no VGPRs, zero fill at the image border from the buffer range check) and computes from LDS.
+//   tile[half][(R+2) rows][WP = w+1 columns][32 ch]: column 0 of a row is the zero left halo AND (being the element after
+//   column w of the previous row) the zero right halo, so no second halo column is stored.  WP is odd for even w:
+//   consecutive rows start 64 B (mod 256 B) apart and the four runs one ds_read_b64 serves per cycle hit disjoint banks.
+//   9 pad pixels after each half absorb the over-read of a partial last column segment.
+// A thread owns 4 channels of one run = SEG output columns of one row; the column loop is fully unrolled with the three
+// rolling accumulators renamed statically (no register shuffling), every tap is applied exactly once.
+// MODE 0: forward (writes y).  MODE 1: backward pass 1 (reads dy, writes du for both halves).
+constexpr int TCH = 32;                 // channels per half per tile
+constexpr int TILE_PAD = 9;
+
+struct TileGeo { int WP, PHp; };
+__host__ __device__ inline TileGeo tile_geo(int w, int R) {
+    TileGeo g;
+    g.WP = w + 1;
+    g.PHp = ((R + 2) * g.WP + 1 + TILE_PAD + 15) & ~15;      // pixel slots per half, multiple of 16 (one DMA instruction)
+    return g;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void dwglu_tile_kernel(int h, int w, int Hc, int B, int R, int nbands, int nchunk,
+                                                         const bf16_t* s, uint64_t s_bytes, const bf16_t* wdw,
+                                                         const bf16_t* bdw, const bf16_t* dy, bf16_t* out) {
+    // s_bytes = bytes of the [B,h,w,2Hc] arrays (s, du); dy / y are half that.  All global traffic of the run loop goes
+    // through range-checked buffer instructions: a guarded plain store makes the optimizer sink each output's FMAs into
+    // its branch, which keeps three unpacked input columns live (299 VGPRs).
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+    const int total = nbands * nchunk * B;
+    int u = xcd_unit(total);
+    if (u >= total) return;
+    const int rb = u % nbands; u /= nbands;
+    const int cx = u % nchunk, b = u / nchunk;
+    const int i0 = rb * R, ch0 = cx * TCH;
+    const TileGeo geo = tile_geo(w, R);
+    const int WP = geo.WP, PHp = geo.PHp, C2 = 2 * Hc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- stage: one wave instruction = 16 pixel slots x 64 B
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(s, s_bytes);
+        const int ninstr = 2 * PHp / 16;
+        const int k = lane & 3;
+        const int ch = ch0 + k * 8;
+        for (int it = wave; it < ninstr; it += 4) {
+            const int p = it * 16 + (lane >> 2);
+            const int half = p >= PHp ? 1 : 0;
+            const int q = p - half * PHp;
+            const int r = q / WP, cidx = q - r * WP;
+            const int ii = i0 - 1 + r, jj = cidx - 1;
+            const bool ok = r < R + 2 && jj >= 0 && ii >= 0 && ii < h && ch < Hc;
+            const uint32_t voff = ok ? (uint32_t)(((((int64_t)b * h + ii) * w + jj) * C2 + half * Hc + ch) * 2) : YAT_OOB;
+            lds_dma16(rs, (YAT_LDS void*)(tile + it * 1024), voff);
+        }
+    }
+    // ---- per-thread constants while the tile is in flight
+    const int cg = lane & 7;
+    const int ca = ch0 + cg * 4, cgl = Hc + ca;
+    const bool chan_ok = ca < Hc;
+    float wa[9][4], wg[9][4], ba[4], bg[4];
+    {
+        const int cs = chan_ok ? ca : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                wa[t][e] = bf2f(wdw[(cs + e) * 9 + t]);
+                wg[t][e] = bf2f(wdw[(Hc + cs + e) * 9 + t]);
+            }
+        }
+        unpack4(*reinterpret_cast<const u32x2*>(bdw + cs), ba);
+        unpack4(*reinterpret_cast<const u32x2*>(bdw + Hc + cs), bg);
+        // opaque to the optimizer: otherwise it keeps the packed words and re-unpacks every weight inside the run loop
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wa[t][e]), "+v"(wg[t][e]));
+    }
+    const int nseg = (w + SEG - 1) / SEG, nruns = R * nseg;
+    const int slot = wave * 8 + (lane >> 3);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, MODE == 0 ? s_bytes / 2 : s_bytes);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(MODE == 1 ? dy : s, s_bytes / 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int run = slot; run < nruns; run += 32) {
+        const int row = run % R, seg = run / R;             // rows fastest: neighbouring runs sit in different bank groups
+        const int i = i0 + row;
+        if (i >= h || !chan_ok) continue;
+        const int j0 = seg * SEG;
+        const unsigned char* pa = tile + ((row * WP + j0) * TCH + cg * 4) * 2;       // row `row` of the tile = image row i-1
+        const unsigned char* pg = pa + PHp * TCH * 2;
+        const int64_t pix0 = ((int64_t)b * h + i) * w + j0;
+        u32x2 dyv[3];                                       // dy of output o is fetched at step o, used at step o + 2
+        float A[3][4], G[3][4];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { A[m][e] = ba[e]; G[m][e] = bg[e]; }
+        u32x2 nxt[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            nxt[2 * r] = *reinterpret_cast<const u32x2*>(pa + (r * WP) * TCH * 2);
+            nxt[2 * r + 1] = *reinterpret_cast<const u32x2*>(pg + (r * WP) * TCH * 2);
+        }
+#pragma unroll
+        for (int t = 0; t < SEG + 2; ++t) {                 // input column j0 - 1 + t  (tile column j0 + t)
+            u32x2 cur[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) cur[m] = nxt[m];
+            if (MODE == 1 && t < SEG)
+                dyv[t % 3] = __builtin_amdgcn_raw_buffer_load_b64(
+                    rdy, j0 + t < w ? (uint32_t)(((pix0 + t) * Hc + ca) * 2) : YAT_OOB, 0, 0);
+            if (t + 1 < SEG + 2) {                          // next column's LDS reads fly under this column's FMAs
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    nxt[2 * r] = *reinterpret_cast<const u32x2*>(pa + (r * WP + t + 1) * TCH * 2);
+                    nxt[2 * r + 1] = *reinterpret_cast<const u32x2*>(pg + (r * WP + t + 1) * TCH * 2);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float za[4], zg[4];
+                unpack4(cur[2 * r], za);
+                unpack4(cur[2 * r + 1], zg);
+#pragma unroll
+                for (int dj = 2; dj >= 0; --dj) {           // output o = t - dj takes tap column dj (same order as above)
+                    const int o = t - dj;
+                    if (o < 0 || o >= SEG) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        A[o % 3][e] += wa[r * 3 + dj][e] * za[e];
+                        G[o % 3][e] += wg[r * 3 + dj][e] * zg[e];
+                    }
+                }
+            }
+            const int o = t - 2;                            // output column j0 + o has now seen all three input columns
+            if (o >= 0) {
+                float ua[4], ug[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ua[e] = rbf(A[o % 3][e]); ug[e] = rbf(G[o % 3][e]); A[o % 3][e] = ba[e]; G[o % 3][e] = bg[e]; }
+                const bool live = j0 + o < w;
+                {
+                    if (MODE == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b64(
+                            pack4(ua[0] * rbf(silu_f(ug[0])), ua[1] * rbf(silu_f(ug[1])), ua[2] * rbf(silu_f(ug[2])),
+                                  ua[3] * rbf(silu_f(ug[3]))),
+                            rout, live ? (uint32_t)(((pix0 + o) * Hc + ca) * 2) : YAT_OOB, 0, 0);
+                    } else {
+                        float d[4], da[4], dg[4];
+                        unpack4(dyv[o % 3], d);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            da[e] = d[e] * rbf(silu_f(ug[e]));
+                            dg[e] = rbf(d[e] * ua[e]) * dsilu_f(ug[e]);
+                        }
+                        const uint32_t off = live ? (uint32_t)(((pix0 + o) * C2 + ca) * 2) : YAT_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b64(pack4(da[0], da[1], da[2], da[3]), rout, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(pack4(dg[0], dg[1], dg[2], dg[3]), rout,
+                                                                  live ? off + (uint32_t)Hc * 2 : YAT_OOB, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);              // keep the unrolled columns from hoisting all their reads
+        }
+    }
+}
+
+// rows per band: the largest R whose tile leaves room for three workgroups per CU, weighted by how well R * nseg runs
+// fill the 32 run slots and by the (R+2)/R halo re-read
+inline int pick_band_rows(int h, int w, size_t* lds_bytes) {
+    const int nseg = (w + SEG - 1) / SEG;
+    int best = 0;
+    double best_score = 0;
+    for (int R = 2; R <= 16 && R <= ((h + 1) & ~1); ++R) {
+        const size_t bytes = (size_t)2 * tile_geo(w, R).PHp * TCH * 2;
+        if (bytes > 53248) break;
+        const int nruns = R * nseg, passes = (nruns + 31) / 32;
+        const int nb = (h + R - 1) / R;
+        const double score = (double)nruns / (passes * 32) * R / (R + 2) * h / (nb * R);
+        if (score > best_score) { best_score = score; best = R; }
+    }
+    if (best) *lds_bytes = (size_t)2 * tile_geo(w, best).PHp * TCH * 2;
+    return best;
+}
+
+template <int MODE>
+int launch_tile(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
+                bf16_t* out, hipStream_t stream) {
+    size_t lds = 0;
+    const int R = pick_band_rows(h, w, &lds);
+    const uint64_t s_bytes = (uint64_t)B * h * w * 2 * Hc * 2;
+    if (!R || (Hc & 7) || s_bytes > 0x7fffffffull) return -1;          // caller falls back to the direct kernels
+    const int nbands = (h + R - 1) / R, nchunk = (Hc + TCH - 1) / TCH;
+    hipLaunchKernelGGL((dwglu_tile_kernel<MODE>), dim3(grid8((int64_t)nbands * nchunk * B)), dim3(256), lds, stream, h, w,
+                       Hc, B, R, nbands, nchunk, s, s_bytes, wdw, bdw, dy, out);
+    return 0;
+}
+
 // backward pass 2.  Block = 64 channel groups (4 channels each, either half) x 4 column segments;
 // thread = rows [i0, i0+ROWS) x columns [j0, j0+SEG) of image b.
 //   dz[i,j] = SiLU'(z[i,j]) * bf16( sum_taps W[tap] du[i-di, j-dj] )
@@ -253,10 +460,6 @@ __global__ void dwconv_reduce_kernel(int P, int C2, const float* ws, bf16_t* dw,
     *dst = f2bf(s);
 }
 
-inline int nseg_of(int w) { return (w + SEG - 1) / SEG; }
-inline int nsb_of(int w) { return (w + 4 * SEG - 1) / (4 * SEG); }
-inline int nrg_of(int h) { return (h + ROWS - 1) / ROWS; }
-inline unsigned grid8(int64_t total) { return (unsigned)(((total + 7) / 8) * 8); }
 
 }  // namespace
 
@@ -267,6 +470,11 @@ int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* w
     const void* z = s;
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !z || !wdw || !bdw || !y) return YAT_EINVAL;
     if ((int64_t)h * nseg_of(w) * B * ((Hc / 4 + 63) / 64) * 2 > 0x7fffff00ll) return YAT_EINVAL;
+    if (w <= 64 && launch_tile<0>(B, h, w, Hc, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)bdw, nullptr,
+                                  (bf16_t*)y, (hipStream_t)stream) == 0) {
+        YAT_CHECK_LAUNCH();
+        return YAT_OK;
+    }
     const int nx = (Hc / 4 + 255) / 256;
     hipLaunchKernelGGL((dwconv_glu_kernel<0>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
                        (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)z, (const bf16_t*)wdw,
@@ -294,9 +502,11 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     const uint64_t du_bytes = ((uint64_t)B * h * w * C2 * 2 + 255) & ~255ull;
     float* ws = (float*)((char*)workspace + du_bytes);
     const int nx = (Hc / 4 + 255) / 256, nx2 = (C2 / 4 + 63) / 64;
-    hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
-                       (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
-                       (const bf16_t*)bdw, (const bf16_t*)dy, du);
+    if (!(w <= 64 && launch_tile<1>(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
+                                    (const bf16_t*)dy, du, (hipStream_t)stream) == 0))
+        hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
+                           (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
+                           (const bf16_t*)bdw, (const bf16_t*)dy, du);
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dwconv_bwd2_kernel, dim3(grid8((int64_t)nx2 * gy2 * B)), dim3(256), 0, (hipStream_t)stream, h, w,
                        Hc, nx2, nrg_of(h), B, (const bf16_t*)s, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)du,
