@@ -50,6 +50,12 @@ __device__ __forceinline__ void unpack4(const u32x2& v, float* o) {
     o[2] = __uint_as_float(v[1] << 16);
     o[3] = __uint_as_float(v[1] & 0xffff0000u);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// 4 packed bf16 -> two channel pairs
+__device__ __forceinline__ void unpack22(const u32x2& v, f32x2* o) {
+    o[0] = f32x2{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u)};
+    o[1] = f32x2{__uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+}
 __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
     u32x2 v;
     v[0] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);

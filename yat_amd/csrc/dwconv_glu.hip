@@ -3,18 +3,18 @@
 //   u = dwconv3x3(s) + bias;  y = u[:Hc] * SiLU(u[Hc:])
 // (diffusers GLUMBConv as called at /root/reference/utils/patch_sana_attention_layers.py:110-113;
 // z is the conv_inverted output, so the reference's NCHW permutes at :110,112 disappear).
+// Backward = two passes: (1) recompute u, emit du (bf16); (2) transposed conv of du -> dz (times SiLU'(z)) with the
+// weight / bias gradient partials accumulated in registers, reduced per workgroup in LDS, then by a small kernel.
 //
-// HBM-bound (read z, write y).  Lanes run along channels (4 channels = 8 B per lane, 512 B
-// contiguous per wave-instruction).  A thread owns one image row segment of SEG output columns and
-// walks it left to right with rolling accumulators: every input column (rows i-1, i, i+1) is
-// loaded once and scattered into the three output columns it touches, so no 3x3 window lives in
-// registers and each z element is fetched ~3.75x from L2 instead of 9x.  The next column's loads
-// are issued before the current column is consumed (register double buffer) so L2/HBM latency
-// hides under the FMA work.  (Recomputing SiLU on every load made the kernel VALU-bound: 3.75 SiLUs per
-// element; the producer GEMM now applies it once.)
-// Backward = two passes: (1) recompute u, emit du (bf16); (2) transposed conv of du -> dz (times
-// SiLU'(z)), with the weight / bias gradient partials accumulated in registers over ROWS x SEG
-// pixels, reduced across the block's segments in LDS, then across blocks by a small kernel.
+// Two generations of kernels live here:
+//  * LDS-tiled kernels (dwglu_tile_kernel<0/1>, dwglu_bwd2_tile_kernel) for w <= 64 -- the product path at every SANA
+//    aspect bucket.  A workgroup stages (R+2) image rows x w columns x 32 channels with LDS-DMA and computes from LDS;
+//    a thread owns 4 channels of a run of SEG output columns and walks it with three statically rotated accumulators,
+//    so each tap is applied exactly once and nothing is shuffled between registers.  Measured (B=8, 32x32, Hc=5600):
+//    forward ~89 us, backward ~350 us; PMC shows the forward at ~75 % VALU utilisation (unpack + FMA + SiLU), i.e. these
+//    are VALU-bound at ~3 TB/s of algorithmic traffic, not HBM-bound.
+//  * direct kernels (dwconv_glu_kernel<0/1>, dwconv_bwd2_kernel) for wider images: lanes along channels (8 B per lane),
+//    one guarded global load per (row, column, half), register double buffer.  ~25 % slower; kept as the general path.
 #include "common.hpp"
 #include "../../include/yat_hip.h"
 
@@ -147,7 +147,33 @@ inline unsigned grid8(int64_t total) { return (unsigned)(((total + 7) / 8) * 8);
 // A thread owns 4 channels of one run = SEG output columns of one row; the column loop is fully unrolled with the three
 // rolling accumulators renamed statically (no register shuffling), every tap is applied exactly once.
 // MODE 0: forward (writes y).  MODE 1: backward pass 1 (reads dy, writes du for both halves).
-constexpr int TCH = 32;                 // channels per half per tile
+// 9 taps of 4 consecutive channels = 36 contiguous bf16 (8-byte aligned since the channel index is a multiple of 4):
+// nine 8-byte loads issued together, then regrouped as channel pairs per tap
+__device__ __forceinline__ void load_taps(const bf16_t* wdw, int c, f32x2 (&wv)[9][2]) {
+    u32x2 raw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) raw[k] = *reinterpret_cast<const u32x2*>(wdw + (int64_t)c * 9 + k * 4);
+    float flat[36];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) unpack4(raw[k], flat + 4 * k);      // flat[e*9 + t]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) wv[t][pr] = f32x2{flat[(2 * pr) * 9 + t], flat[(2 * pr + 1) * 9 + t]};
+    // opaque to the optimizer (after ALL loads): otherwise it keeps the packed words and re-unpacks each weight in the run loop
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) asm volatile("" : "+v"(wv[t][pr]));
+}
+
+#ifndef YAT_DW_TCH
+#define YAT_DW_TCH 32
+#endif
+constexpr int TCH = YAT_DW_TCH;         // channels per half per tile
+constexpr int NCG = TCH / 4;            // 4-channel groups (threads) across a tile pixel
+constexpr int PPP = TCH / 8;            // 16-byte pieces per tile pixel
+constexpr int GPX = 64 / PPP;           // pixels one DMA wave instruction moves
 constexpr int TILE_PAD = 9;
 
 struct TileGeo { int WP, PHp; };
@@ -158,73 +184,86 @@ __host__ __device__ inline TileGeo tile_geo(int w, int R) {
     return g;
 }
 
+// Stage `nrows` image rows (first one ii0; rows outside [0,h) become zeros) of 32 channels starting at element `chan`
+// of a [B,h,w,C2] array into tile slots slot0 + r*WP + 1 + j.  One wave instruction moves 16 consecutive pixels x 64 B:
+// the lane pattern (pixel lane>>2, 16-byte piece lane&3) never changes, only the scalar offset does, so staging costs a
+// few SALU instructions per KiB instead of per-lane index arithmetic.  Slot 0 of every row (the shared zero halo) and the
+// pad are never written here; the whole tile is cleared once per workgroup.
+__device__ __forceinline__ void stage_rows(const __amdgpu_buffer_rsrc_t rs, unsigned char* tile, int slot0, int nrows,
+                                           int ii0, int b, int h, int w, int WP, int C2, int chan, bool lane_ch_ok,
+                                           int wave_s, int nwaves, int lane) {
+    const int ngroups = (w + GPX - 1) / GPX;
+    const uint32_t vlane = (uint32_t)(lane / PPP) * (uint32_t)C2 * 2u + (uint32_t)(lane % PPP) * 16u;
+    int k = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int ii = ii0 + r;
+        const bool row_ok = ii >= 0 && ii < h;
+        for (int g = 0; g < ngroups; ++g, ++k) {
+            if ((k & (nwaves - 1)) != wave_s) continue;                   // wave-uniform: rows x groups dealt round-robin
+            const int jj0 = g * GPX;
+            const uint32_t soff = row_ok ? (uint32_t)(((((int64_t)b * h + ii) * w + jj0) * C2 + chan) * 2) : 0u;
+            if ((lane / PPP) < w - jj0)                                   // partial last group: EXEC-masked lanes write nothing
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (YAT_LDS void*)(tile + (slot0 + r * WP + 1 + jj0) * (TCH * 2)),
+                                                         16, row_ok && lane_ch_ok ? vlane : YAT_OOB, soff, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void clear_tile(unsigned char* tile, int bytes) {
+    for (int o = threadIdx.x * 16; o < bytes; o += blockDim.x * 16) *reinterpret_cast<u32x4*>(tile + o) = u32x4{0u, 0u, 0u, 0u};
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void dwglu_tile_kernel(int h, int w, int Hc, int B, int R, int nbands, int nchunk,
-                                                         const bf16_t* s, uint64_t s_bytes, const bf16_t* wdw,
-                                                         const bf16_t* bdw, const bf16_t* dy, bf16_t* out) {
+__global__ __launch_bounds__(256, 3) void dwglu_tile_kernel(int h, int w, int Hc, int B, int R, int rmagic, int nbands,
+                                                            int bpb, int nchunk, const bf16_t* s, uint64_t s_bytes,
+                                                            const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
+                                                            bf16_t* out) {
     // s_bytes = bytes of the [B,h,w,2Hc] arrays (s, du); dy / y are half that.  All global traffic of the run loop goes
     // through range-checked buffer instructions: a guarded plain store makes the optimizer sink each output's FMAs into
     // its branch, which keeps three unpacked input columns live (299 VGPRs).
+    // A workgroup owns `bpb` consecutive bands of one (image, 32-channel chunk): taps are loaded and the tile cleared once.
     extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
-    const int total = nbands * nchunk * B;
+    const int ngrp = (nbands + bpb - 1) / bpb;
+    const int total = ngrp * nchunk * B;
     int u = xcd_unit(total);
     if (u >= total) return;
-    const int rb = u % nbands; u /= nbands;
+    const int bg = u % ngrp; u /= ngrp;
     const int cx = u % nchunk, b = u / nchunk;
-    const int i0 = rb * R, ch0 = cx * TCH;
+    const int ch0 = cx * TCH;
     const TileGeo geo = tile_geo(w, R);
     const int WP = geo.WP, PHp = geo.PHp, C2 = 2 * Hc;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    // ---- stage: one wave instruction = 16 pixel slots x 64 B
-    {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(s, s_bytes);
-        const int ninstr = 2 * PHp / 16;
-        const int k = lane & 3;
-        const int ch = ch0 + k * 8;
-        for (int it = wave; it < ninstr; it += 4) {
-            const int p = it * 16 + (lane >> 2);
-            const int half = p >= PHp ? 1 : 0;
-            const int q = p - half * PHp;
-            const int r = q / WP, cidx = q - r * WP;
-            const int ii = i0 - 1 + r, jj = cidx - 1;
-            const bool ok = r < R + 2 && jj >= 0 && ii >= 0 && ii < h && ch < Hc;
-            const uint32_t voff = ok ? (uint32_t)(((((int64_t)b * h + ii) * w + jj) * C2 + half * Hc + ch) * 2) : YAT_OOB;
-            lds_dma16(rs, (YAT_LDS void*)(tile + it * 1024), voff);
-        }
-    }
-    // ---- per-thread constants while the tile is in flight
-    const int cg = lane & 7;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, nslots = blockDim.x / NCG;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    clear_tile(tile, 2 * PHp * TCH * 2);
+    // ---- per-thread constants
+    const int cg = lane & (NCG - 1);
     const int ca = ch0 + cg * 4, cgl = Hc + ca;
     const bool chan_ok = ca < Hc;
-    float wa[9][4], wg[9][4], ba[4], bg[4];
+    // channel pairs as explicit 2-vectors (see pass 2 below): one v_pk_fma_f32 per (tap, pair) with a fixed pairing
+    f32x2 wa[9][2], wg[9][2], ba[2], bg2[2];
     {
         const int cs = chan_ok ? ca : 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                wa[t][e] = bf2f(wdw[(cs + e) * 9 + t]);
-                wg[t][e] = bf2f(wdw[(Hc + cs + e) * 9 + t]);
-            }
-        }
-        unpack4(*reinterpret_cast<const u32x2*>(bdw + cs), ba);
-        unpack4(*reinterpret_cast<const u32x2*>(bdw + Hc + cs), bg);
-        // opaque to the optimizer: otherwise it keeps the packed words and re-unpacks every weight inside the run loop
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wa[t][e]), "+v"(wg[t][e]));
+        load_taps(wdw, cs, wa);
+        load_taps(wdw, Hc + cs, wg);
+        unpack22(*reinterpret_cast<const u32x2*>(bdw + cs), ba);
+        unpack22(*reinterpret_cast<const u32x2*>(bdw + Hc + cs), bg2);
     }
     const int nseg = (w + SEG - 1) / SEG, nruns = R * nseg;
-    const int slot = wave * 8 + (lane >> 3);
+    const int slot = threadIdx.x / NCG;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(s, s_bytes);
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, MODE == 0 ? s_bytes / 2 : s_bytes);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(MODE == 1 ? dy : s, s_bytes / 2);
+    const bool lane_ch_ok = ch0 + (lane % PPP) * 8 < Hc;
+
+  for (int rb = bg * bpb; rb < min(nbands, (bg + 1) * bpb); ++rb) {
+    const int i0 = rb * R;
+    __syncthreads();                                        // tile cleared / previous band fully consumed
+    stage_rows(rs, tile, 0, R + 2, i0 - 1, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
+    stage_rows(rs, tile, PHp, R + 2, i0 - 1, b, h, w, WP, C2, Hc + ch0, lane_ch_ok, wave_s, nwaves, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int run = slot; run < nruns; run += 32) {
-        const int row = run % R, seg = run / R;             // rows fastest: neighbouring runs sit in different bank groups
+    for (int run = slot; run < nruns; run += nslots) {
+        const int seg = (run * rmagic) >> 16, row = run - seg * R;      // rows fastest: neighbouring runs, other bank group
         const int i = i0 + row;
         if (i >= h || !chan_ok) continue;
         const int j0 = seg * SEG;
@@ -232,11 +271,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void dwglu_tile_kernel(int 
         const unsigned char* pg = pa + PHp * TCH * 2;
         const int64_t pix0 = ((int64_t)b * h + i) * w + j0;
         u32x2 dyv[3];                                       // dy of output o is fetched at step o, used at step o + 2
-        float A[3][4], G[3][4];
+        f32x2 A[3][2], G[3][2];
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { A[m][e] = ba[e]; G[m][e] = bg[e]; }
+            for (int pr = 0; pr < 2; ++pr) { A[m][pr] = ba[pr]; G[m][pr] = bg2[pr]; }
         u32x2 nxt[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -260,17 +299,17 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void dwglu_tile_kernel(int 
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                float za[4], zg[4];
-                unpack4(cur[2 * r], za);
-                unpack4(cur[2 * r + 1], zg);
+                f32x2 za[2], zg[2];
+                unpack22(cur[2 * r], za);
+                unpack22(cur[2 * r + 1], zg);
 #pragma unroll
                 for (int dj = 2; dj >= 0; --dj) {           // output o = t - dj takes tap column dj (same order as above)
                     const int o = t - dj;
                     if (o < 0 || o >= SEG) continue;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        A[o % 3][e] += wa[r * 3 + dj][e] * za[e];
-                        G[o % 3][e] += wg[r * 3 + dj][e] * zg[e];
+                    for (int pr = 0; pr < 2; ++pr) {
+                        A[o % 3][pr] += wa[r * 3 + dj][pr] * za[pr];
+                        G[o % 3][pr] += wg[r * 3 + dj][pr] * zg[pr];
                     }
                 }
             }
@@ -278,46 +317,49 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void dwglu_tile_kernel(int 
             if (o >= 0) {
                 float ua[4], ug[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ua[e] = rbf(A[o % 3][e]); ug[e] = rbf(G[o % 3][e]); A[o % 3][e] = ba[e]; G[o % 3][e] = bg[e]; }
-                const bool live = j0 + o < w;
-                {
-                    if (MODE == 0) {
-                        __builtin_amdgcn_raw_buffer_store_b64(
-                            pack4(ua[0] * rbf(silu_f(ug[0])), ua[1] * rbf(silu_f(ug[1])), ua[2] * rbf(silu_f(ug[2])),
-                                  ua[3] * rbf(silu_f(ug[3]))),
-                            rout, live ? (uint32_t)(((pix0 + o) * Hc + ca) * 2) : YAT_OOB, 0, 0);
-                    } else {
-                        float d[4], da[4], dg[4];
-                        unpack4(dyv[o % 3], d);
+                for (int e = 0; e < 4; ++e) { ua[e] = rbf(A[o % 3][e >> 1][e & 1]); ug[e] = rbf(G[o % 3][e >> 1][e & 1]); }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            da[e] = d[e] * rbf(silu_f(ug[e]));
-                            dg[e] = rbf(d[e] * ua[e]) * dsilu_f(ug[e]);
-                        }
-                        const uint32_t off = live ? (uint32_t)(((pix0 + o) * C2 + ca) * 2) : YAT_OOB;
-                        __builtin_amdgcn_raw_buffer_store_b64(pack4(da[0], da[1], da[2], da[3]), rout, off, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(pack4(dg[0], dg[1], dg[2], dg[3]), rout,
-                                                                  live ? off + (uint32_t)Hc * 2 : YAT_OOB, 0, 0);
+                for (int pr = 0; pr < 2; ++pr) { A[o % 3][pr] = ba[pr]; G[o % 3][pr] = bg2[pr]; }
+                const bool live = j0 + o < w;
+                if (MODE == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        pack4(ua[0] * rbf(silu_f(ug[0])), ua[1] * rbf(silu_f(ug[1])), ua[2] * rbf(silu_f(ug[2])),
+                              ua[3] * rbf(silu_f(ug[3]))),
+                        rout, live ? (uint32_t)(((pix0 + o) * Hc + ca) * 2) : YAT_OOB, 0, 0);
+                } else {
+                    float d[4], da[4], dg[4];
+                    unpack4(dyv[o % 3], d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        da[e] = d[e] * rbf(silu_f(ug[e]));
+                        dg[e] = rbf(d[e] * ua[e]) * dsilu_f(ug[e]);
                     }
+                    const uint32_t off = live ? (uint32_t)(((pix0 + o) * C2 + ca) * 2) : YAT_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4(da[0], da[1], da[2], da[3]), rout, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4(dg[0], dg[1], dg[2], dg[3]), rout,
+                                                          live ? off + (uint32_t)Hc * 2 : YAT_OOB, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);              // keep the unrolled columns from hoisting all their reads
         }
     }
+  }
 }
 
 // rows per band: the largest R whose tile leaves room for three workgroups per CU, weighted by how well R * nseg runs
 // fill the 32 run slots and by the (R+2)/R halo re-read
-inline int pick_band_rows(int h, int w, size_t* lds_bytes) {
+inline int pick_band_rows(int h, int w, size_t* lds_bytes, int* threads) {
     const int nseg = (w + SEG - 1) / SEG;
     int best = 0;
     double best_score = 0;
+    *threads = 256;
+    const int ns = *threads / NCG;
     for (int R = 2; R <= 16 && R <= ((h + 1) & ~1); ++R) {
         const size_t bytes = (size_t)2 * tile_geo(w, R).PHp * TCH * 2;
         if (bytes > 53248) break;
-        const int nruns = R * nseg, passes = (nruns + 31) / 32;
+        const int nruns = R * nseg, passes = (nruns + ns - 1) / ns;
         const int nb = (h + R - 1) / R;
-        const double score = (double)nruns / (passes * 32) * R / (R + 2) * h / (nb * R);
+        const double score = (double)nruns / (passes * ns) * R / (R + 2) * h / (nb * R);
         if (score > best_score) { best_score = score; best = R; }
     }
     if (best) *lds_bytes = (size_t)2 * tile_geo(w, best).PHp * TCH * 2;
@@ -328,13 +370,176 @@ template <int MODE>
 int launch_tile(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
                 bf16_t* out, hipStream_t stream) {
     size_t lds = 0;
-    const int R = pick_band_rows(h, w, &lds);
+    int threads = 256;
+    const int R = pick_band_rows(h, w, &lds, &threads);
     const uint64_t s_bytes = (uint64_t)B * h * w * 2 * Hc * 2;
     if (!R || (Hc & 7) || s_bytes > 0x7fffffffull) return -1;          // caller falls back to the direct kernels
     const int nbands = (h + R - 1) / R, nchunk = (Hc + TCH - 1) / TCH;
-    hipLaunchKernelGGL((dwglu_tile_kernel<MODE>), dim3(grid8((int64_t)nbands * nchunk * B)), dim3(256), lds, stream, h, w,
-                       Hc, B, R, nbands, nchunk, s, s_bytes, wdw, bdw, dy, out);
+    // bands per workgroup: as many as still leave >= 3 rounds of workgroups (3 resident per CU)
+    int bpb = nbands;
+    while (bpb > 1 && (int64_t)((nbands + bpb - 1) / bpb) * nchunk * B < 3 * 768) --bpb;
+    const int ngrp = (nbands + bpb - 1) / bpb;
+    hipLaunchKernelGGL((dwglu_tile_kernel<MODE>), dim3(grid8((int64_t)ngrp * nchunk * B)), dim3(threads), lds, stream, h, w,
+                       Hc, B, R, (65536 + R - 1) / R, nbands, bpb, nchunk, s, s_bytes, wdw, bdw, dy, out);
     return 0;
+}
+
+// LDS-tiled backward pass 2 (same staging scheme; all 2*Hc channels are independent here, 32 per workgroup):
+//   du tile: rows i0-1 .. i0+R (zero outside the image), s and z tiles: rows i0 .. i0+R-1, all with the shared zero column.
+//   dz[i,j] = SiLU'(z[i,j]) * bf16( sum_taps W[tap] du[i-di, j-dj] );  dW[tap] += s[i,j] * du[i-di, j-dj];  db += du[i,j]
+// The thread's dW/db registers are summed over the 32 run slots through the (then free) tile memory: one partial row
+// per workgroup, ws[(b*nbands + band)][2Hc*10].
+__global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, int Hc, int B, int R, int rmagic, int nbands,
+                                                                 int bpb, int nchunk, const bf16_t* sact, const bf16_t* z,
+                                                                 const bf16_t* du, uint64_t bytes, const bf16_t* wdw,
+                                                                 bf16_t* dz, float* ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+    const int ngrp = (nbands + bpb - 1) / bpb;
+    const int total = ngrp * nchunk * B;
+    int u = xcd_unit(total);
+    if (u >= total) return;
+    const int bg = u % ngrp; u /= ngrp;
+    const int cx = u % nchunk, b = u / nchunk;
+    const int ch0 = cx * TCH, C2 = 2 * Hc;
+    const int WP = w + 1;
+    const int PHd = ((R + 2) * WP + 1 + TILE_PAD + 15) & ~15, PHc = (R * WP + 1 + TILE_PAD + 15) & ~15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, nslots = blockDim.x / NCG;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    clear_tile(tile, (PHd + 2 * PHc) * TCH * 2);
+    const int cg = lane & (NCG - 1);
+    const int c0 = ch0 + cg * 4;
+    const bool chan_ok = c0 < C2;
+    // channel pairs as explicit 2-vectors: every multiply-add below is one v_pk_fma_f32 with a fixed register pairing
+    // (left to the SLP vectorizer, taps get paired across different weights and the weight set is kept twice)
+    f32x2 wt[9][2], dW[9][2], db[2];
+    {
+        const int cs = chan_ok ? c0 : 0;
+        load_taps(wdw, cs, wt);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dW[t][0] = dW[t][1] = f32x2{0.f, 0.f};
+        db[0] = db[1] = f32x2{0.f, 0.f};
+    }
+    const int nseg = (w + SEG - 1) / SEG, nruns = R * nseg;
+    const int slot = threadIdx.x / NCG;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(du, bytes), rs = make_rsrc(sact, bytes), rz = make_rsrc(z, bytes);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dz, bytes);
+    const bool lane_ch_ok = ch0 + (lane % PPP) * 8 < C2;
+
+  for (int rb = bg * bpb; rb < min(nbands, (bg + 1) * bpb); ++rb) {
+    const int i0 = rb * R;
+    __syncthreads();
+    stage_rows(rd, tile, 0, R + 2, i0 - 1, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
+    stage_rows(rs, tile, PHd, R, i0, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
+    stage_rows(rz, tile, PHd + PHc, R, i0, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int run = slot; run < nruns; run += nslots) {
+        const int seg = (run * rmagic) >> 16, row = run - seg * R;
+        const int i = i0 + row;
+        if (i >= h || !chan_ok) continue;
+        const int j0 = seg * SEG;
+        const unsigned char* pd = tile + ((row * WP + j0) * TCH + cg * 4) * 2;                 // du rows row .. row+2
+        const unsigned char* ps = tile + ((PHd + row * WP + j0 + 1) * TCH + cg * 4) * 2;       // s at output column j0
+        const unsigned char* pz = ps + PHc * TCH * 2;
+        const int64_t pix0 = ((int64_t)b * h + i) * w + j0;
+        f32x2 acc[3][2], S[3][2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m][0] = acc[m][1] = f32x2{0.f, 0.f};
+        u32x2 nxt[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) nxt[r] = *reinterpret_cast<const u32x2*>(pd + (r * WP) * TCH * 2);
+#pragma unroll
+        for (int t = 0; t < SEG + 2; ++t) {                 // du column j0 - 1 + t
+            u32x2 cur[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cur[r] = nxt[r];
+            if (t + 1 < SEG + 2) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) nxt[r] = *reinterpret_cast<const u32x2*>(pd + (r * WP + t + 1) * TCH * 2);
+            }
+            if (t < SEG) {                                  // s of output column t (zero past the image: it must not count)
+                u32x2 sv = *reinterpret_cast<const u32x2*>(ps + t * TCH * 2);
+                if (j0 + t >= w) sv = u32x2{0u, 0u};
+                unpack22(sv, S[t % 3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                f32x2 d[2];
+                unpack22(cur[r], d);
+                const int tr = (2 - r) * 3;                 // du row i + r - 1 -> tap row 2 - r
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc) {            // output o = t + tc - 2 takes tap column tc
+                    const int o = t + tc - 2;
+                    if (o < 0 || o >= SEG) continue;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        acc[o % 3][pr] += wt[tr + tc][pr] * d[pr];
+                        dW[tr + tc][pr] += S[o % 3][pr] * d[pr];
+                    }
+                }
+                if (r == 1 && t >= 1 && t <= SEG) {         // du[i, j0 + t - 1]: the bias gradient; past the image edge the
+                    const float m = j0 + t - 1 < w ? 1.f : 0.f;                      // tile wraps to real data: mask it
+                    db[0] += m * d[0];
+                    db[1] += m * d[1];
+                }
+            }
+            const int o = t - 2;
+            if (o >= 0) {
+                float zz[4];
+                unpack4(*reinterpret_cast<const u32x2*>(pz + o * TCH * 2), zz);
+                const f32x2 a0 = acc[o % 3][0], a1 = acc[o % 3][1];
+                const u32x2 v = pack4(rbf(a0[0]) * dsilu_f(zz[0]), rbf(a0[1]) * dsilu_f(zz[1]), rbf(a1[0]) * dsilu_f(zz[2]),
+                                      rbf(a1[1]) * dsilu_f(zz[3]));
+                acc[o % 3][0] = acc[o % 3][1] = f32x2{0.f, 0.f};
+                __builtin_amdgcn_raw_buffer_store_b64(v, rout, j0 + o < w ? (uint32_t)(((pix0 + o) * C2 + c0) * 2) : YAT_OOB,
+                                                      0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
+    // ---- sum the run slots through LDS: red[slot][cg*40 + e*10 + k]; one partial row per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(tile);
+    {
+        float* mine = red + slot * (NCG * 40) + cg * 40;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) mine[e * 10 + t] = dW[t][e >> 1][e & 1];
+            mine[e * 10 + 9] = db[e >> 1][e & 1];
+        }
+    }
+    __syncthreads();
+    float* wp = ws + ((int64_t)b * ngrp + bg) * C2 * 10 + (int64_t)ch0 * 10;
+    const int nvalid = min(TCH, C2 - ch0) * 10;
+    for (int idx = threadIdx.x; idx < nvalid; idx += blockDim.x) {
+        float t = 0.f;
+        for (int sl = 0; sl < nslots; ++sl) t += red[sl * (NCG * 40) + idx];
+        wp[idx] = t;
+    }
+}
+
+// tile geometry for pass 2 (R rows per band, two workgroups per CU)
+inline int pick_band_rows_bwd2(int h, int w, size_t* lds_bytes, int* threads) {
+    const int nseg = (w + SEG - 1) / SEG, WP = w + 1;
+    int best = 0;
+    double best_score = 0;
+    *threads = 256;
+    const int ns = *threads / NCG;
+    for (int R = 4; R <= 16 && R <= ((h + 1) & ~1); ++R) {     // >= ROWS: the partial rows fit the workspace
+        const int PHd = ((R + 2) * WP + 1 + TILE_PAD + 15) & ~15, PHc = (R * WP + 1 + TILE_PAD + 15) & ~15;
+        size_t bytes = (size_t)(PHd + 2 * PHc) * TCH * 2;
+        if (bytes < ns * NCG * 40 * sizeof(float)) bytes = ns * NCG * 40 * sizeof(float);
+        if (bytes > 65536) break;
+        const int nruns = R * nseg, passes = (nruns + ns - 1) / ns;
+        const int nb = (h + R - 1) / R;
+        // du is a third of the traffic: its halo re-read weighs a third
+        const double score = (double)nruns / (passes * ns) * (3.0 * R / (3.0 * R + 2.0)) * h / (nb * R);
+        if (score > best_score) { best_score = score; best = R; *lds_bytes = bytes; }
+    }
+    return best;
 }
 
 // backward pass 2.  Block = 64 channel groups (4 channels each, either half) x 4 column segments;
@@ -508,11 +713,28 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
                            (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
                            (const bf16_t*)bdw, (const bf16_t*)dy, du);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dwconv_bwd2_kernel, dim3(grid8((int64_t)nx2 * gy2 * B)), dim3(256), 0, (hipStream_t)stream, h, w,
-                       Hc, nx2, nrg_of(h), B, (const bf16_t*)s, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)du,
-                       (bf16_t*)dz, ws);
+    size_t lds2 = 0;
+    int threads2 = 256;
+    const int R2 = w <= 64 && !(C2 & 7) && du_bytes <= 0x7fffffffull ? pick_band_rows_bwd2(h, w, &lds2, &threads2) : 0;
+    int nparts;
+    if (R2) {
+        const int nbands = (h + R2 - 1) / R2, nchunk = (C2 + TCH - 1) / TCH;
+        int bpb = nbands;
+        while (bpb > 1 && (int64_t)((nbands + bpb - 1) / bpb) * nchunk * B < 4 * 512) --bpb;
+        const int ngrp = (nbands + bpb - 1) / bpb;
+        nparts = B * ngrp;                                     // <= B * nrg_of(h) * nsb_of(w): fits the same workspace
+        hipLaunchKernelGGL(dwglu_bwd2_tile_kernel, dim3(grid8((int64_t)ngrp * nchunk * B)), dim3(threads2), lds2,
+                           (hipStream_t)stream, h, w, Hc, B, R2, (65536 + R2 - 1) / R2, nbands, bpb, nchunk,
+                           (const bf16_t*)s, (const bf16_t*)z,
+                           (const bf16_t*)du, (uint64_t)B * h * w * C2 * 2, (const bf16_t*)wdw, (bf16_t*)dz, ws);
+    } else {
+        nparts = B * gy2;
+        hipLaunchKernelGGL(dwconv_bwd2_kernel, dim3(grid8((int64_t)nx2 * gy2 * B)), dim3(256), 0, (hipStream_t)stream, h,
+                           w, Hc, nx2, nrg_of(h), B, (const bf16_t*)s, (const bf16_t*)z, (const bf16_t*)wdw,
+                           (const bf16_t*)du, (bf16_t*)dz, ws);
+    }
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * 10 + 63) / 64), dim3(256), 0, (hipStream_t)stream, B * gy2, C2,
+    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * 10 + 63) / 64), dim3(256), 0, (hipStream_t)stream, nparts, C2,
                        (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, accumulate);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
