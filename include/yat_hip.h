@@ -132,22 +132,27 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
  * the conv_inverted GEMM (activation = SiLU, aux_out = z), so SiLU is evaluated once per element.
  *   y[b,i,j,c] = u_c * silu(u_{c+Hc}),  u = bias + sum_taps wdw[c, tap] * s[b,i+di,j+dj,c]
  * wdw: bf16 [2*Hc, 9] (diffusers conv_depth.weight [2Hc,1,3,3] flattened), bdw: bf16 [2*Hc].
- * bwd: dz (bf16, includes the SiLU derivative), dwdw / dbdw partial sums reduced via workspace.
+ * bwd: dz (bf16, includes the SiLU derivative), dwdw / dbdw partial sums reduced via workspace;
+ *      dz_colsum_bf16 (nullable, [2Hc]) (+)= sum over pixels of dz: the bias gradient of conv_inverted, taken in the
+ *      same pass instead of a separate yat_colsum_bf16 over dz.
  * ------------------------------------------------------------------------------------------ */
 uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc);
 int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* wdw, const void* bdw, void* y,
                        yat_stream_t stream);
 int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z, const void* wdw, const void* bdw,
-                       const void* dy, void* dz, void* dwdw_bf16, void* dbdw_bf16, int accumulate, void* workspace,
-                       yat_stream_t stream);
+                       const void* dy, void* dz, void* dwdw_bf16, void* dbdw_bf16, void* dz_colsum_bf16, int accumulate,
+                       void* workspace, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * gated residual backward: out = res + bf16(gate[b,:] * lin)   (patch_sana_attention_layers.py:95,113)
  *   dlin = bf16(gate * dout);  dgate_acc[b,:] += sum_n dout * lin   (fp32)
+ *   dbias_bf16 (nullable): (+)= sum_rows dlin -- the bias gradient of the Linear that produced `lin`
+ *   (attn1.to_out.0), taken in the same pass instead of a separate yat_colsum_bf16 over dlin.
  * ------------------------------------------------------------------------------------------ */
 uint64_t yat_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
 int yat_gate_bwd(int M, int D, int rows_per_batch, const void* dout, const void* lin, const void* gate, int gate_ld,
-                 void* dlin, float* dgate_acc, int acc_ld, void* workspace, yat_stream_t stream);
+                 void* dlin, float* dgate_acc, int acc_ld, void* dbias_bf16, int accumulate_bias, void* workspace,
+                 yat_stream_t stream);
 
 /* elementwise helpers: y = act(x) and dx = dy * act'(x) on bf16 (time-embed / caption MLPs);
  * act: 1 SiLU, 2 GELU(tanh).  add: out = bf16(a + b).  f32->bf16 convert. */

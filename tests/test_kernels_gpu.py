@@ -339,6 +339,18 @@ def test_gate_bwd(ops):
     ops.gate_bwd(dout, lin, gate, 6 * D, n, dlin, acc[:, 5], 6 * D, ws)
     close(dlin, (gate.float().repeat_interleave(n, 0) * dout.float()).to(BF), "gate_bwd_dlin")
     close(acc[:, 5], rb(dout.float() * lin.float()).view(B, n, D).sum(1), "gate_bwd_dgate", atol=1e-2)
+    # fused bias gradient of the gated Linear = column sum of dlin (same pass), plain and accumulating
+    dlin2, acc2 = torch.empty_like(dlin), torch.zeros_like(acc)
+    dbias = torch.empty(D, dtype=BF, device=DEV)
+    ops.gate_bwd(dout, lin, gate, 6 * D, n, dlin2, acc2[:, 5], 6 * D, ws, dbias=dbias)
+    assert torch.equal(dlin2, dlin) and torch.equal(acc2, acc)
+    want = dlin.float().sum(0)
+    close(dbias, want.to(BF), "gate_bwd_dbias", atol=1e-2)
+    ref_cs = torch.empty(D, dtype=BF, device=DEV)
+    ops.colsum(dlin, ref_cs, torch.empty(int(ops._lib().yat_colsum_workspace_bytes(M, D)), dtype=torch.uint8, device=DEV))
+    close(dbias, ref_cs, "gate_bwd_dbias_vs_colsum", atol=1e-2)
+    ops.gate_bwd(dout, lin, gate, 6 * D, n, dlin2, acc2[:, 5], 6 * D, ws, dbias=dbias, accumulate_bias=True)
+    close(dbias, (2 * want).to(BF), "gate_bwd_dbias_acc", tol=1e-2, atol=2e-2)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -437,7 +449,9 @@ def _glu_ref(z, wdw, bdw, B, h, w, Hc):
     return y.permute(0, 2, 3, 1).reshape(B * h * w, Hc)
 
 
-@pytest.mark.parametrize("B,h,w,Hc", [(2, 4, 4, 16), (2, 5, 9, 40), (1, 16, 64, 160), (2, 33, 3, 8)])
+# the last two cases take the direct (non-tiled) kernels: w > 64, and a channel count that is not a multiple of 8
+@pytest.mark.parametrize("B,h,w,Hc", [(2, 4, 4, 16), (2, 5, 9, 40), (1, 16, 64, 160), (2, 33, 3, 8), (2, 32, 32, 72),
+                                      (1, 3, 70, 8), (1, 6, 5, 12)])
 def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     M = B * h * w
     z = rnd(M, 2 * Hc, seed=37)
@@ -464,6 +478,12 @@ def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     as_good_as(dz, flow[0], truth[0], f"dwconv_dz {h}x{w}x{Hc}", tol_flow=1e-2)
     as_good_as(dw, flow[1], truth[1], f"dwconv_dw {h}x{w}x{Hc}", tol_flow=1e-2)
     as_good_as(db, flow[2], truth[2], f"dwconv_db {h}x{w}x{Hc}", tol_flow=1e-2)
+    # fused conv_inverted bias gradient: column sum of the dz the kernel itself wrote
+    dz2, dw2, db2 = torch.empty_like(z), torch.empty_like(wdw), torch.empty_like(bdw)
+    dzs = torch.empty(2 * Hc, dtype=BF, device=DEV)
+    ops.dwconv_glu_bwd(s_act, z, B, h, w, Hc, wdw, bdw, dy, dz2, dw2, db2, ws, dz_colsum=dzs)
+    assert torch.equal(dz2, dz) and torch.equal(dw2, dw) and torch.equal(db2, db)
+    close(dzs, dz.float().sum(0).to(BF), f"dwconv_dz_colsum {h}x{w}x{Hc}", atol=1e-2)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise / recipe

@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int SEG = 8;      // output columns per thread
+constexpr int PK = 11;      // partial values per channel: 9 taps, conv bias, column sum of dz
 constexpr int ROWS = 4;     // rows per thread in backward pass 2
 
 struct Col6 { u32x2 v[6]; };   // rows (i-1, i, i+1) x (half a, half g), packed bf16x4
@@ -411,13 +412,13 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
     const bool chan_ok = c0 < C2;
     // channel pairs as explicit 2-vectors: every multiply-add below is one v_pk_fma_f32 with a fixed register pairing
     // (left to the SLP vectorizer, taps get paired across different weights and the weight set is kept twice)
-    f32x2 wt[9][2], dW[9][2], db[2];
+    f32x2 wt[9][2], dW[9][2], db[2], dzs[2];                 // dzs: column sum of dz = bias gradient of conv_inverted
     {
         const int cs = chan_ok ? c0 : 0;
         load_taps(wdw, cs, wt);
 #pragma unroll
         for (int t = 0; t < 9; ++t) dW[t][0] = dW[t][1] = f32x2{0.f, 0.f};
-        db[0] = db[1] = f32x2{0.f, 0.f};
+        db[0] = db[1] = dzs[0] = dzs[1] = f32x2{0.f, 0.f};
     }
     const int nseg = (w + SEG - 1) / SEG, nruns = R * nseg;
     const int slot = threadIdx.x / NCG;
@@ -492,31 +493,36 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
                 const u32x2 v = pack4(rbf(a0[0]) * dsilu_f(zz[0]), rbf(a0[1]) * dsilu_f(zz[1]), rbf(a1[0]) * dsilu_f(zz[2]),
                                       rbf(a1[1]) * dsilu_f(zz[3]));
                 acc[o % 3][0] = acc[o % 3][1] = f32x2{0.f, 0.f};
-                __builtin_amdgcn_raw_buffer_store_b64(v, rout, j0 + o < w ? (uint32_t)(((pix0 + o) * C2 + c0) * 2) : YAT_OOB,
-                                                      0, 0);
+                const bool live = j0 + o < w;
+                f32x2 vz[2];
+                unpack22(live ? v : u32x2{0u, 0u}, vz);     // the rounded values, as a later column sum over dz would see them
+                dzs[0] += vz[0];
+                dzs[1] += vz[1];
+                __builtin_amdgcn_raw_buffer_store_b64(v, rout, live ? (uint32_t)(((pix0 + o) * C2 + c0) * 2) : YAT_OOB, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
   }
-    // ---- sum the run slots through LDS: red[slot][cg*40 + e*10 + k]; one partial row per workgroup
+    // ---- sum the run slots through LDS: red[slot][cg*4*PK + e*PK + k]; one partial row per workgroup
     __syncthreads();
     float* red = reinterpret_cast<float*>(tile);
     {
-        float* mine = red + slot * (NCG * 40) + cg * 40;
+        float* mine = red + slot * (NCG * 4 * PK) + cg * 4 * PK;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) mine[e * 10 + t] = dW[t][e >> 1][e & 1];
-            mine[e * 10 + 9] = db[e >> 1][e & 1];
+            for (int t = 0; t < 9; ++t) mine[e * PK + t] = dW[t][e >> 1][e & 1];
+            mine[e * PK + 9] = db[e >> 1][e & 1];
+            mine[e * PK + 10] = dzs[e >> 1][e & 1];
         }
     }
     __syncthreads();
-    float* wp = ws + ((int64_t)b * ngrp + bg) * C2 * 10 + (int64_t)ch0 * 10;
-    const int nvalid = min(TCH, C2 - ch0) * 10;
+    float* wp = ws + ((int64_t)b * ngrp + bg) * C2 * PK + (int64_t)ch0 * PK;
+    const int nvalid = min(TCH, C2 - ch0) * PK;
     for (int idx = threadIdx.x; idx < nvalid; idx += blockDim.x) {
         float t = 0.f;
-        for (int sl = 0; sl < nslots; ++sl) t += red[sl * (NCG * 40) + idx];
+        for (int sl = 0; sl < nslots; ++sl) t += red[sl * (NCG * 4 * PK) + idx];
         wp[idx] = t;
     }
 }
@@ -531,7 +537,7 @@ inline int pick_band_rows_bwd2(int h, int w, size_t* lds_bytes, int* threads) {
     for (int R = 4; R <= 16 && R <= ((h + 1) & ~1); ++R) {     // >= ROWS: the partial rows fit the workspace
         const int PHd = ((R + 2) * WP + 1 + TILE_PAD + 15) & ~15, PHc = (R * WP + 1 + TILE_PAD + 15) & ~15;
         size_t bytes = (size_t)(PHd + 2 * PHc) * TCH * 2;
-        if (bytes < ns * NCG * 40 * sizeof(float)) bytes = ns * NCG * 40 * sizeof(float);
+        if (bytes < ns * NCG * 4 * PK * sizeof(float)) bytes = ns * NCG * 4 * PK * sizeof(float);
         if (bytes > 65536) break;
         const int nruns = R * nseg, passes = (nruns + ns - 1) / ns;
         const int nb = (h + R - 1) / R;
@@ -549,7 +555,7 @@ inline int pick_band_rows_bwd2(int h, int w, size_t* lds_bytes, int* threads) {
 // partials: ws[((b*nrg + rg)*nsb + sb)][2Hc*10]  (10 = 9 taps + bias per channel)
 __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, int nx, int nrg, int B, const bf16_t* sact, const bf16_t* z,
                                                           const bf16_t* wdw, const bf16_t* du, bf16_t* dz, float* ws) {
-    __shared__ float red[4][64][41];
+    __shared__ float red[4][64][4 * PK + 1];
     const int C2 = 2 * Hc;
     const int lg = threadIdx.x & 63, lseg = threadIdx.x >> 6;
     const int nsb = (w + 4 * SEG - 1) / (4 * SEG);           // segment-blocks per row
@@ -637,30 +643,33 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) red[lseg][lg][e * 10 + t] = dW[t][e];
-        red[lseg][lg][e * 10 + 9] = db[e];
+        for (int t = 0; t < 9; ++t) red[lseg][lg][e * PK + t] = dW[t][e];
+        red[lseg][lg][e * PK + 9] = db[e];
+        red[lseg][lg][e * PK + 10] = 0.f;                    // dz column sum: taken by a separate pass on this path
     }
     __syncthreads();
     if (lseg == 0 && active) {
-        float* wp = ws + (((int64_t)b * nrg * nsb + rg * nsb + sb)) * C2 * 10 + (int64_t)c0 * 10;
+        float* wp = ws + (((int64_t)b * nrg * nsb + rg * nsb + sb)) * C2 * PK + (int64_t)c0 * PK;
 #pragma unroll
-        for (int k = 0; k < 40; ++k) wp[k] = red[0][lg][k] + red[1][lg][k] + red[2][lg][k] + red[3][lg][k];
+        for (int k = 0; k < 4 * PK; ++k) wp[k] = red[0][lg][k] + red[1][lg][k] + red[2][lg][k] + red[3][lg][k];
     }
 }
 
-__global__ void dwconv_reduce_kernel(int P, int C2, const float* ws, bf16_t* dw, bf16_t* dbias, int accumulate) {
+__global__ void dwconv_reduce_kernel(int P, int C2, const float* ws, bf16_t* dw, bf16_t* dbias, bf16_t* dzsum,
+                                     int accumulate) {
     __shared__ float red[4][64];
-    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);    // over C2*10
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);    // over C2*PK
     const int part = threadIdx.x >> 6;
     float s = 0.f;
-    if (idx < C2 * 10)
-        for (int p = part; p < P; p += 4) s += ws[(int64_t)p * C2 * 10 + idx];
+    if (idx < C2 * PK)
+        for (int p = part; p < P; p += 4) s += ws[(int64_t)p * C2 * PK + idx];
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
-    if (part != 0 || idx >= C2 * 10) return;
+    if (part != 0 || idx >= C2 * PK) return;
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    const int ch = idx / 10, t = idx % 10;
-    bf16_t* dst = t < 9 ? dw + ch * 9 + t : dbias + ch;
+    const int ch = idx / PK, t = idx % PK;
+    bf16_t* dst = t < 9 ? dw + ch * 9 + t : (t == 9 ? dbias + ch : (dzsum ? dzsum + ch : nullptr));
+    if (!dst) return;
     if (accumulate) s = rbf(s) + bf2f(*dst);
     *dst = f2bf(s);
 }
@@ -691,11 +700,11 @@ int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* w
 uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc) {
     // du (bf16 [B,h,w,2Hc]) followed by the fp32 partials
     const uint64_t du_bytes = ((uint64_t)B * h * w * 2 * Hc * 2 + 255) & ~255ull;
-    return du_bytes + (uint64_t)B * nrg_of(h) * nsb_of(w) * 2 * Hc * 10 * sizeof(float);
+    return du_bytes + (uint64_t)B * nrg_of(h) * nsb_of(w) * 2 * Hc * PK * sizeof(float);
 }
 
 int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z, const void* wdw, const void* bdw,
-                       const void* dy, void* dz, void* dwdw, void* dbdw, int accumulate, void* workspace,
+                       const void* dy, void* dz, void* dwdw, void* dbdw, void* dz_colsum, int accumulate, void* workspace,
                        yat_stream_t stream) {
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !s || !z || !wdw || !bdw || !dy || !dz || !dwdw || !dbdw ||
         !workspace)
@@ -734,9 +743,11 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
                            (const bf16_t*)du, (bf16_t*)dz, ws);
     }
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * 10 + 63) / 64), dim3(256), 0, (hipStream_t)stream, nparts, C2,
-                       (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, accumulate);
+    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * PK + 63) / 64), dim3(256), 0, (hipStream_t)stream, nparts, C2,
+                       (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, R2 ? (bf16_t*)dz_colsum : (bf16_t*)nullptr, accumulate);
     YAT_CHECK_LAUNCH();
+    if (dz_colsum && !R2)                                     // direct path: the column sum of dz is its own pass
+        return yat_colsum_bf16(B * h * w, C2, dz, C2, dz_colsum, accumulate, ws, stream);
     return YAT_OK;
 }
 

@@ -296,18 +296,20 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int M, int D, const bf
 
 // ------------------------------------------------------------------ strip kernels (512 columns x 32 rows per wave)
 constexpr int STRIP_ROWS = 32;
-// MODE 0: column sum of x.  MODE 1: gate backward: dlin = bf16(gate*dout), partial = dout*lin
+// MODE 0: column sum of x.  MODE 1: gate backward: dlin = bf16(gate*dout), partial = dout*lin, and (ws2 != null) the
+// column sum of dlin, i.e. the bias gradient of the gated Linear, for free.
+// The four waves of a workgroup are summed in LDS: one partial row per workgroup (the follow-up reduction reads 4x less).
 template <int MODE>
 __global__ __launch_bounds__(256) void strip_kernel(int rows_per_batch, int cols, const bf16_t* x, int ld,
                                                     const bf16_t* lin, const bf16_t* gate, int gate_ld, bf16_t* dlin,
-                                                    float* ws) {
+                                                    float* ws, float* ws2) {
     // grid = (ceil(cols/512), ceil(rpb / 128), B)
+    __shared__ float red[(MODE == 1 ? 2 : 1) * WAVES * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 512 + lane * 8;
     const int b = blockIdx.z;
     const int rg = blockIdx.y * WAVES + wave;                 // row group within the batch
-    const int ngroups = gridDim.y * WAVES;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float g[8];
     if (MODE == 1 && c0 < cols) unpack8(*reinterpret_cast<const u32x4*>(gate + (int64_t)b * gate_ld + c0), g);
     if (c0 < cols) {
@@ -324,13 +326,26 @@ __global__ __launch_bounds__(256) void strip_kernel(int rows_per_batch, int cols
                 float l[8], o[8];
                 unpack8(*reinterpret_cast<const u32x4*>(lin + row * ld + c0), l);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { acc[e] += rbf(a[e] * l[e]); o[e] = g[e] * a[e]; }
+                for (int e = 0; e < 8; ++e) { acc[e] += rbf(a[e] * l[e]); o[e] = rbf(g[e] * a[e]); acc2[e] += o[e]; }
                 *reinterpret_cast<u32x4*>(dlin + row * ld + c0) = pack8(o);
             }
         }
-        float* wp = ws + ((int64_t)b * ngroups + rg) * cols + c0;
-        *reinterpret_cast<f32x4*>(wp) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-        *reinterpret_cast<f32x4*>(wp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[wave * 512 + lane * 8 + e] = acc[e];
+        if (MODE == 1) red[(WAVES + wave) * 512 + lane * 8 + e] = acc2[e];
+    }
+    __syncthreads();
+    // 256 threads x 2 columns
+    const int part = (int)(gridDim.y * blockIdx.z + blockIdx.y);     // partial row: (batch, row block)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int cl = threadIdx.x + 256 * k, c = blockIdx.x * 512 + cl;
+        if (c >= cols) continue;
+        ws[(int64_t)part * cols + c] = red[cl] + red[512 + cl] + red[1024 + cl] + red[1536 + cl];
+        if (MODE == 1 && ws2)
+            ws2[(int64_t)part * cols + c] = red[2048 + cl] + red[2560 + cl] + red[3072 + cl] + red[3584 + cl];
     }
 }
 
@@ -465,7 +480,7 @@ int yat_rmsnorm_bwd(int M, int D, const void* x, const void* w, const float* rst
 
 uint64_t yat_colsum_workspace_bytes(int rows, int cols) {
     const int gy = (rows + WAVES * STRIP_ROWS - 1) / (WAVES * STRIP_ROWS);
-    return (uint64_t)gy * WAVES * cols * sizeof(float);
+    return (uint64_t)gy * cols * sizeof(float);
 }
 
 int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out, int accumulate, void* workspace,
@@ -474,10 +489,10 @@ int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out, int ac
     const int gy = (rows + WAVES * STRIP_ROWS - 1) / (WAVES * STRIP_ROWS);
     hipLaunchKernelGGL((strip_kernel<0>), dim3((cols + 511) / 512, gy, 1), dim3(256), 0, (hipStream_t)stream, rows, cols,
                        (const bf16_t*)x, ld, (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr,
-                       (float*)workspace);
+                       (float*)workspace, (float*)nullptr);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       gy * WAVES, cols, (const float*)workspace, (bf16_t*)out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, gy, cols,
+                       (const float*)workspace, (bf16_t*)out, accumulate);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
@@ -485,23 +500,29 @@ int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out, int ac
 uint64_t yat_gate_bwd_workspace_bytes(int M, int D, int rpb) {
     if (M <= 0 || rpb <= 0) return 0;
     const uint64_t gy = (rpb + WAVES * STRIP_ROWS - 1) / (WAVES * STRIP_ROWS);
-    return (uint64_t)(M / rpb) * gy * WAVES * D * sizeof(float);
+    return 2 * (uint64_t)(M / rpb) * gy * D * sizeof(float);        // gate partials + bias-gradient partials
 }
 
 int yat_gate_bwd(int M, int D, int rpb, const void* dout, const void* lin, const void* gate, int gate_ld, void* dlin,
-                 float* dgate_acc, int acc_ld, void* workspace, yat_stream_t stream) {
+                 float* dgate_acc, int acc_ld, void* dbias, int accumulate_bias, void* workspace, yat_stream_t stream) {
     if (M <= 0 || rpb <= 0 || M % rpb || (D & 7) || (gate_ld & 7) || !dout || !lin || !gate || !dlin || !dgate_acc ||
         !workspace)
         return YAT_EINVAL;
     const int B = M / rpb;
     const int gy = (rpb + WAVES * STRIP_ROWS - 1) / (WAVES * STRIP_ROWS);
+    float* ws2 = dbias ? (float*)workspace + (int64_t)B * gy * D : nullptr;
     hipLaunchKernelGGL((strip_kernel<1>), dim3((D + 511) / 512, gy, B), dim3(256), 0, (hipStream_t)stream, rpb, D,
                        (const bf16_t*)dout, D, (const bf16_t*)lin, (const bf16_t*)gate, gate_ld, (bf16_t*)dlin,
-                       (float*)workspace);
+                       (float*)workspace, ws2);
     YAT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, B,
-                       gy * WAVES, D, (const float*)workspace, dgate_acc, (float*)nullptr, D, acc_ld);
+    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, B, gy, D,
+                       (const float*)workspace, dgate_acc, (float*)nullptr, D, acc_ld);
     YAT_CHECK_LAUNCH();
+    if (dbias) {                                              // bias gradient of the gated Linear = column sum of dlin
+        hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, B * gy, D,
+                           (const float*)ws2, (bf16_t*)dbias, accumulate_bias);
+        YAT_CHECK_LAUNCH();
+    }
     return YAT_OK;
 }
 

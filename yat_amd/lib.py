@@ -42,9 +42,9 @@ SIGNATURES = {
     "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P, I, P]),
     "yat_dwconv_glu_bwd_workspace_bytes": (U64, [I, I, I, I]),
     "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P]),
-    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, I, P, P]),
+    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, I, P, P]),
     "yat_gate_bwd_workspace_bytes": (U64, [I, I, I]),
-    "yat_gate_bwd": (I, [I, I, I, P, P, P, I, P, P, I, P, P]),
+    "yat_gate_bwd": (I, [I, I, I, P, P, P, I, P, P, I, P, I, P, P]),
     "yat_act_fwd": (I, [I64, I, P, P, P]),
     "yat_act_bwd": (I, [I64, I, P, P, P, P]),
     "yat_add_bf16": (I, [I64, P, P, P, P]),

@@ -174,10 +174,12 @@ def rmsnorm_bwd(x2d, w, rstd, dy, dx, dw, workspace, accumulate_dw=False):
     _l.check(rc, "yat_rmsnorm_bwd")
 
 
-def gate_bwd(dout, lin, gate, gate_ld, rows_per_batch, dlin, dgate_acc, acc_ld, workspace):
+def gate_bwd(dout, lin, gate, gate_ld, rows_per_batch, dlin, dgate_acc, acc_ld, workspace, dbias=None,
+             accumulate_bias=False):
+    """dlin = gate * dout, dgate += sum dout * lin; ``dbias`` (optional) (+)= column sum of dlin in the same pass."""
     M, D = dout.shape
     rc = _lib().yat_gate_bwd(M, D, rows_per_batch, _p(dout), _p(lin), _p(gate), gate_ld, _p(dlin), _p(dgate_acc), acc_ld,
-                             _p(workspace), _stream())
+                             _p(dbias), int(accumulate_bias), _p(workspace), _stream())
     _l.check(rc, "yat_gate_bwd")
 
 
@@ -236,9 +238,10 @@ def dwconv_glu_bwd_workspace_bytes(B, h, w, Hc):
     return int(_lib().yat_dwconv_glu_bwd_workspace_bytes(B, h, w, Hc))
 
 
-def dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False):
+def dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False, dz_colsum=None):
+    """``dz_colsum`` (optional, [2Hc]) (+)= column sum of dz (the conv_inverted bias gradient) in the same pass."""
     rc = _lib().yat_dwconv_glu_bwd(B, h, w, Hc, _p(s), _p(z), _p(wdw), _p(bdw), _p(dy), _p(dz), _p(dwdw), _p(dbdw),
-                                   int(accumulate), _p(workspace), _stream())
+                                   _p(dz_colsum), int(accumulate), _p(workspace), _stream())
     _l.check(rc, "yat_dwconv_glu_bwd")
 
 

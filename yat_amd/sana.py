@@ -495,8 +495,9 @@ class SanaTransformer2DModelHIP(nn.Module):
             writes(dz)
             ops.dwconv_glu_bwd(A.s, A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
-                               G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc)
-            wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D), pre + "ff.conv_inverted.bias")
+                               G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
+                               dz_colsum=G[pre + "ff.conv_inverted.bias"])                # bias gradient in the same pass
+            wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D))
             dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf("dh", (M, D)))
             other = dxb if dx is dxa else dxa
             writes(other)
@@ -525,8 +526,9 @@ class SanaTransformer2DModelHIP(nn.Module):
             on_side(dkv2, kv_grads)
             # x1 = x + gate_msa * lin1
             writes(dlin)
-            ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate)
-            wgrad(dlin, A.attn, pre + "attn1.to_out.0.weight", (D, D), pre + "attn1.to_out.0.bias")
+            ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate,
+                         dbias=G[pre + "attn1.to_out.0.bias"], accumulate_bias=acc)       # bias gradient in the same pass
+            wgrad(dlin, A.attn, pre + "attn1.to_out.0.weight", (D, D))
             dattn = ops.linear_dgrad(dlin, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf("dqkv", (M, 3 * D))
             writes(dqkv)
