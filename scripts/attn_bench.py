@@ -30,7 +30,8 @@ for name, lens in (("all64", [64] * B), ("all160", [160] * B), ("all512", [512] 
     kvl = torch.tensor(lens, dtype=torch.int32, device=dev)
     sc = 1 / math.sqrt(dh)
     f = timeit(lambda: ops.sdpa_fwd(q, kv[:, :D], kv[:, D:], B, N, T, H, dh, sc, bias, kvl, out, lse))
-    b_ = timeit(lambda: ops.sdpa_bwd(q, kv[:, :D], kv[:, D:], B, N, T, H, dh, sc, bias, kvl, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:]))
+    work = ops.kv_work_list(lens, T, dev)
+    b_ = timeit(lambda: ops.sdpa_bwd(q, kv[:, :D], kv[:, D:], B, N, T, H, dh, sc, bias, kvl, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:], work=work))
     tiles = sum((L + 63) // 64 for L in lens)
     print(f"sdpa {name:8s} key-tiles={tiles:3d}  fwd={f:7.1f}us  bwd(dq+dkv)={b_:7.1f}us", flush=True)
 H1, D1 = 70, 2240

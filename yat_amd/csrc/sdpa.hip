@@ -47,6 +47,13 @@ __device__ __forceinline__ bf16x8 frag_row(const char* lds, int row0, int ks, in
     const uint32_t c = (ks * 4 + (lane >> 4)) ^ (r & 15);
     return lds_read8(lds, r * 256 + c * 16);
 }
+// same fragment from a TR-swizzled image (chunk ^ ((r&7)<<1)): the eight rows a ds_read_b128 serves together still land in
+// eight distinct 16-byte bank groups, so one K image can feed both Q K^T (this) and dS K (frag_tr_acc)
+__device__ __forceinline__ bf16x8 frag_row_tr(const char* lds, int row0, int ks, int lane) {
+    const uint32_t r = row0 + (lane & 15);
+    const uint32_t c = (ks * 4 + (lane >> 4)) ^ ((r & 7) << 1);
+    return lds_read8(lds, r * 256 + c * 16);
+}
 // operand fragment in ACCUMULATOR k order from a TR image: idx = col0 + (lane&15);
 // k slot (g, j): row = krow0 + 4g + j (j < 4), krow0 + 16 + 4g + (j - 4) (j >= 4)
 __device__ __forceinline__ bf16x8 frag_tr_acc(const char* lds, int krow0, int col0, int lane) {
@@ -91,14 +98,17 @@ struct SdpaP {
     const bf16_t* dout; int lddo; float* delta; bf16_t* dq; int lddq; bf16_t* dk; bf16_t* dv; int lddkv;
     uint64_t q_bytes, kv_bytes, do_bytes;
     uint64_t stat_bytes;             // bytes of the lse / delta arrays (B*H*N*4)
+    uint64_t bias_bytes;             // bytes of the key-bias array (B*T*4)
     const int* work; int n_work;     // dK/dV kernel: compact list of (batch, key tile) pairs, or null for the dense grid
 };
 
 // ------------------------------------------------------------------------------------------ forward
+// One stage = K (ROW image) + V (TR image) + the 64 key-bias floats.  Two stages in LDS: tile t+1 (and its bias, by
+// 4-byte LDS-DMA -- an ordinary global load inside the loop would drain the DMAs with its vmcnt(0)) is in flight while
+// tile t is consumed, one barrier per tile.  With ~3 live key tiles per image the loop is latency, not MFMA, bound.
+constexpr int FWD_STAGE = 2 * TILE + 256;
 __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;            // ROW image
-    char* Vs = smem + TILE;     // TR image
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -107,6 +117,18 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
+
+    auto stage = [&](int k0, char* base) {
+        stage64x128<IMG_ROW>(rk, base, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rv, base + TILE, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
+        if (wave == 0) {
+            const int key = k0 + lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
+                                                     key < p.T ? (uint32_t)(((int64_t)b * p.T + key) * 4) : YAT_OOB, 0, 0, 0);
+        }
+    };
+    stage(0, smem);
 
     bf16x8 qf[4];
 #pragma unroll
@@ -118,12 +140,15 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -1e30f, l = 0.f;
 
-    for (int k0 = 0; k0 < klim; k0 += 64) {
-        __syncthreads();
-        stage64x128<IMG_ROW>(rk, Ks, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rv, Vs, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
+    int it = 0;
+    for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
+        char* cur = smem + (it & 1) * FWD_STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                                       // tile `it` landed for every wave; stage (it+1)&1 is free
+        if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * FWD_STAGE);
+        const char* Ks = cur;
+        const char* Vs = cur + TILE;
+        const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
 
         f32x4 s[4];
 #pragma unroll
@@ -134,14 +159,16 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
         }
         float mx = -1e30f;
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj)
+        for (int nj = 0; nj < 4; ++nj) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + nj * 16 + 4 * g + r;
-                float v = key < p.T ? s[nj][r] * p.scale + p.bias[(int64_t)b * p.T + key] : -1e30f;
+                float v = key < p.T ? s[nj][r] * p.scale + bv[r] : -1e30f;
                 s[nj][r] = v;
                 mx = fmaxf(mx, v);
             }
+        }
         mx = group_max(mx);
         const float mn = fmaxf(m, mx);
         const float alpha = __expf(m - mn);
@@ -180,11 +207,11 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
+// Stage = K (TR-swizzled image: read row-wise for S = Q K^T and transposed for dQ = dS K), V (ROW image), key bias.
+// Two stages, one barrier per key tile, as in the forward.
+constexpr int DQ_STAGE = 2 * TILE + 256;
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;              // ROW image of K
-    char* Vs = smem + TILE;       // ROW image of V
-    char* Kt = smem + 2 * TILE;   // TR image of K
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -193,8 +220,21 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
     const int64_t qrow = (int64_t)b * p.N + q0 + li, qlim = (int64_t)b * p.N + p.N;
     const int qi = q0 + li;
+
+    auto stage = [&](int k0, char* base) {
+        const int64_t r0 = (int64_t)b * p.T + k0, rl = (int64_t)b * p.T + p.T;
+        stage64x128<IMG_TR>(rk, base, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_ROW>(rv, base + TILE, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+        if (wave == 0) {
+            const int key = k0 + lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
+                                                     key < p.T ? (uint32_t)(((int64_t)b * p.T + key) * 4) : YAT_OOB, 0, 0, 0);
+        }
+    };
+    stage(0, smem);
 
     bf16x8 qf[4], dof[4];
     float dl = 0.f;
@@ -214,14 +254,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < klim; k0 += 64) {
-        __syncthreads();
-        const int64_t r0 = (int64_t)b * p.T + k0, rl = (int64_t)b * p.T + p.T;
-        stage64x128<IMG_ROW>(rk, Ks, r0, rl, p.ldkv, col0, p.dh, wave, lane);
-        stage64x128<IMG_ROW>(rv, Vs, r0, rl, p.ldkv, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rk, Kt, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+    int it = 0;
+    for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
+        char* cur = smem + (it & 1) * DQ_STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * DQ_STAGE);
+        const char* Kt = cur;
+        const char* Vs = cur + TILE;
+        const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
 
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -230,19 +271,21 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
             dp[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s[nj] = mfma16(frag_row(Ks, nj * 16, ks, lane), qf[ks], s[nj]);
+                s[nj] = mfma16(frag_row_tr(Kt, nj * 16, ks, lane), qf[ks], s[nj]);
                 dp[nj] = mfma16(frag_row(Vs, nj * 16, ks, lane), dof[ks], dp[nj]);
             }
         }
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj)
+        for (int nj = 0; nj < 4; ++nj) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + nj * 16 + 4 * g + r;
                 float pr = 0.f;
-                if (key < p.T) pr = __expf(s[nj][r] * p.scale + p.bias[(int64_t)b * p.T + key] - lse);
+                if (key < p.T) pr = __expf(s[nj][r] * p.scale + bv[r] - lse);
                 s[nj][r] = pr * (dp[nj][r] - dl);   // dS (w.r.t. the scaled logits)
             }
+        }
         const bf16x8 f0 = acc_to_frag(s[0], s[1]), f1 = acc_to_frag(s[2], s[3]);
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
@@ -391,7 +434,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     }
 }
 
-constexpr int FWD_LDS = 2 * TILE, DQ_LDS = 3 * TILE, DKV_LDS = 2 * (4 * TILE + 512);
+constexpr int FWD_LDS = 2 * FWD_STAGE, DQ_LDS = 2 * DQ_STAGE, DKV_LDS = 2 * (4 * TILE + 512);
 
 int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv) {
     if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7)) return YAT_EINVAL;
@@ -406,11 +449,17 @@ extern "C" {
 int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream) {
     if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 3) || !q || !k || !v || !key_bias || !out) return YAT_EINVAL;
+    static bool fwd_attr_set = false;
+    if (!fwd_attr_set) {
+        if (hipFuncSetAttribute((const void*)sdpa_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
+            return YAT_EINVAL;
+        fwd_attr_set = true;
+    }
     SdpaP p{};
     p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
     p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = lse;
-    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2;
+    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
     hipLaunchKernelGGL(sdpa_fwd_kernel, dim3((N + 63) / 64, H, B), dim3(256), FWD_LDS, (hipStream_t)stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
@@ -427,7 +476,9 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) !=
-            hipSuccess)
+                hipSuccess ||
+            hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS) !=
+                hipSuccess)
             return YAT_EINVAL;
         attr_set = true;
     }
@@ -438,6 +489,7 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.dout = (const bf16_t*)dout; p.lddo = lddo; p.delta = delta; p.dq = (bf16_t*)dq; p.lddq = lddq;
     p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lddkv = lddkv;
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
+    p.bias_bytes = (uint64_t)B * T * 4;
     p.stat_bytes = (uint64_t)B * H * N * 4;
     hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), DQ_LDS, (hipStream_t)stream, p);
     YAT_CHECK_LAUNCH();
