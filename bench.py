@@ -206,6 +206,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The step runs on a high-priority stream: the side streams (weight gradients, AdamW) keep priority 0, so the
+    # dependent chain gets the CUs first whenever a long weight-gradient workgroup retires.
+    if os.environ.get("YAT_HP_MAIN", "0") != "0":          # measured: no gain (99.9 vs 100.4 ms), off by default
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     log("inputs resident; warm-up")
     for i in range(args.warmup):
         step(i)

@@ -56,6 +56,19 @@ int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int l
                      void* C, int ldc, const yat_gemm_epilogue* ep, int variant, void* workspace,
                      uint64_t workspace_bytes, yat_stream_t stream);
 
+/* Grouped GEMM: `count` (<= 8) independent problems of ONE layout (a_t, b_t) in a single launch of 256 x 256 tiles,
+ * each with its own epilogue.  Replaces the per-layer sequence of nn.Linear weight-gradient GEMMs torch autograd issues
+ * one by one under loss.backward() (common/trainer.py:341): a SANA block's seven dW = dy^T x products are 81..396 tiles
+ * each -- poor fills of 256 CUs on their own, ~1240 tiles (4.85 rounds) together, with no split-K slabs. */
+typedef struct yat_gemm_problem {
+    int M, N, K;
+    const void* A; int lda;
+    const void* B; int ldb;
+    void* C; int ldc;
+    const yat_gemm_epilogue* epilogue;   /* nullable */
+} yat_gemm_problem;
+int yat_gemm_grouped_bf16(int a_t, int b_t, int count, const yat_gemm_problem* problems, yat_stream_t stream);
+
 /* out[c] (+)= sum_r x[r, c]  (bias gradients).  workspace: >= yat_colsum_workspace_bytes(rows, cols). */
 uint64_t yat_colsum_workspace_bytes(int rows, int cols);
 int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out_bf16, int accumulate, void* workspace,

@@ -114,6 +114,29 @@ def test_gemm_tn_wgrad(ops, M, N, K):
     close(dw, (rb(ref) + rb(ref)).to(BF), f"gemm_tn_acc {M}x{N}x{K}")
 
 
+def test_gemm_grouped_wgrad(ops):
+    """yat_gemm_grouped_bf16: several dW = dy^T x of different shapes (ragged tiles, different K) in one launch are
+    bit-identical to the same problems launched one by one on the 256x256 tile, plain and accumulating."""
+    shapes = [(1056, 264, 2240), (1056, 520, 96), (512, 2240, 264), (200, 72, 96), (1056, 264, 264)]    # (tokens, N, K)
+    items, singles = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = rnd(M, N, scale=M ** -0.5, seed=300 + i), rnd(M, K, seed=320 + i)
+        items.append((dy, x, torch.zeros(N, K, dtype=BF, device=DEV)))
+        one = torch.empty(N, K, dtype=BF, device=DEV)
+        ops.gemm(dy, x, one, a_t=True, b_t=True, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, variant=4)
+        singles.append(one)
+    ops.wgrad_grouped(items)
+    for (dy, x, out), one, sh in zip(items, singles, shapes):
+        assert torch.equal(out, one), f"grouped wgrad differs from the single launch for {sh}"
+        close(out, (dy.float().T @ x.float()).to(BF), f"gemm_grouped {sh}")
+    ops.wgrad_grouped(items, accumulate=True)
+    for (dy, x, out), one, sh in zip(items, singles, shapes):
+        ref = rb(dy.float().T @ x.float())
+        close(out, (ref + ref).to(BF), f"gemm_grouped_acc {sh}")
+    with pytest.raises(Exception):
+        ops.wgrad_grouped(items * 2)                      # more than 8 problems
+
+
 @pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("M,N,K", [(256, 320, 64), (512, 640, 192), (300, 328, 96), (1024, 2240, 5600), (777, 1000, 264)])
 def test_gemm256_all_layouts(ops, variant, M, N, K):

@@ -173,21 +173,16 @@ double est_time_256(int M, int N, int K, int BNv, int ksplit) {
 
 }  // namespace
 
-extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                                void* C, int ldc, const yat_gemm_epilogue* ep, int variant, void* workspace,
-                                uint64_t workspace_bytes, yat_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// argument checks + descriptor shared by the single and the grouped entry points
+static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                       int ldc, const yat_gemm_epilogue* ep, GemmP& p) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return YAT_EINVAL;
     if ((N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return YAT_EINVAL;
     if (!a_t && (K & 7)) return YAT_EINVAL;            // 16-B chunks along k
     if (a_t && (M & 7)) return YAT_EINVAL;             // 16-B chunks along m
     if (b_t && (N & 7)) return YAT_EINVAL;
     if (!b_t && (K & 7)) return YAT_EINVAL;
-    int ksplit = 1;
-    if (variant >= 100) { ksplit = variant / 100; variant %= 100; }     // tests / tuning: 100*ksplit + variant
-    if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
-    if (ksplit != 1 && ksplit != 2 && ksplit != 4) return YAT_EINVAL;
-    GemmP p{};
+    p = GemmP{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     if (ep) {
@@ -201,6 +196,36 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
     if (p.a_bytes > 0x7fffffffull || p.b_bytes > 0x7fffffffull) return YAT_EINVAL;
+    p.ksplit = 1;
+    return YAT_OK;
+}
+
+int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs, hipStream_t stream);
+
+extern "C" int yat_gemm_grouped_bf16(int a_t, int b_t, int count, const yat_gemm_problem* problems, yat_stream_t stream) {
+    if (count < 1 || count > 8 || !problems) return YAT_EINVAL;
+    GemmP ps[8];
+    for (int i = 0; i < count; ++i) {
+        const yat_gemm_problem& q = problems[i];
+        const int rc = fill_gemm_p(a_t, b_t, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.epilogue, ps[i]);
+        if (rc) return rc;
+    }
+    return yat_gemm256_grouped_launch(a_t, b_t, count, ps, (hipStream_t)stream);
+}
+
+extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                void* C, int ldc, const yat_gemm_epilogue* ep, int variant, void* workspace,
+                                uint64_t workspace_bytes, yat_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int ksplit = 1;
+    if (variant >= 100) { ksplit = variant / 100; variant %= 100; }     // tests / tuning: 100*ksplit + variant
+    if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) return YAT_EINVAL;
+    GemmP p;
+    {
+        const int rc = fill_gemm_p(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, ep, p);
+        if (rc) return rc;
+    }
     const bool wide_ok = !(N & 7) && !(ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
                          !(p.gate && (p.gate_ld & 7));
     if (variant == 0) {

@@ -100,20 +100,21 @@ __device__ __forceinline__ bf16x8 frag256(const char* lds, int idx0, int kk, int
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
+// workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of `nwg` work items
+__device__ __forceinline__ int xcd_contiguous(int nwg) {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// One workgroup's whole job: `id` = work item inside problem p (tile x K slice, before the row-group swizzle).
 template <bool A_T, bool B_T, int NT>
-__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
+__device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     using G = Geo<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wc = wave & 3;
 
-    const int nwg = p.nbm * p.nbn * p.ksplit;
-    int id;
-    {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
     const int ksl = id % p.ksplit;             // K slice of this workgroup (slices of one tile are neighbours -> same XCD)
     id /= p.ksplit;
     const int GROUP = 4;
@@ -316,6 +317,57 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
 }
 
 template <bool A_T, bool B_T, int NT>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
+    gemm256_body<A_T, B_T, NT>(p, xcd_contiguous(p.nbm * p.nbn * p.ksplit));
+}
+
+// Grouped launch: up to YAT_MAX_GROUP independent problems of one layout in ONE grid (problem g owns work items
+// [first[g], first[g+1])).  A transformer block's seven weight-gradient GEMMs launched one by one leave 5..45 % of the
+// CUs idle in their last round (81..396 tiles on 256 CUs) or pay for split-K slabs; together they are ~1240 full-K
+// tiles = 4.85 rounds.  The descriptors travel in the kernel argument segment (no device allocation, no copy).
+constexpr int YAT_MAX_GROUP = 8;
+struct GroupedP {
+    int ngroups;
+    int first[YAT_MAX_GROUP + 1];
+    GemmP g[YAT_MAX_GROUP];
+};
+
+template <bool A_T, bool B_T, int NT>
+__global__ __launch_bounds__(512, 1) void gemm256_grouped_kernel(GroupedP gp) {
+    const int id = xcd_contiguous(gp.first[gp.ngroups]);
+    int g = 0;
+    while (g + 1 < gp.ngroups && id >= gp.first[g + 1]) ++g;
+    gemm256_body<A_T, B_T, NT>(gp.g[g], id - gp.first[g]);
+}
+
+template <bool A_T, bool B_T, int NT>
+int launch256_grouped(int ngroups, const GemmP* probs, hipStream_t stream) {
+    using G = Geo<NT>;
+    if (ngroups < 1 || ngroups > YAT_MAX_GROUP) return YAT_EINVAL;
+    GroupedP gp{};
+    gp.ngroups = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        GemmP q = probs[i];
+        q.nbm = (q.M + BM - 1) / BM;
+        q.nbn = (q.N + G::BN - 1) / G::BN;
+        q.ksplit = 1;
+        q.partial = nullptr;
+        gp.g[i] = q;
+        gp.first[i + 1] = gp.first[i] + q.nbm * q.nbn;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm256_grouped_kernel<A_T, B_T, NT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256_grouped_kernel<A_T, B_T, NT>), dim3(gp.first[ngroups]), dim3(512), G::LDS, stream, gp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? YAT_OK : (int)e;
+}
+
+template <bool A_T, bool B_T, int NT>
 int launch256(const GemmP& p0, hipStream_t stream) {
     using G = Geo<NT>;
     GemmP p = p0;
@@ -360,6 +412,18 @@ int yat_gemm_splitk_reduce(const GemmP& p, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? YAT_OK : (int)e;
+}
+
+// grouped launch, 256 x 256 tiles (the one geometry whose tile counts add up well for the weight-gradient set)
+int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs, hipStream_t stream) {
+#define YAT_CASE(AT, BT) \
+    if (a_t == AT && b_t == BT) return launch256_grouped<AT, BT, 4>(ngroups, probs, stream);
+    YAT_CASE(false, false)
+    YAT_CASE(false, true)
+    YAT_CASE(true, true)
+    YAT_CASE(true, false)
+#undef YAT_CASE
+    return YAT_EINVAL;
 }
 
 // variant: 4 -> BN=256, 5 -> BN=320

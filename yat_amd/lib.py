@@ -20,11 +20,17 @@ class GemmEpilogue(C.Structure):
                 ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I)]
 
 
+class GemmProblem(C.Structure):
+    _fields_ = [("M", I), ("N", I), ("K", I), ("A", P), ("lda", I), ("B", P), ("ldb", I), ("C", P), ("ldc", I),
+                ("epilogue", C.POINTER(GemmEpilogue))]
+
+
 # name -> (restype, argtypes)
 SIGNATURES = {
     "yat_version": (I, []),
     "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
     "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P, U64, P]),
+    "yat_gemm_grouped_bf16": (I, [I, I, I, C.POINTER(GemmProblem), P]),
     "yat_colsum_workspace_bytes": (U64, [I, I]),
     "yat_colsum_bf16": (I, [I, I, P, I, P, I, P, P]),
     "yat_modulation_fwd": (I, [I, I, I, P, P, I, I, P, P]),

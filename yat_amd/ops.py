@@ -108,6 +108,35 @@ def linear_wgrad(dy2d, x2d, out, accumulate=False):
                 residual=out if accumulate else None)
 
 
+def wgrad_grouped(items, accumulate=False):
+    """yat_gemm_grouped_bf16 for a set of weight gradients: items = [(dy [M,N], x [M,K], out [N,K]), ...], all
+    dW = dy^T x (optionally += out) in ONE launch of 256x256 tiles (see include/yat_hip.h)."""
+    n = len(items)
+    probs = (_l.GemmProblem * n)()
+    eps = (_l.GemmEpilogue * n)()
+    flops = 0.0
+    for i, (dy, x, out) in enumerate(items):
+        _chk_bf16(dy, x, out)
+        M, N = dy.shape
+        K = x.shape[1]
+        pr = probs[i]
+        pr.M, pr.N, pr.K = N, K, M
+        pr.A, pr.lda, pr.B, pr.ldb, pr.C, pr.ldc = _p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), K
+        if accumulate:
+            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out), 0, 0, K, 0)
+            pr.epilogue = C.pointer(eps[i])
+        flops += 2.0 * M * N * K
+    timer = GEMM_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib().yat_gemm_grouped_bf16(1, 1, n, probs, _stream())
+    if timer is not None:
+        e1.record()
+        timer.append((flops, e0, e1, ("tn", 0, 0, 0, f"grouped x{n}", False, accumulate, False)))
+    _l.check(rc, "yat_gemm_grouped_bf16")
+
+
 def colsum(x2d, out, workspace, accumulate=False):
     """yat_colsum_bf16: out[c] (+)= sum_r x[r,c]."""
     rows, cols = x2d.shape

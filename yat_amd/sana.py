@@ -165,6 +165,8 @@ class SanaTransformer2DModelHIP(nn.Module):
         self.bucket_bounds = self._make_buckets(specs, offs, off)
         self.grad_ready = None            # callable(bucket_index) set by HipDDP
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"   # weight gradients on a second stream
+        self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
+        self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
         self._side = None
         self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
         self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
@@ -478,69 +480,99 @@ class SanaTransformer2DModelHIP(nn.Module):
                                  dmodf2d[:, 0:D], dmodf2d[:, D:2 * D], 2 * D, ws_ln)
         ops.modulation_bwd(dmodf, G["scale_shift_table"], demb, 0, accumulate_table=acc)
         denc = buf("denc", (Mt, D))
-        # ---- blocks, last to first
+        # ---- blocks, last to first.  A block's seven weight gradients are deferred to its end and go out as ONE grouped
+        # GEMM launch on the side stream (~1240 full-K 256x256 tiles = 4.85 rounds of the 256 CUs, instead of seven
+        # launches of 81..396 tiles, three of them split-K); the gradient buffers they read alternate between two sets
+        # by block parity, so the main stream is already writing block i-1's while the side stream reads block i's.
+        set_done = [None, None]
         for i in reversed(range(cfg.num_layers)):
             pre = f"transformer_blocks.{i}."
             A = S.blocks[i]
+            par = i & 1
+            if set_done[par] is not None:
+                main.wait_event(set_done[par])                # block i+2's weight gradients have read this set
+                set_done[par] = None
             mod2d = A.mod.view(B, 6 * D)
             dmod = buf("dmod", (B, 6, D), f32).zero_()
             dmod2d = dmod.view(B, 6 * D)
+            deferred = []                                     # (dy, x, dW) of this block
+
+            def emit(dy_, x_, gw_, bias=None):
+                if self.defer_wgrad or side is None:
+                    deferred.append((dy_, x_, gw_))
+                    return
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
+                    if bias is not None:
+                        ops.colsum(dy_, bias, ws_col, accumulate=acc)
             # x3 = x2 + gate_mlp * lin3
-            dlin = buf("dlin", (M, D))
-            writes(dlin)
-            ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
-            wgrad(dlin, A.y, pre + "ff.conv_point.weight", (D, Hc))
-            dy = ops.linear_dgrad(dlin, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
-            dz = buf("dz", (M, 2 * Hc))
-            writes(dz)
+            dlin3 = buf(f"dlin3.{par}", (M, D))
+            ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
+            emit(dlin3, A.y, G[pre + "ff.conv_point.weight"].view(D, Hc))
+            dy = ops.linear_dgrad(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
+            dz = buf(f"dz.{par}", (M, 2 * Hc))
             ops.dwconv_glu_bwd(A.s, A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
                                dz_colsum=G[pre + "ff.conv_inverted.bias"])                # bias gradient in the same pass
-            wgrad(dz, A.h2, pre + "ff.conv_inverted.weight", (2 * Hc, D))
+            emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D))
             dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf("dh", (M, D)))
             other = dxb if dx is dxa else dxa
-            writes(other)
-            dx2 = ops.ln_modulate_bwd(A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2_, dx, other,
+            dx2 = ops.ln_modulate_bwd(A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2_, dx, buf(f"dx2.{par}", (M, D)),
                                       dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln)
             # x2 = x1 + to_out(o2)
-            wgrad(dx2, A.o2, pre + "attn2.to_out.0.weight", (D, D), pre + "attn2.to_out.0.bias")
+            emit(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"])
             do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf("dh", (M, D)))
-            dq2 = buf("dq2", (M, D))
-            dkv2 = buf("dkv2", (Mt, 2 * D))
+            dq2 = buf(f"dq2.{par}", (M, D))
+            dkv2 = buf(f"dkv2.{par}", (Mt, 2 * D))
             delta = buf("delta", (B, H2, N), f32)
-            writes(dq2, dkv2)
             ops.sdpa_bwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse,
                          delta, dq2, dkv2[:, :D], dkv2[:, D:], work=S.kv_work)
-            wgrad(dq2, A.x1, pre + "attn2.to_q.weight", (D, D), pre + "attn2.to_q.bias")
-            writes(dx2)                                                                           # overwritten in place below
-            dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=dx2, residual=dx2)      # dx1 = dx2 + dq2 Wq
+            emit(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"])
+            dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
-
-            def kv_grads(dkv2=dkv2, wkv=wkv, gkv=gkv, gbkv=gbkv, first=(i == cfg.num_layers - 1)):
-                # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
-                ops.linear_wgrad(dkv2, S.encn, gkv, accumulate=acc)
-                ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
-                ops.linear_dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
-            on_side(dkv2, kv_grads)
+            emit(dkv2, S.encn, gkv, gbkv)
             # x1 = x + gate_msa * lin1
-            writes(dlin)
-            ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate,
+            dlin1 = buf(f"dlin1.{par}", (M, D))
+            ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin1, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate,
                          dbias=G[pre + "attn1.to_out.0.bias"], accumulate_bias=acc)       # bias gradient in the same pass
-            wgrad(dlin, A.attn, pre + "attn1.to_out.0.weight", (D, D))
-            dattn = ops.linear_dgrad(dlin, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
-            dqkv = buf("dqkv", (M, 3 * D))
-            writes(dqkv)
+            emit(dlin1, A.attn, G[pre + "attn1.to_out.0.weight"])
+            dattn = ops.linear_dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
+            dqkv = buf(f"dqkv.{par}", (M, 3 * D))
             ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
-            on_side(dqkv, lambda dqkv=dqkv, gqkv=gqkv, A=A: ops.linear_wgrad(dqkv, A.h1, gqkv, accumulate=acc))
+            emit(dqkv, A.h1, gqkv)
             dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf("dh", (M, D)))
-            other = dxb if dx1 is dxa else dxa
-            writes(other)
-            dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1, dx1, other,
+            dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1, dx1, dx,
                                      dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln)
             ops.modulation_bwd(dmod, G[pre + "scale_shift_table"], dtmod, D, accumulate_table=acc)
+
+            def block_grads(deferred=deferred, dx2=dx2, dq2=dq2, dkv2=dkv2, wkv=wkv, gbkv=gbkv, pre=pre,
+                            first=(i == cfg.num_layers - 1)):
+                if deferred:
+                    if self.grouped_wgrad:
+                        # largest K first: the short tiles (text side, K = B*T) fill the tail
+                        ops.wgrad_grouped(sorted(deferred, key=lambda it: -it[0].shape[0]), accumulate=acc)
+                    else:
+                        for dy_, x_, gw_ in deferred:
+                            ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
+                    ops.colsum(dx2, G[pre + "attn2.to_out.0.bias"], ws_col, accumulate=acc)
+                    ops.colsum(dq2, G[pre + "attn2.to_q.bias"], ws_col, accumulate=acc)
+                    ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
+                # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
+                ops.linear_dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
+
+            if side is None:
+                block_grads()
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    block_grads()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                set_done[par] = ev
             if self.grad_ready is not None:
                 if side is not None:
                     main.wait_stream(side)
