@@ -165,6 +165,8 @@ class SanaTransformer2DModelHIP(nn.Module):
         self.bucket_bounds = self._make_buckets(specs, offs, off)
         self.grad_ready = None            # callable(bucket_index) set by HipDDP
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"   # weight gradients on a second stream
+        self.fwd_chains = int(os.environ.get("YAT_FWD_CHAINS", "2"))           # independent forward chains (image ranges)
+        self._chains = {}
         self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
         self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
         self._side = None
@@ -348,57 +350,94 @@ class SanaTransformer2DModelHIP(nn.Module):
                                 out=buf("te_tmod", (B, 6 * D)))
         # 3. caption projection + RMSNorm + K/V projections: text_branch() above
         scale2 = 1.0 / math.sqrt(dh2)
-        # 4. transformer blocks
+        # 4. transformer blocks + 5. output head.  Activations live in whole-batch buffers (the backward runs on the whole
+        # batch); the forward walks them as `fwd_chains` independent chains over disjoint image ranges, each on its own
+        # stream: while one chain sits in a memory-bound kernel (norms, attention, depthwise conv) the other one's
+        # GEMM has the matrix cores, and a chain's single-round GEMMs no longer leave the other CUs idle.
+        f32 = torch.float32
         for i in range(cfg.num_layers):
-            pre = f"transformer_blocks.{i}."
-            A = SimpleNamespace(x_in=x)
-            params_ready(i + 1)
-            A.mod = ops.modulation_fwd(P[pre + "scale_shift_table"], S.tmod, D, buf(f"b{i}.mod", (B, 6, D)))
-            mod2d = A.mod.view(B, 6 * D)
-            A.h1, A.mean1, A.rstd1 = ops.ln_modulate_fwd(
-                x, mod2d[:, 0:D], mod2d[:, D:2 * D], 6 * D, N, cfg.norm_eps, buf(f"b{i}.h1", (M, D)),
-                buf(f"b{i}.mean1", (M,), torch.float32), buf(f"b{i}.rstd1", (M,), torch.float32))
-            wqkv, _ = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
-            A.qkv = ops.linear_fwd(A.h1, wqkv, out=buf(f"b{i}.qkv", (M, 3 * D)))
-            A.la_state = buf(f"b{i}.la_state", (B * H1 * 33 * 32,), torch.float32)     # kept for the backward
-            A.attn = ops.linear_attn_fwd(A.qkv, B, N, H1, D, 2 * D, buf(f"b{i}.attn", (M, D)), A.la_state)
-            A.lin1 = buf(f"b{i}.lin1", (M, D))
-            A.x1 = ops.linear_fwd(A.attn, P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"],
-                                  out=buf(f"b{i}.x1", (M, D)), aux_out=A.lin1, gate=mod2d[:, 2 * D:3 * D],
-                                  ld_gate=6 * D, residual=x, rows_per_batch=N)
-            A.q2 = ops.linear_fwd(A.x1, P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"],
-                                  out=buf(f"b{i}.q2", (M, D)))
+            A = SimpleNamespace()
+            A.mod = buf(f"b{i}.mod", (B, 6, D))
+            A.h1, A.mean1, A.rstd1 = buf(f"b{i}.h1", (M, D)), buf(f"b{i}.mean1", (M,), f32), buf(f"b{i}.rstd1", (M,), f32)
+            A.qkv = buf(f"b{i}.qkv", (M, 3 * D))
+            A.la_state = buf(f"b{i}.la_state", (B * H1 * 33 * 32,), f32)                  # kept for the backward
+            A.attn, A.lin1, A.x1, A.q2 = (buf(f"b{i}.{n}", (M, D)) for n in ("attn", "lin1", "x1", "q2"))
             A.kv2 = S.kv2[i]
-            if side is not None:
-                main.wait_event(S.kv_ready[i])
-            A.o2 = buf(f"b{i}.o2", (M, D))
-            A.lse = buf(f"b{i}.lse", (B, H2, N), torch.float32)
-            ops.sdpa_fwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, key_bias, kv_len, A.o2, A.lse)
-            A.x2 = ops.linear_fwd(A.o2, P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"],
-                                  out=buf(f"b{i}.x2", (M, D)), residual=A.x1)
-            A.h2, A.mean2, A.rstd2 = ops.ln_modulate_fwd(
-                A.x2, mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, buf(f"b{i}.h2", (M, D)),
-                buf(f"b{i}.mean2", (M,), torch.float32), buf(f"b{i}.rstd2", (M,), torch.float32))
-            A.z = buf(f"b{i}.z", (M, 2 * Hc))                 # pre-activation (for SiLU' in backward)
-            A.s = ops.linear_fwd(A.h2, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D),
-                                 P[pre + "ff.conv_inverted.bias"], out=buf(f"b{i}.s", (M, 2 * Hc)),
-                                 activation="silu", aux_out=A.z)
-            A.y = ops.dwconv_glu_fwd(A.s, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
-                                     P[pre + "ff.conv_depth.bias"], buf(f"b{i}.y", (M, Hc)))
-            A.lin3 = buf(f"b{i}.lin3", (M, D))
-            x = ops.linear_fwd(A.y, P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=buf(f"b{i}.x3", (M, D)),
-                               aux_out=A.lin3, gate=mod2d[:, 5 * D:6 * D], ld_gate=6 * D, residual=A.x2,
-                               rows_per_batch=N)
+            A.o2, A.lse, A.x2 = buf(f"b{i}.o2", (M, D)), buf(f"b{i}.lse", (B, H2, N), f32), buf(f"b{i}.x2", (M, D))
+            A.h2, A.mean2, A.rstd2 = buf(f"b{i}.h2", (M, D)), buf(f"b{i}.mean2", (M,), f32), buf(f"b{i}.rstd2", (M,), f32)
+            A.z, A.s = buf(f"b{i}.z", (M, 2 * Hc)), buf(f"b{i}.s", (M, 2 * Hc))          # z: pre-activation, for SiLU'
+            A.y, A.lin3, A.x3 = buf(f"b{i}.y", (M, Hc)), buf(f"b{i}.lin3", (M, D)), buf(f"b{i}.x3", (M, D))
+            A.x_in = x if i == 0 else S.blocks[i - 1].x3
             S.blocks.append(A)
-        # 5. output head: modulated norm + proj_out + unpatchify
-        S.x_last = x
-        S.modf = ops.modulation_fwd(P["scale_shift_table"], S.embedded, 0, buf("modf", (B, 2, D)))
-        modf2d = S.modf.view(B, 2 * D)
-        S.hf, S.meanf, S.rstdf = ops.ln_modulate_fwd(x, modf2d[:, 0:D], modf2d[:, D:2 * D], 2 * D, N, 1e-6,
-                                                     buf("hf", (M, D)), buf("meanf", (M,), torch.float32),
-                                                     buf("rstdf", (M,), torch.float32))
-        out_tok = ops.linear_fwd(S.hf, P["proj_out.weight"], P["proj_out.bias"], out=buf("out_tok", (M, Cout)))
-        pred = ops.transpose(out_tok.view(B, N, Cout), torch.empty(B, Cout, N, dtype=BF16, device=dev))
+        S.x_last = S.blocks[-1].x3 if cfg.num_layers else x
+        S.modf = buf("modf", (B, 2, D))
+        S.hf, S.meanf, S.rstdf = buf("hf", (M, D)), buf("meanf", (M,), f32), buf("rstdf", (M,), f32)
+        out_tok = buf("out_tok", (M, Cout))
+        pred = torch.empty(B, Cout, N, dtype=BF16, device=dev)
+        la_per_image = H1 * 33 * 32
+
+        def run_chain(b0, b1, stream):
+            nb = b1 - b0
+            rs, ts, bs = slice(b0 * N, b1 * N), slice(b0 * T, b1 * T), slice(b0, b1)
+            for i in range(cfg.num_layers):
+                pre = f"transformer_blocks.{i}."
+                A = S.blocks[i]
+                xin = A.x_in[rs]
+                params_ready(i + 1, stream)
+                ops.modulation_fwd(P[pre + "scale_shift_table"], S.tmod[bs], D, A.mod[bs])
+                mod2d = A.mod.view(B, 6 * D)[bs]
+                ops.ln_modulate_fwd(xin, mod2d[:, 0:D], mod2d[:, D:2 * D], 6 * D, N, cfg.norm_eps, A.h1[rs], A.mean1[rs],
+                                    A.rstd1[rs])
+                wqkv, _ = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
+                ops.linear_fwd(A.h1[rs], wqkv, out=A.qkv[rs])
+                ops.linear_attn_fwd(A.qkv[rs], nb, N, H1, D, 2 * D, A.attn[rs],
+                                    A.la_state[b0 * la_per_image:b1 * la_per_image])
+                ops.linear_fwd(A.attn[rs], P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"], out=A.x1[rs],
+                               aux_out=A.lin1[rs], gate=mod2d[:, 2 * D:3 * D], ld_gate=6 * D, residual=xin,
+                               rows_per_batch=N)
+                ops.linear_fwd(A.x1[rs], P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"], out=A.q2[rs])
+                if side is not None:
+                    stream.wait_event(S.kv_ready[i])
+                kv = A.kv2[ts]
+                ops.sdpa_fwd(A.q2[rs], kv[:, :D], kv[:, D:], nb, N, T, H2, dh2, scale2, key_bias[bs], kv_len[bs], A.o2[rs],
+                             A.lse[bs])
+                ops.linear_fwd(A.o2[rs], P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"], out=A.x2[rs],
+                               residual=A.x1[rs])
+                ops.ln_modulate_fwd(A.x2[rs], mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, A.h2[rs],
+                                    A.mean2[rs], A.rstd2[rs])
+                ops.linear_fwd(A.h2[rs], P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), P[pre + "ff.conv_inverted.bias"],
+                               out=A.s[rs], activation="silu", aux_out=A.z[rs])
+                ops.dwconv_glu_fwd(A.s[rs], nb, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
+                                   P[pre + "ff.conv_depth.bias"], A.y[rs])
+                ops.linear_fwd(A.y[rs], P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=A.x3[rs], aux_out=A.lin3[rs],
+                               gate=mod2d[:, 5 * D:6 * D], ld_gate=6 * D, residual=A.x2[rs], rows_per_batch=N)
+            # output head: modulated norm + proj_out + unpatchify
+            ops.modulation_fwd(P["scale_shift_table"], S.embedded[bs], 0, S.modf[bs])
+            modf2d = S.modf.view(B, 2 * D)[bs]
+            ops.ln_modulate_fwd(S.x_last[rs], modf2d[:, 0:D], modf2d[:, D:2 * D], 2 * D, N, 1e-6, S.hf[rs], S.meanf[rs],
+                                S.rstdf[rs])
+            ops.linear_fwd(S.hf[rs], P["proj_out.weight"], P["proj_out.bias"], out=out_tok[rs])
+            ops.transpose(out_tok[rs].view(nb, N, Cout), pred[bs])
+
+        nchain = max(1, min(self.fwd_chains, B))
+        if nchain == 1:
+            run_chain(0, B, main)
+        else:
+            bounds = [(B * c) // nchain for c in range(nchain + 1)]
+            fork = torch.cuda.Event()
+            fork.record(main)
+            joins = []
+            for c in range(1, nchain):
+                st = self._chain_stream(c)
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    run_chain(bounds[c], bounds[c + 1], st)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                joins.append(ev)
+            run_chain(bounds[0], bounds[1], main)
+            for ev in joins:
+                main.wait_event(ev)
         self._saved = S
         return pred.view(B, Cout, h, w)
 
@@ -409,6 +448,11 @@ class SanaTransformer2DModelHIP(nn.Module):
             cur = torch.cuda.current_stream()
             for ev in pev:
                 cur.wait_event(ev)
+
+    def _chain_stream(self, c):
+        if c not in self._chains:
+            self._chains[c] = torch.cuda.Stream(device=self.flat_param.device)
+        return self._chains[c]
 
     def _side_stream(self):
         if self._side is None:
