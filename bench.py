@@ -242,11 +242,11 @@ def main():
     # ---- roofline pass (after the timed region): per-launch GEMM durations by HIP events on the launch stream.
     # The step overlaps independent GEMMs on two streams, so in the timed region two kernels share the CUs and
     # their individual durations overlap; the per-kernel figure is therefore taken with the streams serialized
-    # (YAT_SIDE_WGRAD=0 behaviour), same kernels, same shapes, same inputs.
+    # (YAT_SIDE_WGRAD=0 YAT_OVERLAP_ADAMW=0 YAT_FWD_CHAINS=1 behaviour), same kernels, same shapes, same inputs.
     timer = None
     if not args.no_gemm_timer:          # every rank runs it (the DDP collectives need all of them); rank 0 reports
-        saved = (model.side_wgrad, opt.overlap_update)
-        model.side_wgrad, opt.overlap_update = False, False
+        saved = (model.side_wgrad, opt.overlap_update, model.fwd_chains)
+        model.side_wgrad, opt.overlap_update, model.fwd_chains = False, False, 1
         step(0)
         torch.cuda.synchronize()
         timer = []
@@ -255,7 +255,7 @@ def main():
             step(1 + i)
         torch.cuda.synchronize()
         ops.GEMM_TIMER = None
-        model.side_wgrad, opt.overlap_update = saved
+        model.side_wgrad, opt.overlap_update, model.fwd_chains = saved
         barrier()
 
     if rank == 0:

@@ -13,9 +13,10 @@ dependency (``diffusers``, requirements.txt:7) that is absent from this
 container, so the restatement of the model math below cannot be checked
 against reference outputs.  What IS pinned:
 
-* the config boundary: ``oracle/params_ref.py`` is checked against JSON
-  produced by importing the reference's own
-  ``common/training_parameters_reader.py`` (tests/golden/make_params_golden.py);
+* the config boundary: the host-side reader (``yat_amd/common/training_parameters_reader.py``)
+  is checked in ``tests/test_params_golden.py`` against JSON produced by importing the
+  reference's own ``common/training_parameters_reader.py``
+  (``tests/golden/make_params_golden.py`` is the generating script);
 * the RNG stream of the recipe (fresh ``torch.Generator()`` per step,
   trainer.py:325) and the AdamW / clip arithmetic: both are *stock torch*, the
   same dependency the reference calls, executed here on CPU;
