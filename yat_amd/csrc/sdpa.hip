@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int TILE = 16384;  // one [64][128] bf16 image
-constexpr int DKV_STAGE = 4 * TILE + 512;   // one query-tile stage of the dK/dV kernel
+constexpr int DKV_STAGE = 2 * TILE + 512;   // one query-tile stage of the dK/dV kernel: Q, dO (one image each), lse, delta
 
 enum { IMG_ROW = 0, IMG_TR = 1 };
 
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // stage layout: ROW image of Q | ROW image of dO | TR image of Q | TR image of dO | lse[64] | delta[64]
+    // stage layout: Q | dO (TR-swizzled images, read row-wise for S / dP and transposed for dK / dV) | lse[64] | delta[64]
+    // (staging a ROW and a TR image of each, as before, made the loop LDS-DMA bound: 64 KB per query tile per CU)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     // Work decomposition: launching early-exit workgroups of this LDS-heavy kernel is NOT free (measured: ~0.24 us
@@ -363,10 +364,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     // double-buffered query tiles: tile qt+1 is DMA'd while tile qt is consumed
     auto stage_q = [&](int q0, char* base) {
         const int64_t r0 = (int64_t)b * p.N + q0, rl = (int64_t)b * p.N + p.N;
-        stage64x128<IMG_ROW>(rq, base, r0, rl, p.ldq, col0, p.dh, wave, lane);
-        stage64x128<IMG_ROW>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rq, base + 2 * TILE, r0, rl, p.ldq, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rdo, base + 3 * TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rq, base, r0, rl, p.ldq, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
         // lse / delta rows by 4-byte LDS-DMA as well: an ordinary VGPR load here would make the compiler wait
         // vmcnt(0) for it -- draining the 16 tile DMAs just issued and undoing the double buffering.  Rows past N read
         // as 0 (range check); their Q and dO rows are zero too, so P stays finite and dS = P * (0 - 0) = 0.
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
             const int qi = q0 + lane;
             const int64_t si = ((int64_t)b * p.H + h) * p.N + qi;
             const uint32_t voff = qi < p.N ? (uint32_t)(si * 4) : YAT_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? rlse : rdel, (YAT_LDS void*)(base + 4 * TILE + wave * 256), 4,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? rlse : rdel, (YAT_LDS void*)(base + 2 * TILE + wave * 256), 4,
                                                      voff, 0, 0, 0);
         }
     };
@@ -384,11 +383,9 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // tile `it` landed everywhere; every wave is done with the other stage
         if (q0 + 64 < p.N) stage_q(q0 + 64, smem + ((it + 1) & 1) * DKV_STAGE);
-        const char* Qs = cur;
-        const char* Os = cur + TILE;
-        const char* Qt = cur + 2 * TILE;
-        const char* Ot = cur + 3 * TILE;
-        const float* lse_s = reinterpret_cast<const float*>(cur + 4 * TILE);
+        const char* Qt = cur;
+        const char* Ot = cur + TILE;
+        const float* lse_s = reinterpret_cast<const float*>(cur + 2 * TILE);
         const float* del_s = lse_s + 64;
 
         f32x4 s[4], dp[4];
@@ -398,8 +395,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
             dp[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s[nq] = mfma16(frag_row(Qs, nq * 16, ks, lane), kf[ks], s[nq]);     // [q = 16nq+4g+r][key = li]
-                dp[nq] = mfma16(frag_row(Os, nq * 16, ks, lane), vf[ks], dp[nq]);
+                s[nq] = mfma16(frag_row_tr(Qt, nq * 16, ks, lane), kf[ks], s[nq]);     // [q = 16nq+4g+r][key = li]
+                dp[nq] = mfma16(frag_row_tr(Ot, nq * 16, ks, lane), vf[ks], dp[nq]);
             }
         }
 #pragma unroll
@@ -434,7 +431,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     }
 }
 
-constexpr int FWD_LDS = 2 * FWD_STAGE, DQ_LDS = 2 * DQ_STAGE, DKV_LDS = 2 * (4 * TILE + 512);
+constexpr int FWD_LDS = 2 * FWD_STAGE, DQ_LDS = 2 * DQ_STAGE, DKV_LDS = 2 * DKV_STAGE;
 
 int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv) {
     if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7)) return YAT_EINVAL;
