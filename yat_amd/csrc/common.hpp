@@ -94,6 +94,20 @@ __device__ __forceinline__ float dgelu_tanh_f(float x) {
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (private L2 each) by their linear index (x fastest).  This maps the
+// launch's linear index to a work unit so that every XCD owns one contiguous run of units: neighbouring units -- which
+// usually touch neighbouring bytes (the other half of a 128-B line, a halo row) -- then share an L2 instead of each
+// fetching their own copy from HBM.  Returns the unit's (x, y, z) in the kernel's own grid coordinates.
+__device__ __forceinline__ void xcd_contiguous3(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    bx = u % gx;
+    by = (u / gx) % gy;
+    bz = u / (gx * gy);
+}
+
 // ---- MFMA 16x16x32 bf16 fragment loaders (wave64) -------------------------------------------
 // Operand register layout (both A and B): lane l holds index idx = l & 15 (row of A / col of B)
 // and k = 8*(l>>4) + j, j = 0..7.  Result: lane holds D[row = 4*(l>>4) + r][col = l & 15].

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void la_state_kernel(int N, const bf16_t* qkv,
                                                        uint64_t bytes, float* S_out) {
     __shared__ __attribute__((aligned(16))) char lds[4 * 8192 + 4 * 6 * 64 * 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = blockIdx.x, b = blockIdx.y;
+    int h, b, unused_z;
+    xcd_contiguous3(h, b, unused_z);            // adjacent heads (the two halves of a 128-B line) on one XCD
     char* kt = lds + wave * 8192;
     char* vt = kt + 4096;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, bytes);
@@ -200,7 +201,8 @@ __device__ __forceinline__ void u_tiles(const bf16x8 (&shi)[3], const bf16x8 (&s
 __global__ __launch_bounds__(256) void la_fwd_kernel(int N, int H, const bf16_t* qkv, int ld, const float* S_all,
                                                      bf16_t* out, int ld_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int cx, h, b;
+    xcd_contiguous3(cx, h, b);                  // chunks of a head, then the next head, on one XCD
     const float* S = S_all + ((int64_t)b * H + h) * SS;
     bf16x8 shi[3], slo[3];
 #pragma unroll
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void la_fwd_kernel(int N, int H, const bf16_t*
     const int g = lane >> 4, li = lane & 15;
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-        const int n0 = blockIdx.x * TB + wave * 64 + grp * 16;
+        const int n0 = cx * TB + wave * 64 + grp * 16;
         if (n0 >= N) break;
         const int n = n0 + li;
         f32x4 ut[3];
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
     // wave-private: dU hi and lo images [32 tokens][64 c'] bf16 (128-B rows) + q image [32 tokens][32 c] bf16 (64-B rows)
     __shared__ __attribute__((aligned(16))) char lds[4 * (2 * 4096 + 2048) + 4 * 6 * 64 * 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
+    int cx, h, b;
+    xcd_contiguous3(cx, h, b);                  // chunks of a head, then the next head, on one XCD
     const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = lane & 3;
     const float* S = S_all + ((int64_t)b * H + h) * SS;
     char* du_img = lds + wave * 10240;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
     for (int half = 0; half < 2; ++half) {                       // 32 tokens per dS k-step
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            const int n0 = blockIdx.x * TB + wave * 64 + half * 32 + sub * 16;
+            const int n0 = cx * TB + wave * 64 + half * 32 + sub * 16;
             const int n = n0 + li;
             const bf16x8 qf = relu8(tok_frag(qb, ld, n, N, lane));
             f32x4 ut[3];
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
         for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 6 + t * 2 + ct) * 64 + lane) * 4) = ds[t][ct];
     __syncthreads();
     if (wave == 0) {
-        float* slab = dS_part + (((int64_t)b * H + h) * gridDim.x + blockIdx.x) * SS;
+        float* slab = dS_part + (((int64_t)b * H + h) * gridDim.x + cx) * SS;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -388,7 +391,8 @@ __global__ void la_reduce_slabs_kernel(int nbh, int nchunks, const float* part, 
 __global__ __launch_bounds__(256) void la_bwd_kv_kernel(int N, int H, const bf16_t* qkv, int ld, int k_off, int v_off,
                                                         const float* dS_all, bf16_t* dqkv, int ld_dq) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int cx, h, b;
+    xcd_contiguous3(cx, h, b);                  // chunks of a head, then the next head, on one XCD
     const int g = lane >> 4, li = lane & 15;
     const float* dS = dS_all + ((int64_t)b * H + h) * SS;
     bf16x8 rhi[2], rlo[2], chi[2], clo[2];
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void la_bwd_kv_kernel(int N, int H, const bf16
     bf16_t* dvb = dqkv + (int64_t)b * N * ld_dq + h * C + v_off;
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-        const int n0 = blockIdx.x * TB + wave * 64 + grp * 16;
+        const int n0 = cx * TB + wave * 64 + grp * 16;
         if (n0 >= N) break;
         const int n = n0 + li;
         const bf16x8 kf = relu8(tok_frag(kb, ld, n, N, lane));

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyat_hip.so")
+LIB_PATH = os.environ.get("YAT_HIP_LIB") or os.path.join(_HERE, "libyat_hip.so")   # override: A/B of two builds
 
 P, I, I64, U64, F, D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
