@@ -91,13 +91,16 @@ int yat_modulation_bwd(int B, int S, int D, const float* dmod, void* dtable_bf16
  * shift/scale: bf16 [B, mod_ld] rows (pointers already offset to the slot); b = row / rows_per_batch.
  * bwd: dx = (dres?) + LN'(dy * (1+scale));  dshift_acc[b,:] += sum_n dy;  dscale_acc[b,:] += sum_n dy * xhat
  *      (fp32 accumulators with leading dimension acc_ld).
+ *      parts: 1 = dx only (the dependent chain), 2 = dshift/dscale only (needed by nobody downstream: the caller may
+ *      run it on another stream), 3 = both.
  * ------------------------------------------------------------------------------------------ */
 uint64_t yat_ln_bwd_workspace_bytes(int M, int D, int rows_per_batch);
 int yat_ln_modulate_fwd(int M, int D, int rows_per_batch, float eps, const void* x, const void* shift,
                         const void* scale, int mod_ld, void* y, float* mean, float* rstd, yat_stream_t stream);
 int yat_ln_modulate_bwd(int M, int D, int rows_per_batch, const void* x, const float* mean, const float* rstd,
                         const void* scale, int mod_ld, const void* dy, const void* dres, void* dx,
-                        float* dshift_acc, float* dscale_acc, int acc_ld, void* workspace, yat_stream_t stream);
+                        float* dshift_acc, float* dscale_acc, int acc_ld, void* workspace, int parts,
+                        yat_stream_t stream);
 
 /* RMSNorm with affine weight, eps inside the sqrt (caption_norm, patched_sana_transformer.py:136,298)
  *   y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * w ).   bwd: dx, dw (bf16, optional accumulate). */
@@ -132,11 +135,13 @@ int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q,
                  int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream);
 /* work_list (optional, device int32 [n_work][2] = (batch, key tile) for every key tile with tile*64 < kv_len[batch], n_work
  * known on the host from the embedding lengths): the dK/dV kernel then launches only those workgroups; NULL = dense
- * grid over all T/64 tiles with early exit (correct, but idle LDS-heavy workgroups cost ~0.24 us each). */
+ * grid over all T/64 tiles with early exit (correct, but idle LDS-heavy workgroups cost ~0.24 us each).
+ * parts: 1 = dQ and delta (what the dependent chain needs), 2 = dK/dV (reads delta; feeds only the text-side weight
+ * gradients, so the caller may run it on another stream after part 1), 3 = both. */
 int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
                  const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,
-                 int n_work, yat_stream_t stream);
+                 int n_work, int parts, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * GLUMBConv middle: SiLU -> depthwise 3x3 (pad 1, bias) -> chunk2 -> a * SiLU(g)

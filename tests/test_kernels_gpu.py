@@ -307,6 +307,12 @@ def test_ln_modulate_fwd_bwd(ops, B, n, D):
     as_good_as(acc[:, 3], flow[1], truth[1], f"ln_bwd_dshift D={D}", tol_flow=2e-2)
     as_good_as(acc[:, 4], flow[2], truth[2], f"ln_bwd_dscale D={D}", tol_flow=2e-2)
     assert acc[:, [0, 1, 2, 5]].abs().max().item() == 0.0
+    # the two halves launched separately (dx on the dependent chain, shift/scale gradients elsewhere) give the same bits
+    dx_p, acc_p = torch.empty_like(dx), torch.zeros_like(acc)
+    ops.ln_modulate_bwd(x, mean, rstd, scale, 6 * D, n, dy, dres, dx_p, acc_p[:, 3], acc_p[:, 4], 6 * D, ws, parts=1)
+    assert torch.equal(dx_p, dx) and acc_p.abs().max().item() == 0.0
+    ops.ln_modulate_bwd(x, mean, rstd, scale, 6 * D, n, dy, None, None, acc_p[:, 3], acc_p[:, 4], 6 * D, ws, parts=2)
+    assert torch.equal(acc_p, acc)
 
 
 def test_rmsnorm_fwd_bwd(ops):
@@ -457,6 +463,12 @@ def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
     ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, dout, lse, delta, dq2, dkv2[:, :D], dkv2[:, D:],
                  work=ops.kv_work_list(lens, T, DEV))
     assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2)
+    # dQ (+delta) and dK/dV as two separate calls (the second may run on another stream): same bits
+    dq3, dkv3, delta3 = torch.empty_like(dq), torch.full_like(kv, float("nan")), torch.empty_like(delta)
+    for part in (1, 2):
+        ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvlen, out, dout, lse, delta3, dq3, dkv3[:, :D], dkv3[:, D:],
+                     work=ops.kv_work_list(lens, T, DEV), parts=part)
+    assert torch.equal(dq, dq3) and torch.equal(dkv, dkv3) and torch.equal(delta, delta3)
     as_good_as(dq, fl[0], qr.grad, f"sdpa_dq T={T}", tol_flow=1e-2)
     as_good_as(dkv[:, :D], fl[1], kr.grad, f"sdpa_dk T={T}", tol_flow=1e-2)
     as_good_as(dkv[:, D:], fl[2], vr.grad, f"sdpa_dv T={T}", tol_flow=1e-2)

@@ -420,11 +420,12 @@ uint64_t yat_ln_bwd_workspace_bytes(int M, int D, int rpb) {
 
 int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean, const float* rstd, const void* scale,
                         int mod_ld, const void* dy, const void* dres, void* dx, float* dshift_acc, float* dscale_acc,
-                        int acc_ld, void* workspace, yat_stream_t stream) {
-    if (M <= 0 || rpb <= 0 || M % rpb || (mod_ld & 7) || !x || !dy || !dx || !workspace || !dshift_acc || !dscale_acc)
-        return YAT_EINVAL;
+                        int acc_ld, void* workspace, int parts, yat_stream_t stream) {
+    if (M <= 0 || rpb <= 0 || M % rpb || (mod_ld & 7) || !x || !dy || parts < 1 || parts > 3) return YAT_EINVAL;
+    if ((parts & 1) && !dx) return YAT_EINVAL;
+    if ((parts & 2) && (!workspace || !dshift_acc || !dscale_acc)) return YAT_EINVAL;
     const int B = M / rpb;
-    int rc = dispatch_maxv(D, [&](auto mv) {
+    int rc = !(parts & 1) ? YAT_OK : dispatch_maxv(D, [&](auto mv) {
         constexpr int MV = decltype(mv)::value;
         hipLaunchKernelGGL((ln_mod_bwd_rows_kernel<MV>), dim3((M + WAVES - 1) / WAVES), dim3(256), 0, (hipStream_t)stream, M,
                            D, rpb, (const bf16_t*)x, mean, rstd, (const bf16_t*)scale, mod_ld, (const bf16_t*)dy,
@@ -432,7 +433,7 @@ int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean,
         YAT_CHECK_LAUNCH();
         return YAT_OK;
     });
-    if (rc) return rc;
+    if (rc || !(parts & 2)) return rc;
     const int gy = (rpb + WAVES * 32 - 1) / (WAVES * 32);
     hipLaunchKernelGGL(ln_mod_bwd_cols_kernel, dim3((D + 511) / 512, gy, B), dim3(256), 0, (hipStream_t)stream, rpb, D,
                        (const bf16_t*)x, mean, rstd, (const bf16_t*)dy, (float*)workspace);

@@ -465,7 +465,7 @@ int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q,
 int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
                  const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,
-                 int n_work, yat_stream_t stream) {
+                 int n_work, int parts, yat_stream_t stream) {
     if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddkv & 3) || !q || !k || !v ||
         !key_bias || !out || !dout || !lse || !delta || !dq || !dk || !dv)
         return YAT_EINVAL;
@@ -488,8 +488,12 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
     p.bias_bytes = (uint64_t)B * T * 4;
     p.stat_bytes = (uint64_t)B * H * N * 4;
-    hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), DQ_LDS, (hipStream_t)stream, p);
-    YAT_CHECK_LAUNCH();
+    if (parts < 1 || parts > 3) return YAT_EINVAL;
+    if (parts & 1) {                               // dQ, and delta = rowsum(dO * O) which the dK/dV part reads
+        hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), DQ_LDS, (hipStream_t)stream, p);
+        YAT_CHECK_LAUNCH();
+    }
+    if (!(parts & 2)) return YAT_OK;
     if (work_list && n_work > 0) {
         p.work = work_list; p.n_work = n_work;
         hipLaunchKernelGGL(sdpa_bwd_dkv_kernel, dim3(n_work, H, 1), dim3(256), DKV_LDS, (hipStream_t)stream, p);

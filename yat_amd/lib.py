@@ -37,7 +37,7 @@ SIGNATURES = {
     "yat_modulation_bwd": (I, [I, I, I, P, P, I, P, I, I, P]),
     "yat_ln_bwd_workspace_bytes": (U64, [I, I, I]),
     "yat_ln_modulate_fwd": (I, [I, I, I, F, P, P, P, I, P, P, P, P]),
-    "yat_ln_modulate_bwd": (I, [I, I, I, P, P, P, P, I, P, P, P, P, P, I, P, P]),
+    "yat_ln_modulate_bwd": (I, [I, I, I, P, P, P, P, I, P, P, P, P, P, I, P, I, P]),
     "yat_rmsnorm_bwd_workspace_bytes": (U64, [I, I]),
     "yat_rmsnorm_fwd": (I, [I, I, F, P, P, P, P, P]),
     "yat_rmsnorm_bwd": (I, [I, I, P, P, P, P, P, P, I, P, P]),
@@ -45,7 +45,7 @@ SIGNATURES = {
     "yat_linear_attn_fwd": (I, [I, I, I, P, I, I, I, P, I, P, P]),
     "yat_linear_attn_bwd": (I, [I, I, I, P, I, I, I, P, I, P, I, P, P, P]),
     "yat_sdpa_fwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, P]),
-    "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P, I, P]),
+    "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P, I, I, P]),
     "yat_dwconv_glu_bwd_workspace_bytes": (U64, [I, I, I, I]),
     "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P]),
     "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, I, P, P]),

@@ -179,10 +179,12 @@ def ln_bwd_workspace_bytes(M, D, rpb):
 
 
 def ln_modulate_bwd(x2d, mean, rstd, scale, mod_ld, rows_per_batch, dy, dres, dx, dshift_acc, dscale_acc, acc_ld,
-                    workspace):
+                    workspace, parts=3):
+    """parts: 1 = dx only, 2 = dshift/dscale accumulators only, 3 = both (see include/yat_hip.h)."""
     M, D = x2d.shape
     rc = _lib().yat_ln_modulate_bwd(M, D, rows_per_batch, _p(x2d), _p(mean), _p(rstd), _p(scale), mod_ld, _p(dy),
-                                    _p(dres), _p(dx), _p(dshift_acc), _p(dscale_acc), acc_ld, _p(workspace), _stream())
+                                    _p(dres), _p(dx), _p(dshift_acc), _p(dscale_acc), acc_ld, _p(workspace), parts,
+                                    _stream())
     _l.check(rc, "yat_ln_modulate_bwd")
     return dx
 
@@ -246,12 +248,14 @@ def kv_work_list(lens, T, device):
     return torch.tensor(pairs, dtype=torch.int32).to(device, non_blocking=True)
 
 
-def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv, work=None):
+def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv, work=None,
+             parts=3):
+    """parts: 1 = dQ + delta, 2 = dK/dV (after part 1, possibly on another stream), 3 = both."""
     assert k2d.stride(0) == v2d.stride(0) and dk.stride(0) == dv.stride(0)
     rc = _lib().yat_sdpa_bwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                              _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
                              _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0), _p(work),
-                             0 if work is None else work.shape[0], _stream())
+                             0 if work is None else work.shape[0], parts, _stream())
     _l.check(rc, "yat_sdpa_bwd")
 
 

@@ -537,19 +537,30 @@ class SanaTransformer2DModelHIP(nn.Module):
                 main.wait_event(set_done[par])                # block i+2's weight gradients have read this set
                 set_done[par] = None
             mod2d = A.mod.view(B, 6 * D)
-            dmod = buf("dmod", (B, 6, D), f32).zero_()
+            dmod = buf(f"dmod.{par}", (B, 6, D), f32).zero_()
             dmod2d = dmod.view(B, 6 * D)
             deferred = []                                     # (dy, x, dW) of this block
+
+            def off_chain(fn):
+                """Work nobody downstream on the dependent chain reads: side stream, right behind its producer."""
+                if side is None:
+                    fn()
+                    return
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    fn()
 
             def emit(dy_, x_, gw_, bias=None):
                 if self.defer_wgrad or side is None:
                     deferred.append((dy_, x_, gw_))
                     return
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
+
+                def run():
                     ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
                     if bias is not None:
                         ops.colsum(dy_, bias, ws_col, accumulate=acc)
+                off_chain(run)
+
             # x3 = x2 + gate_mlp * lin3
             dlin3 = buf(f"dlin3.{par}", (M, D))
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
@@ -561,18 +572,28 @@ class SanaTransformer2DModelHIP(nn.Module):
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
                                dz_colsum=G[pre + "ff.conv_inverted.bias"])                # bias gradient in the same pass
             emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D))
-            dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf("dh", (M, D)))
+            dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf(f"dh2.{par}", (M, D)))
             other = dxb if dx is dxa else dxa
-            dx2 = ops.ln_modulate_bwd(A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2_, dx, buf(f"dx2.{par}", (M, D)),
-                                      dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln)
+            # LayerNorm backward: dx on the chain; the shift/scale gradients (column statistics) feed only the
+            # modulation tables and go to the side stream
+            ln2 = (A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2_)
+            dx2 = ops.ln_modulate_bwd(*ln2, dx, buf(f"dx2.{par}", (M, D)), dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D],
+                                      6 * D, ws_ln, parts=1 if side is not None else 3)
+            if side is not None:
+                off_chain(lambda ln2=ln2, dmod2d=dmod2d: ops.ln_modulate_bwd(
+                    *ln2, None, None, dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln, parts=2))
             # x2 = x1 + to_out(o2)
             emit(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"])
-            do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf("dh", (M, D)))
+            do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf(f"do2.{par}", (M, D)))
             dq2 = buf(f"dq2.{par}", (M, D))
             dkv2 = buf(f"dkv2.{par}", (Mt, 2 * D))
-            delta = buf("delta", (B, H2, N), f32)
-            ops.sdpa_bwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse,
-                         delta, dq2, dkv2[:, :D], dkv2[:, D:], work=S.kv_work)
+            delta = buf(f"delta.{par}", (B, H2, N), f32)
+            sd = (A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse, delta,
+                  dq2, dkv2[:, :D], dkv2[:, D:])
+            # cross-attention backward: dQ (+delta) on the chain, dK/dV -- read only by the text-side gradients -- behind it
+            ops.sdpa_bwd(*sd, work=S.kv_work, parts=1 if side is not None else 3)
+            if side is not None:
+                off_chain(lambda sd=sd: ops.sdpa_bwd(*sd, work=S.kv_work, parts=2))
             emit(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"])
             dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
@@ -588,10 +609,16 @@ class SanaTransformer2DModelHIP(nn.Module):
             ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
             emit(dqkv, A.h1, gqkv)
-            dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf("dh", (M, D)))
-            dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1, dx1, dx,
-                                     dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln)
-            ops.modulation_bwd(dmod, G[pre + "scale_shift_table"], dtmod, D, accumulate_table=acc)
+            dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf(f"dh1.{par}", (M, D)))
+            ln1 = (A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1)
+            dx = ops.ln_modulate_bwd(*ln1, dx1, dx, dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln,
+                                     parts=1 if side is not None else 3)
+
+            def table_grads(ln1=ln1, dmod=dmod, dmod2d=dmod2d, pre=pre):
+                if side is not None:
+                    ops.ln_modulate_bwd(*ln1, None, None, dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln, parts=2)
+                ops.modulation_bwd(dmod, G[pre + "scale_shift_table"], dtmod, D, accumulate_table=acc)
+            off_chain(table_grads)
 
             def block_grads(deferred=deferred, dx2=dx2, dq2=dq2, dkv2=dkv2, wkv=wkv, gbkv=gbkv, pre=pre,
                             first=(i == cfg.num_layers - 1)):
