@@ -50,11 +50,27 @@ for name, lay, m, n, k in SHAPES:
                 else:
                     err = ((out.float() - ref).norm() / ref.norm()).item()
                     assert err < 2e-3, (name, v, err)
+    # YARDSTICK ONLY (never used by the product path): the vendor library through torch.matmul on the same operands,
+    # to know how far a hand-written kernel is from what the platform's tuned GEMM reaches on this shape.
+    ta = a.t() if a_t else a
+    tb = b if b_t else b.t()
+    lib_t = []
+    for r in range(rounds + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            torch.matmul(ta, tb, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        if r > 0:
+            lib_t.append(e0.elapsed_time(e1) / 3)
     fl = 2.0 * m * n * k
+    lib_tf = fl / (sorted(lib_t)[len(lib_t) // 2] * 1e-3) / 1e12
     line = {v: (fl / (sorted(t)[len(t) // 2] * 1e-3) / 1e12 if t else 0.0) for v, t in times.items()}
     res[name] = line
     print(f"{name:12s} {lay} {m:6d}x{n:6d}x{k:6d}  v128={line[1]:7.1f}  v256={line[4]:7.1f}  v320={line[5]:7.1f}  "
-          f"2x256={line[204]:7.1f}  2x320={line[205]:7.1f}  4x320={line[405]:7.1f}  auto={line[0]:7.1f} TF", flush=True)
+          f"2x256={line[204]:7.1f}  2x320={line[205]:7.1f}  4x320={line[405]:7.1f}  auto={line[0]:7.1f} TF   "
+          f"[vendor lib yardstick {lib_tf:7.1f}]", flush=True)
 tot_fl = {v: 0.0 for v in (1, 4, 5, 0)}
 tot_t = {v: 0.0 for v in (1, 4, 5, 0)}
 import torch as _t

@@ -637,17 +637,20 @@ class SanaTransformer2DModelHIP(nn.Module):
 
             if side is None:
                 block_grads()
+                if self.grad_ready is not None:
+                    self.grad_ready(i + 1)
             else:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     block_grads()
+                    # bucket i+1 is complete once the side stream gets here (it has waited for the main stream's
+                    # share: the fused bias / depthwise gradients); the DDP hook records its event on the CURRENT
+                    # stream, so the all-reduce follows the side stream and the dependent chain never waits for it
+                    if self.grad_ready is not None:
+                        self.grad_ready(i + 1)
                     ev = torch.cuda.Event()
                     ev.record(side)
                 set_done[par] = ev
-            if self.grad_ready is not None:
-                if side is not None:
-                    main.wait_stream(side)
-                self.grad_ready(i + 1)
         # ---- embedders (small: back on the main stream)
         if side is not None:
             main.wait_stream(side)
