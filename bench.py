@@ -277,15 +277,25 @@ def main():
             gf = sum(t[0] for t in timer)
             gms = sum(t[1].elapsed_time(t[2]) for t in timer)
             ach = gf / (gms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN, all epilogues)",
+            # HBM traffic of the same kernel family per launch, from the committed PMC passes (collected separately, as
+            # the profiling guide prescribes: --pmc runs cannot be combined with the timed run)
+            traffic, traffic_src = None, None
+            tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gemm_traffic.json")
+            if os.path.exists(tj):
+                with open(tj) as f:
+                    tdat = json.load(f)
+                traffic, traffic_src = tdat["hbm_bytes_per_launch"], tdat["source"]
+            alg_bytes = sum(t[4] for t in timer if len(t) > 4) / max(1, sum(1 for t in timer if len(t) > 4))
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel / gemm_bf16_kernel (NT/NN/TN, all epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                               "traffic_source": traffic_src, "algorithmic_operand_bytes_per_launch": alg_bytes,
                                "mode": f"serialized-stream pass of {args.roofline_steps} steps after the timed region",
                                "launches": len(timer), "avg_launch_us": 1e3 * gms / len(timer),
                                "gemm_ms_per_step_serialized": gms / args.roofline_steps}
         if timer and args.gemm_detail:
             agg = {}
-            for fl, e0, e1, key in timer:
+            for fl, e0, e1, key, *_ in timer:
                 a = agg.setdefault(key, [0, 0.0, fl])
                 a[0] += 1
                 a[1] += e0.elapsed_time(e1)

@@ -78,8 +78,9 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
                                  C.byref(ep) if ep is not None else None, variant, _p(ws), ws.numel(), _stream())
     if timer is not None:
         e1.record()
-        timer.append((2.0 * M * N * K, e0, e1, ("tn"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
-                      gate is not None, residual is not None, aux_out is not None)))
+        nbytes = 2.0 * (M * K + K * N + M * N * (1 + (residual is not None) + (aux_out is not None)))
+        timer.append((2.0 * M * N * K, e0, e1, ("nt"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
+                      gate is not None, residual is not None, aux_out is not None), nbytes))
     _l.check(rc, "yat_gemm_bf16")
     return out
 
@@ -133,7 +134,7 @@ def wgrad_grouped(items, accumulate=False):
     rc = _lib().yat_gemm_grouped_bf16(1, 1, n, probs, _stream())
     if timer is not None:
         e1.record()
-        timer.append((flops, e0, e1, ("tn", 0, 0, 0, f"grouped x{n}", False, accumulate, False)))
+        timer.append((flops, e0, e1, ("tt", 0, 0, 0, f"grouped x{n}", False, accumulate, False)))
     _l.check(rc, "yat_gemm_grouped_bf16")
 
 
