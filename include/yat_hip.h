@@ -38,6 +38,9 @@ typedef struct yat_gemm_epilogue {
     const void* gate;      /* bf16 [M/rows_per_batch, ld_gate] or NULL: v = gate[b, n] * v          */
     const void* residual;  /* bf16 [M, ld_residual] or NULL: v += residual[m, n]  (may alias C)     */
     int ld_aux, ld_gate, ld_residual, rows_per_batch;
+    const void* glu_u;     /* bf16 [M, ld_glu_u] = [u_a | u_g] (N columns each) or NULL.  GLU backward fused into the */
+    int ld_glu_u;          /* GEMM that produces dy (GLUMBConv conv_point dgrad): with d = bf16(result), C is [M, 2N]:  */
+                           /* C[m,n] = d*bf16(SiLU(u_g)), C[m,N+n] = bf16(d*u_a)*SiLU'(u_g); excludes the other options */
 } yat_gemm_epilogue;
 
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
@@ -153,13 +156,16 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
  * bwd: dz (bf16, includes the SiLU derivative), dwdw / dbdw partial sums reduced via workspace;
  *      dz_colsum_bf16 (nullable, [2Hc]) (+)= sum over pixels of dz: the bias gradient of conv_inverted, taken in the
  *      same pass instead of a separate yat_colsum_bf16 over dz.
+ * fwd u_out (nullable, bf16 [B,h,w,2Hc]): the conv output u (pre-GLU) kept for the backward;
+ * bwd du_in (nullable, bf16 [B,h,w,2Hc]): du already computed (yat_gemm_epilogue.glu_u in the GEMM that produces dy,
+ *      from the kept u) -- pass 1 (recompute u, GLU backward) is skipped and `dy` / `s`-recompute are not needed.
  * ------------------------------------------------------------------------------------------ */
 uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc);
 int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* wdw, const void* bdw, void* y,
-                       yat_stream_t stream);
+                       void* u_out, yat_stream_t stream);
 int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z, const void* wdw, const void* bdw,
                        const void* dy, void* dz, void* dwdw_bf16, void* dbdw_bf16, void* dz_colsum_bf16, int accumulate,
-                       void* workspace, yat_stream_t stream);
+                       void* workspace, const void* du_in, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * gated residual backward: out = res + bf16(gate[b,:] * lin)   (patch_sana_attention_layers.py:95,113)

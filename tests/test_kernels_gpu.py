@@ -521,6 +521,40 @@ def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     close(dzs, dz.float().sum(0).to(BF), f"dwconv_dz_colsum {h}x{w}x{Hc}", atol=1e-2)
 
 
+@pytest.mark.parametrize("B,h,w,Hc,Dm", [(2, 8, 8, 40, 64), (1, 16, 64, 160, 96), (2, 32, 32, 320, 264), (1, 3, 70, 8, 32)])
+def test_glu_backward_in_gemm_epilogue(ops, B, h, w, Hc, Dm):
+    """The forward keeps u = dwconv(s)+b; the GEMM that produces dy (conv_point dgrad) applies the GLU backward in its
+    epilogue.  Must be bit-identical to the unfused path (dy GEMM -> depthwise backward pass 1 -> pass 2)."""
+    M = B * h * w
+    z = rnd(M, 2 * Hc, seed=50)
+    s_act = F.silu(z.float()).to(BF)
+    wdw, bdw = rnd(2 * Hc, 9, scale=1 / 3, seed=51), rnd(2 * Hc, scale=0.1, seed=52)
+    y, y2, u = (torch.empty(M, c, dtype=BF, device=DEV) for c in (Hc, Hc, 2 * Hc))
+    ops.dwconv_glu_fwd(s_act, B, h, w, Hc, wdw, bdw, y)
+    ops.dwconv_glu_fwd(s_act, B, h, w, Hc, wdw, bdw, y2, u_out=u)
+    assert torch.equal(y, y2)
+    si = s_act.float().view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
+    uref = F.conv2d(si, wdw.float().view(2 * Hc, 1, 3, 3), bdw.float(), padding=1, groups=2 * Hc)
+    close(u, uref.permute(0, 2, 3, 1).reshape(M, 2 * Hc).to(BF), f"dwconv_u {h}x{w}x{Hc}")
+    ua, ug = u[:, :Hc].float(), u[:, Hc:].float()
+    assert torch.equal(y.float(), (ua * F.silu(ug).to(BF).float()).to(BF).float())      # y is exactly GLU(u)
+    dlin, wp = rnd(M, Dm, scale=0.2, seed=53), rnd(Dm, Hc, scale=Dm ** -0.5, seed=54)   # conv_point: [D, Hc]
+    ws = torch.empty(ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc), dtype=torch.uint8, device=DEV)
+    outs = []
+    for fused in (False, True):
+        dz, dw, db = torch.empty_like(z), torch.empty_like(wdw), torch.empty_like(bdw)
+        if fused:
+            du = torch.empty(M, 2 * Hc, dtype=BF, device=DEV)
+            ops.linear_dgrad_glu(dlin, wp, u, du)
+            ops.dwconv_glu_bwd(s_act, z, B, h, w, Hc, wdw, bdw, None, dz, dw, db, ws, du=du)
+        else:
+            dy = ops.linear_dgrad(dlin, wp)
+            ops.dwconv_glu_bwd(s_act, z, B, h, w, Hc, wdw, bdw, dy, dz, dw, db, ws)
+        outs.append((dz, dw, db))
+    for a, b_, nm in zip(outs[0], outs[1], ("dz", "dw", "db")):
+        assert torch.equal(a, b_), f"fused GLU backward changes {nm}"
+
+
 # ------------------------------------------------------------------------------------------------ elementwise / recipe
 def test_elementwise(ops):
     x, dy = rnd(1000, 37, seed=41), rnd(1000, 37, seed=42)      # numel not a multiple of 8 -> scalar tail

@@ -9,7 +9,9 @@ repeated builds are no-ops.
 from __future__ import annotations
 
 import hashlib
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -51,16 +53,37 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    resources = {}
+
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        # -Rpass-analysis=kernel-resource-usage: per-kernel VGPRs / spills / scratch as compiler remarks (free), kept in
+        # build/resources.json.  A kernel that silently starts using scratch (an innocent-looking epilogue branch did that
+        # to every 256x320 GEMM once: +11 ms per step) fails the build instead of the benchmark.
+        cmd = [hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        cur = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"remark:\s+Function Name: (\S+)", line)
+            if m:
+                cur = resources.setdefault(f"{src}:{m.group(1)}", {})
+                continue
+            m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill|Occupancy \[waves/SIMD\]|"
+                          r"LDS Size \[bytes/block\]): (\d+)", line)
+            if m and cur is not None:
+                cur[m.group(1)] = int(m.group(2))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    with open(os.path.join(objdir, "resources.json"), "w") as f:
+        json.dump(resources, f, indent=1, sort_keys=True)
+    bad = {k: v for k, v in resources.items() if v.get("ScratchSize [bytes/lane]", 0) or v.get("VGPRs Spill", 0)}
+    if bad:
+        raise RuntimeError("kernels using scratch memory / spilling VGPRs (not allowed on this path): "
+                           + json.dumps(bad, indent=1))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

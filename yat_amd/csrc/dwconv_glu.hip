@@ -46,7 +46,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, int nseg, int nx, int B,
                                                          const bf16_t* z /* = SiLU(conv_inverted) */,
                                                          const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
-                                                         bf16_t* out) {
+                                                         bf16_t* out, bf16_t* u_out) {
     const int total = nx * h * nseg * B;
     int u = xcd_unit(total);
     if (u >= total) return;
@@ -111,6 +111,10 @@ __global__ __launch_bounds__(256) void dwconv_glu_kernel(int h, int w, int Hc, i
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ua[e] = rbf(aP[e]); ug[e] = rbf(gP[e]); }
             if (MODE == 0) {
+                if (u_out) {
+                    *reinterpret_cast<u32x2*>(u_out + pix * C2 + ca) = pack4(ua[0], ua[1], ua[2], ua[3]);
+                    *reinterpret_cast<u32x2*>(u_out + pix * C2 + cg) = pack4(ug[0], ug[1], ug[2], ug[3]);
+                }
                 *reinterpret_cast<u32x2*>(out + pix * Hc + ca) =
                     pack4(ua[0] * rbf(silu_f(ug[0])), ua[1] * rbf(silu_f(ug[1])), ua[2] * rbf(silu_f(ug[2])),
                           ua[3] * rbf(silu_f(ug[3])));
@@ -217,8 +221,8 @@ template <int MODE>
 __global__ __launch_bounds__(256, 3) void dwglu_tile_kernel(int h, int w, int Hc, int B, int R, int rmagic, int nbands,
                                                             int bpb, int nchunk, const bf16_t* s, uint64_t s_bytes,
                                                             const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
-                                                            bf16_t* out) {
-    // s_bytes = bytes of the [B,h,w,2Hc] arrays (s, du); dy / y are half that.  All global traffic of the run loop goes
+                                                            bf16_t* out, bf16_t* u_out) {
+    // s_bytes = bytes of the [B,h,w,2Hc] arrays (s, du, u_out); dy / y are half that.  All global traffic of the run loop goes
     // through range-checked buffer instructions: a guarded plain store makes the optimizer sink each output's FMAs into
     // its branch, which keeps three unpacked input columns live (299 VGPRs).
     // A workgroup owns `bpb` consecutive bands of one (image, 32-channel chunk): taps are loaded and the tile cleared once.
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(256, 3) void dwglu_tile_kernel(int h, int w, int Hc
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(s, s_bytes);
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, MODE == 0 ? s_bytes / 2 : s_bytes);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(MODE == 1 ? dy : s, s_bytes / 2);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(u_out ? u_out : out, u_out ? s_bytes : 0);      // forward only, optional
     const bool lane_ch_ok = ch0 + (lane % PPP) * 8 < Hc;
 
   for (int rb = bg * bpb; rb < min(nbands, (bg + 1) * bpb); ++rb) {
@@ -323,6 +328,13 @@ __global__ __launch_bounds__(256, 3) void dwglu_tile_kernel(int h, int w, int Hc
                 for (int pr = 0; pr < 2; ++pr) { A[o % 3][pr] = ba[pr]; G[o % 3][pr] = bg2[pr]; }
                 const bool live = j0 + o < w;
                 if (MODE == 0) {
+                    {   // keep u for the backward (the GLU backward then runs in the dy GEMM's epilogue).  Branch-free:
+                        // without u_out the descriptor has zero records and the range check drops the stores.
+                        const uint32_t uo = live ? (uint32_t)(((pix0 + o) * C2 + ca) * 2) : YAT_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b64(pack4(ua[0], ua[1], ua[2], ua[3]), ru, uo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(pack4(ug[0], ug[1], ug[2], ug[3]), ru,
+                                                              live ? uo + (uint32_t)Hc * 2 : YAT_OOB, 0, 0);
+                    }
                     __builtin_amdgcn_raw_buffer_store_b64(
                         pack4(ua[0] * rbf(silu_f(ug[0])), ua[1] * rbf(silu_f(ug[1])), ua[2] * rbf(silu_f(ug[2])),
                               ua[3] * rbf(silu_f(ug[3]))),
@@ -369,7 +381,7 @@ inline int pick_band_rows(int h, int w, size_t* lds_bytes, int* threads) {
 
 template <int MODE>
 int launch_tile(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
-                bf16_t* out, hipStream_t stream) {
+                bf16_t* out, bf16_t* u_out, hipStream_t stream) {
     size_t lds = 0;
     int threads = 256;
     const int R = pick_band_rows(h, w, &lds, &threads);
@@ -381,7 +393,7 @@ int launch_tile(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw,
     while (bpb > 1 && (int64_t)((nbands + bpb - 1) / bpb) * nchunk * B < 3 * 768) --bpb;
     const int ngrp = (nbands + bpb - 1) / bpb;
     hipLaunchKernelGGL((dwglu_tile_kernel<MODE>), dim3(grid8((int64_t)ngrp * nchunk * B)), dim3(threads), lds, stream, h, w,
-                       Hc, B, R, (65536 + R - 1) / R, nbands, bpb, nchunk, s, s_bytes, wdw, bdw, dy, out);
+                       Hc, B, R, (65536 + R - 1) / R, nbands, bpb, nchunk, s, s_bytes, wdw, bdw, dy, out, u_out);
     return 0;
 }
 
@@ -680,19 +692,19 @@ __global__ void dwconv_reduce_kernel(int P, int C2, const float* ws, bf16_t* dw,
 extern "C" {
 
 int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* wdw, const void* bdw, void* y,
-                       yat_stream_t stream) {
+                       void* u_out, yat_stream_t stream) {
     const void* z = s;
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !z || !wdw || !bdw || !y) return YAT_EINVAL;
     if ((int64_t)h * nseg_of(w) * B * ((Hc / 4 + 63) / 64) * 2 > 0x7fffff00ll) return YAT_EINVAL;
     if (w <= 64 && launch_tile<0>(B, h, w, Hc, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)bdw, nullptr,
-                                  (bf16_t*)y, (hipStream_t)stream) == 0) {
+                                  (bf16_t*)y, (bf16_t*)u_out, (hipStream_t)stream) == 0) {
         YAT_CHECK_LAUNCH();
         return YAT_OK;
     }
     const int nx = (Hc / 4 + 255) / 256;
     hipLaunchKernelGGL((dwconv_glu_kernel<0>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
                        (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)z, (const bf16_t*)wdw,
-                       (const bf16_t*)bdw, (const bf16_t*)nullptr, (bf16_t*)y);
+                       (const bf16_t*)bdw, (const bf16_t*)nullptr, (bf16_t*)y, (bf16_t*)u_out);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
@@ -705,23 +717,26 @@ uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc) {
 
 int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z, const void* wdw, const void* bdw,
                        const void* dy, void* dz, void* dwdw, void* dbdw, void* dz_colsum, int accumulate, void* workspace,
-                       yat_stream_t stream) {
-    if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !s || !z || !wdw || !bdw || !dy || !dz || !dwdw || !dbdw ||
-        !workspace)
+                       const void* du_in, yat_stream_t stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !s || !z || !wdw || !bdw || (!dy && !du_in) || !dz || !dwdw ||
+        !dbdw || !workspace)
         return YAT_EINVAL;
     if ((int64_t)h * nseg_of(w) * B * ((Hc / 4 + 63) / 64) * 2 > 0x7fffff00ll) return YAT_EINVAL;
     const int C2 = 2 * Hc;
     const int gy2 = nrg_of(h) * nsb_of(w);
-    bf16_t* du = (bf16_t*)workspace;
+    const bf16_t* du = du_in ? (const bf16_t*)du_in : (const bf16_t*)workspace;
     const uint64_t du_bytes = ((uint64_t)B * h * w * C2 * 2 + 255) & ~255ull;
     float* ws = (float*)((char*)workspace + du_bytes);
     const int nx = (Hc / 4 + 255) / 256, nx2 = (C2 / 4 + 63) / 64;
-    if (!(w <= 64 && launch_tile<1>(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
-                                    (const bf16_t*)dy, du, (hipStream_t)stream) == 0))
-        hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
-                           (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
-                           (const bf16_t*)bdw, (const bf16_t*)dy, du);
-    YAT_CHECK_LAUNCH();
+    if (!du_in) {                                             // pass 1: recompute u, GLU backward -> du (workspace)
+        bf16_t* duw = (bf16_t*)workspace;
+        if (!(w <= 64 && launch_tile<1>(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
+                                        (const bf16_t*)dy, duw, nullptr, (hipStream_t)stream) == 0))
+            hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
+                               (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
+                               (const bf16_t*)bdw, (const bf16_t*)dy, duw, (bf16_t*)nullptr);
+        YAT_CHECK_LAUNCH();
+    }
     size_t lds2 = 0;
     int threads2 = 256;
     const int R2 = w <= 64 && !(C2 & 7) && du_bytes <= 0x7fffffffull ? pick_band_rows_bwd2(h, w, &lds2, &threads2) : 0;

@@ -192,6 +192,9 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
         p.act = ep->activation;
         if (p.act < 0 || p.act > 2) return YAT_EINVAL;
         if (p.gate && (p.gate_ld & 3)) return YAT_EINVAL;
+        p.glu_u = (const bf16_t*)ep->glu_u; p.ld_glu = ep->ld_glu_u;
+        if (p.glu_u && (p.bias || p.gate || p.res || p.aux || p.act || (p.ld_glu & 3) || p.ld_glu < 2 * N || ldc < 2 * N))
+            return YAT_EINVAL;
     }
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
@@ -227,7 +230,11 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (rc) return rc;
     }
     const bool wide_ok = !(N & 7) && !(ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
-                         !(p.gate && (p.gate_ld & 7));
+                         !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7));
+    if (p.glu_u) {                              // GLU-backward epilogue lives in the 256-row kernel only
+        if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
+        if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
+    }
     if (variant == 0) {
         variant = 1;
         if (M >= 1024 && N >= 512 && K >= 256) {

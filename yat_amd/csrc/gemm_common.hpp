@@ -15,7 +15,41 @@ struct GemmP {
     uint64_t a_bytes, b_bytes;
     int ksplit;            // gemm256 only: > 1 -> each workgroup reduces K/ksplit and stores an fp32 partial slab
     float* partial;        // [ksplit][M][N] fp32 (caller workspace)
+    const bf16_t* glu_u;   // GLU backward epilogue: u = [u_a | u_g] of the depthwise conv, [M, ld_glu]; C is [M, 2N]
+    int ld_glu;
 };
+
+// GLU backward fused into the producer of dy (= this GEMM's result d, rounded to bf16 like the Linear's output):
+//   y = u_a * SiLU(u_g)  ->  du_a = d * bf16(SiLU(u_g)),  du_g = bf16(d * u_a) * SiLU'(u_g)
+// -- exactly the arithmetic of the depthwise kernel's backward pass 1, which this replaces.
+// Compiled only into the GLU instantiation of gemm256 (as a runtime branch of the shared epilogue it pushed the
+// accumulators of every 256x320 kernel into scratch: +11 ms per step).
+template <int W>
+__device__ __forceinline__ void glu_bwd_store(const GemmP& p, const float (&v)[W], int m, int n) {
+    float ua[W], ug[W], da[W], dg[W];
+    const bf16_t* up = p.glu_u + (int64_t)m * p.ld_glu + n;
+    if (W == 8) {
+        unpack8(*reinterpret_cast<const u32x4*>(up), ua);
+        unpack8(*reinterpret_cast<const u32x4*>(up + p.N), ug);
+    } else {
+        unpack4(*reinterpret_cast<const u32x2*>(up), ua);
+        unpack4(*reinterpret_cast<const u32x2*>(up + p.N), ug);
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const float d = rbf(v[e]);
+        da[e] = d * rbf(silu_f(ug[e]));
+        dg[e] = rbf(d * ua[e]) * dsilu_f(ug[e]);
+    }
+    bf16_t* cp = p.C + (int64_t)m * p.ldc + n;
+    if (W == 8) {
+        *reinterpret_cast<u32x4*>(cp) = pack8(da);
+        *reinterpret_cast<u32x4*>(cp + p.N) = pack8(dg);
+    } else {
+        *reinterpret_cast<u32x2*>(cp) = pack4(da[0], da[1], da[2], da[3]);
+        *reinterpret_cast<u32x2*>(cp + p.N) = pack4(dg[0], dg[1], dg[2], dg[3]);
+    }
+}
 
 // One lane's 4 consecutive output columns of row m (swapped-operand MFMA result):
 // +bias -> round bf16 (the Linear's output) -> aux store -> activation -> *gate (rounded) -> +residual -> store.

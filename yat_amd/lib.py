@@ -17,7 +17,8 @@ P, I, I64, U64, F, D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.
 
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
-                ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I)]
+                ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I),
+                ("glu_u", P), ("ld_glu_u", I)]
 
 
 class GemmProblem(C.Structure):
@@ -47,8 +48,8 @@ SIGNATURES = {
     "yat_sdpa_fwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, P]),
     "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P, I, I, P]),
     "yat_dwconv_glu_bwd_workspace_bytes": (U64, [I, I, I, I]),
-    "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P]),
-    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, I, P, P]),
+    "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P, P]),
+    "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, I, P, P, P]),
     "yat_gate_bwd_workspace_bytes": (U64, [I, I, I]),
     "yat_gate_bwd": (I, [I, I, I, P, P, P, I, P, P, I, P, I, P, P]),
     "yat_act_fwd": (I, [I64, I, P, P, P]),

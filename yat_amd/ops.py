@@ -59,16 +59,18 @@ def _chk_bf16(*ts):
 
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
-         activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0):
+         activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
+         glu_u=None):
     """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
-    _chk_bf16(a, b, out, bias, aux_out, gate, residual)
+    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u)
     lda = lda if lda is not None else (M if a_t else K)
     ldb = ldb if ldb is not None else (N if b_t else K)
     ldc = ldc if ldc is not None else N
     ep = None
-    if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None:
+    if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None \
+            or glu_u is not None:
         ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
-                             ld_residual, rows_per_batch)
+                             ld_residual, rows_per_batch, _p(glu_u), 0 if glu_u is None else glu_u.stride(0))
     timer = GEMM_TIMER
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,7 +80,8 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
                                  C.byref(ep) if ep is not None else None, variant, _p(ws), ws.numel(), _stream())
     if timer is not None:
         e1.record()
-        nbytes = 2.0 * (M * K + K * N + M * N * (1 + (residual is not None) + (aux_out is not None)))
+        nbytes = 2.0 * (M * K + K * N + M * N * (1 + (residual is not None) + (aux_out is not None) +
+                                                 3 * (glu_u is not None)))
         timer.append((2.0 * M * N * K, e0, e1, ("nt"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
                       gate is not None, residual is not None, aux_out is not None), nbytes))
     _l.check(rc, "yat_gemm_bf16")
@@ -99,6 +102,15 @@ def linear_dgrad(dy2d, w, out=None, **ep):
     K = w.shape[1]
     out = out if out is not None else torch.empty(M, K, dtype=BF16, device=dy2d.device)
     return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, **ep)
+
+
+def linear_dgrad_glu(dy2d, w, u, du):
+    """GLUMBConv conv_point dgrad with the GLU backward in its epilogue: d = dy W ([M, Hc]) never reaches memory;
+    du[:, :Hc] = d * SiLU(u_g), du[:, Hc:] = (d * u_a) * SiLU'(u_g) with u = [u_a | u_g] kept by the forward."""
+    M, N = dy2d.shape
+    K = w.shape[1]
+    assert u.shape == (M, 2 * K) and du.shape == (M, 2 * K)
+    return gemm(dy2d, w, du, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=2 * K, glu_u=u)
 
 
 def linear_wgrad(dy2d, x2d, out, accumulate=False):
@@ -124,7 +136,7 @@ def wgrad_grouped(items, accumulate=False):
         pr.M, pr.N, pr.K = N, K, M
         pr.A, pr.lda, pr.B, pr.ldb, pr.C, pr.ldc = _p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), K
         if accumulate:
-            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out), 0, 0, K, 0)
+            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out), 0, 0, K, 0, None, 0)
             pr.epilogue = C.pointer(eps[i])
         flops += 2.0 * M * N * K
     timer = GEMM_TIMER
@@ -261,9 +273,10 @@ def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, 
 
 
 # ----------------------------------------------------------------------------------------------- GLUMBConv middle
-def dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y):
-    """s = bf16(SiLU(conv_inverted output)) as written by the GEMM epilogue."""
-    rc = _lib().yat_dwconv_glu_fwd(B, h, w, Hc, _p(s), _p(wdw), _p(bdw), _p(y), _stream())
+def dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y, u_out=None):
+    """s = bf16(SiLU(conv_inverted output)) as written by the GEMM epilogue; ``u_out`` (optional [M, 2Hc]) keeps the conv
+    output for the backward (see ``linear_dgrad_glu`` / ``dwconv_glu_bwd(du=...)``)."""
+    rc = _lib().yat_dwconv_glu_fwd(B, h, w, Hc, _p(s), _p(wdw), _p(bdw), _p(y), _p(u_out), _stream())
     _l.check(rc, "yat_dwconv_glu_fwd")
     return y
 
@@ -272,10 +285,11 @@ def dwconv_glu_bwd_workspace_bytes(B, h, w, Hc):
     return int(_lib().yat_dwconv_glu_bwd_workspace_bytes(B, h, w, Hc))
 
 
-def dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False, dz_colsum=None):
-    """``dz_colsum`` (optional, [2Hc]) (+)= column sum of dz (the conv_inverted bias gradient) in the same pass."""
+def dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False, dz_colsum=None, du=None):
+    """``dz_colsum`` (optional, [2Hc]) (+)= column sum of dz (the conv_inverted bias gradient) in the same pass.
+    ``du`` (optional [M, 2Hc]): the GLU backward already applied (``linear_dgrad_glu``); ``dy`` may then be None."""
     rc = _lib().yat_dwconv_glu_bwd(B, h, w, Hc, _p(s), _p(z), _p(wdw), _p(bdw), _p(dy), _p(dz), _p(dwdw), _p(dbdw),
-                                   _p(dz_colsum), int(accumulate), _p(workspace), _stream())
+                                   _p(dz_colsum), int(accumulate), _p(workspace), _p(du), _stream())
     _l.check(rc, "yat_dwconv_glu_bwd")
 
 

@@ -165,6 +165,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         self.bucket_bounds = self._make_buckets(specs, offs, off)
         self.grad_ready = None            # callable(bucket_index) set by HipDDP
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"   # weight gradients on a second stream
+        self.keep_glu_u = os.environ.get("YAT_KEEP_GLU_U", "1") != "0"         # keep the depthwise-conv output (183 MB/block)
         self.fwd_chains = int(os.environ.get("YAT_FWD_CHAINS", "2"))           # independent forward chains (image ranges)
         self._chains = {}
         self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
@@ -367,6 +368,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             A.h2, A.mean2, A.rstd2 = buf(f"b{i}.h2", (M, D)), buf(f"b{i}.mean2", (M,), f32), buf(f"b{i}.rstd2", (M,), f32)
             A.z, A.s = buf(f"b{i}.z", (M, 2 * Hc)), buf(f"b{i}.s", (M, 2 * Hc))          # z: pre-activation, for SiLU'
             A.y, A.lin3, A.x3 = buf(f"b{i}.y", (M, Hc)), buf(f"b{i}.lin3", (M, D)), buf(f"b{i}.x3", (M, D))
+            A.u = buf(f"b{i}.u", (M, 2 * Hc)) if self.keep_glu_u else None      # depthwise-conv output, for the backward
             A.x_in = x if i == 0 else S.blocks[i - 1].x3
             S.blocks.append(A)
         S.x_last = S.blocks[-1].x3 if cfg.num_layers else x
@@ -408,7 +410,7 @@ class SanaTransformer2DModelHIP(nn.Module):
                 ops.linear_fwd(A.h2[rs], P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), P[pre + "ff.conv_inverted.bias"],
                                out=A.s[rs], activation="silu", aux_out=A.z[rs])
                 ops.dwconv_glu_fwd(A.s[rs], nb, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
-                                   P[pre + "ff.conv_depth.bias"], A.y[rs])
+                                   P[pre + "ff.conv_depth.bias"], A.y[rs], u_out=None if A.u is None else A.u[rs])
                 ops.linear_fwd(A.y[rs], P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=A.x3[rs], aux_out=A.lin3[rs],
                                gate=mod2d[:, 5 * D:6 * D], ld_gate=6 * D, residual=A.x2[rs], rows_per_batch=N)
             # output head: modulated norm + proj_out + unpatchify
@@ -565,12 +567,18 @@ class SanaTransformer2DModelHIP(nn.Module):
             dlin3 = buf(f"dlin3.{par}", (M, D))
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
             emit(dlin3, A.y, G[pre + "ff.conv_point.weight"].view(D, Hc))
-            dy = ops.linear_dgrad(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
             dz = buf(f"dz.{par}", (M, 2 * Hc))
+            if A.u is not None:
+                # the GLU backward runs in the epilogue of the GEMM that produces dy (dy itself never reaches memory);
+                # the depthwise kernel's first backward pass (recompute u, 156 us) disappears
+                du_, dy = ops.linear_dgrad_glu(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), A.u,
+                                               buf("du", (M, 2 * Hc))), None
+            else:
+                du_, dy = None, ops.linear_dgrad(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
             ops.dwconv_glu_bwd(A.s, A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
-                               dz_colsum=G[pre + "ff.conv_inverted.bias"])                # bias gradient in the same pass
+                               dz_colsum=G[pre + "ff.conv_inverted.bias"], du=du_)        # bias gradient in the same pass
             emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D))
             dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf(f"dh2.{par}", (M, D)))
             other = dxb if dx is dxa else dxa
