@@ -168,6 +168,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         self.keep_glu_u = os.environ.get("YAT_KEEP_GLU_U", "1") != "0"         # keep the depthwise-conv output (183 MB/block)
         self.fwd_chains = int(os.environ.get("YAT_FWD_CHAINS", "2"))           # independent forward chains (image ranges)
         self._chains = {}
+        self.group_small_wgrad = os.environ.get("YAT_GROUP_SMALL_WGRAD", "1") != "0"   # D x D weight gradients grouped
         self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
         self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
         self._side = None
@@ -552,9 +553,14 @@ class SanaTransformer2DModelHIP(nn.Module):
                 with torch.cuda.stream(side):
                     fn()
 
-            def emit(dy_, x_, gw_, bias=None):
+            small = []                                        # the three D x D weight gradients: one grouped launch
+
+            def emit(dy_, x_, gw_, bias=None, group=False):
                 if self.defer_wgrad or side is None:
                     deferred.append((dy_, x_, gw_))
+                    return
+                if group and self.group_small_wgrad:
+                    small.append((dy_, x_, gw_, bias))
                     return
 
                 def run():
@@ -591,7 +597,7 @@ class SanaTransformer2DModelHIP(nn.Module):
                 off_chain(lambda ln2=ln2, dmod2d=dmod2d: ops.ln_modulate_bwd(
                     *ln2, None, None, dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln, parts=2))
             # x2 = x1 + to_out(o2)
-            emit(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"])
+            emit(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"], group=True)
             do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf(f"do2.{par}", (M, D)))
             dq2 = buf(f"dq2.{par}", (M, D))
             dkv2 = buf(f"dkv2.{par}", (Mt, 2 * D))
@@ -602,7 +608,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             ops.sdpa_bwd(*sd, work=S.kv_work, parts=1 if side is not None else 3)
             if side is not None:
                 off_chain(lambda sd=sd: ops.sdpa_bwd(*sd, work=S.kv_work, parts=2))
-            emit(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"])
+            emit(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"], group=True)
             dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
@@ -611,7 +617,16 @@ class SanaTransformer2DModelHIP(nn.Module):
             dlin1 = buf(f"dlin1.{par}", (M, D))
             ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin1, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate,
                          dbias=G[pre + "attn1.to_out.0.bias"], accumulate_bias=acc)       # bias gradient in the same pass
-            emit(dlin1, A.attn, G[pre + "attn1.to_out.0.weight"])
+            emit(dlin1, A.attn, G[pre + "attn1.to_out.0.weight"], group=True)
+            if small:
+                # 2240 x 2240 x 8192 each: 81 tiles of 256 x 256 -- alone they need split-K (fp32 slabs + a reduce launch);
+                # together 243 full-K tiles fill the 256 CUs in one round
+                def small_grads(small=small):
+                    ops.wgrad_grouped([(a, b, c) for a, b, c, _ in small], accumulate=acc)
+                    for a, _, _, bias_ in small:
+                        if bias_ is not None:
+                            ops.colsum(a, bias_, ws_col, accumulate=acc)
+                off_chain(small_grads)
             dattn = ops.linear_dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf(f"dqkv.{par}", (M, 3 * D))
             ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
