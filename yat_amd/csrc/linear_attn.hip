@@ -228,6 +228,20 @@ __global__ __launch_bounds__(256) void la_fwd_kernel(int N, int H, const bf16_t*
     }
 }
 
+// Bank-conflict swizzles of the wave-private images of the backward q kernel (rows = tokens).  Both images are written
+// row-wise and read with ds_read_b64_tr_b16, whose 32-lane halves fetch a 32-B block from token rows {0..3, 8..11} + 4n:
+//  * dU images, 128-B rows: consecutive rows already alternate between the two halves of the 256-B bank row; XOR the
+//    16-B chunk index with 2 bits taken from row bits 1 and 3 (bit 0 of the chunk untouched: a 32-B block stays whole);
+//  * q image, 64-B rows: rows r and r+8 would hit the same banks -> swap the row's two 32-B blocks when bit 3 is set.
+// (unswizzled, 86 % of this kernel's LDS cycles were bank conflicts: PMC, profiles/r01_g_pmc_per_kernel.txt)
+__device__ __forceinline__ uint32_t du_off(uint32_t row, uint32_t byte) {
+    const uint32_t sw = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+    return row * 128 + ((((byte >> 4) ^ sw) << 4) | (byte & 15));
+}
+__device__ __forceinline__ uint32_t q_off(uint32_t row, uint32_t byte) {
+    return row * 64 + (byte ^ (((row >> 3) & 1) << 5));
+}
+
 // ------------------------------------------------------------------------------------------ backward apply (q side)
 // grid (nchunks, H, B).  Per wave: 64 tokens.  dS partial slab per workgroup.
 __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_t* qkv, int ld, const bf16_t* dout, int ld_do,
@@ -313,17 +327,17 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
                 float hi4[4], lo4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { hi4[r] = valid ? rbf(du[t][r]) : 0.f; lo4[r] = valid ? du[t][r] - hi4[r] : 0.f; }
-                *reinterpret_cast<u32x2*>(du_img + trow * 128 + (t * 16 + 4 * g) * 2) = pack4(hi4[0], hi4[1], hi4[2], hi4[3]);
-                *reinterpret_cast<u32x2*>(du_lo + trow * 128 + (t * 16 + 4 * g) * 2) = pack4(lo4[0], lo4[1], lo4[2], lo4[3]);
+                *reinterpret_cast<u32x2*>(du_img + du_off(trow, (t * 16 + 4 * g) * 2)) = pack4(hi4[0], hi4[1], hi4[2], hi4[3]);
+                *reinterpret_cast<u32x2*>(du_lo + du_off(trow, (t * 16 + 4 * g) * 2)) = pack4(lo4[0], lo4[1], lo4[2], lo4[3]);
             }
             {
                 const float h32 = (valid && g == 0) ? rbf(du32) : 0.f, l32 = (valid && g == 0) ? du32 - h32 : 0.f;
-                *reinterpret_cast<u32x2*>(du_img + trow * 128 + (32 + 4 * g) * 2) = pack4(h32, 0.f, 0.f, 0.f);
-                *reinterpret_cast<u32x2*>(du_lo + trow * 128 + (32 + 4 * g) * 2) = pack4(l32, 0.f, 0.f, 0.f);
+                *reinterpret_cast<u32x2*>(du_img + du_off(trow, (32 + 4 * g) * 2)) = pack4(h32, 0.f, 0.f, 0.f);
+                *reinterpret_cast<u32x2*>(du_lo + du_off(trow, (32 + 4 * g) * 2)) = pack4(l32, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<u32x2*>(du_img + trow * 128 + (48 + 4 * g) * 2) = u32x2{0u, 0u};
-            *reinterpret_cast<u32x2*>(du_lo + trow * 128 + (48 + 4 * g) * 2) = u32x2{0u, 0u};
-            *reinterpret_cast<bf16x8*>(q_img + trow * 64 + g * 16) = qf;       // lane holds channels 8g..8g+7 of token li
+            *reinterpret_cast<u32x2*>(du_img + du_off(trow, (48 + 4 * g) * 2)) = u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(du_lo + du_off(trow, (48 + 4 * g) * 2)) = u32x2{0u, 0u};
+            *reinterpret_cast<bf16x8*>(q_img + q_off(trow, g * 16)) = qf;      // lane holds channels 8g..8g+7 of token li
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private images written
         // dS[c'][c] += sum_n dU[n][c'] relu(q)[n][c]: tokens on k via transposed reads (natural k order both sides)
@@ -332,13 +346,13 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const uint32_t off = (t * 16 + 4 * p4) * 2;
-            af[t] = cat4(lds_read_tr4(du_img, r0 * 128 + off), lds_read_tr4(du_img, r1 * 128 + off));
-            al[t] = cat4(lds_read_tr4(du_lo, r0 * 128 + off), lds_read_tr4(du_lo, r1 * 128 + off));
+            af[t] = cat4(lds_read_tr4(du_img, du_off(r0, off)), lds_read_tr4(du_img, du_off(r1, off)));
+            al[t] = cat4(lds_read_tr4(du_lo, du_off(r0, off)), lds_read_tr4(du_lo, du_off(r1, off)));
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const uint32_t off = (ct * 16 + 4 * p4) * 2;
-            bfr[ct] = cat4(lds_read_tr4(q_img, r0 * 64 + off), lds_read_tr4(q_img, r1 * 64 + off));
+            bfr[ct] = cat4(lds_read_tr4(q_img, q_off(r0, off)), lds_read_tr4(q_img, q_off(r1, off)));
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
