@@ -147,9 +147,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # YAT_DDP_FORCE=1: run the whole data-parallel machinery (RCCL group, bucket hooks on the side stream, comm stream,
+    # optimizer wait) even with ONE rank -- the only way to exercise that code path on a single-GPU box.
+    force_ddp = os.environ.get("YAT_DDP_FORCE", "0") != "0"
+    if world > 1 or force_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from yat_amd import ops
     from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
@@ -162,7 +167,7 @@ def main():
     model = SanaTransformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
     opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
                     overlap_update=os.environ.get("YAT_OVERLAP_ADAMW", "1") != "0")
-    ddp = HipDDP(model) if world > 1 else None
+    ddp = HipDDP(model, force=force_ddp) if (world > 1 or force_ddp) else None
     if ddp:
         ddp.broadcast_parameters()
     recipe = SanaRecipe(model, pad_to=512, device=dev)
@@ -202,7 +207,7 @@ def main():
         return b["h"] * b["w"]
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 

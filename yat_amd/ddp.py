@@ -20,8 +20,9 @@ import torch.distributed as dist
 
 
 class HipDDP:
-    def __init__(self, model, process_group=None, average=True):
+    def __init__(self, model, process_group=None, average=True, force=False):
         self.model = model
+        self.force = force            # run the collectives even in a one-rank group (single-GPU rehearsal of the N>1 path)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -34,11 +35,11 @@ class HipDDP:
 
     def broadcast_parameters(self, src=0):
         """accelerator.prepare -> DDP's rank0 -> all parameter broadcast (trainer.py:253)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.broadcast(self.model.flat_param, src=src, group=self.pg)
 
     def bucket_ready(self, i):
-        if self.world == 1 or not self.sync:
+        if (self.world == 1 and not self.force) or not self.sync:
             return
         lo, hi = self.model.bucket_bounds[i]
         chunk = self.model.flat_grad[lo:hi]
