@@ -90,3 +90,33 @@ def clip_and_adamw_step(params, optimizer: torch.optim.AdamW, max_norm: float = 
     optimizer.step()
     optimizer.zero_grad()
     return total
+
+
+def inference_schedule_ref(sched: FlowMatchSchedule, num_inference_steps: int):
+    """[RECALL] FlowMatchEulerDiscreteScheduler.set_timesteps(n) without dynamic shifting: linspace over
+    t(sigma_max)..t(sigma_min) of the training table, /1000, static shift applied again, *1000; sigmas + [0]."""
+    n = sched.num_train_timesteps
+    ts = np.linspace(float(sched.sigmas[0]) * n, float(sched.sigmas[-1]) * n, num_inference_steps, dtype=np.float32)
+    sig = torch.from_numpy(ts) / n
+    sig = sched.shift * sig / (1 + (sched.shift - 1) * sig)
+    return sig * n, torch.cat([sig, torch.zeros(1)])
+
+
+@torch.no_grad()
+def sample_latents_ref(model, sched: FlowMatchSchedule, latents, prompt_embeds, prompt_mask, negative_embeds, negative_mask,
+                       num_inference_steps=20, guidance_scale=5.0, dtype=torch.bfloat16):
+    """[RECALL] SanaPipeline.__call__ denoising loop (train_sana.py:135-147 calls it with guidance 5.0, 20 steps,
+    output_type='latent'): CFG batch (uncond | cond), Euler flow-match step.  ``model`` is a SanaTransformerRef in
+    ``dtype``; dtype=float32 gives the ground truth for the same initial latents."""
+    timesteps, sigmas = inference_schedule_ref(sched, num_inference_steps)
+    x = latents.to(dtype)
+    enc = torch.cat([negative_embeds, prompt_embeds]).to(dtype)
+    mask = torch.cat([negative_mask, prompt_mask])
+    for i in range(num_inference_steps):
+        x_in = torch.cat([x, x])
+        t = timesteps[i].expand(x_in.shape[0])
+        v = model(x_in, enc, t, encoder_attention_mask=mask)
+        v_u, v_c = v.float().chunk(2)
+        v = (v_u + guidance_scale * (v_c - v_u)).to(dtype)
+        x = (x.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(dtype)
+    return x

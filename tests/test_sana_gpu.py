@@ -144,3 +144,30 @@ def test_grad_accumulation_adds():
     g2 = hip.flat_grad.float()
     expect = (g1.float() * 2)
     assert rel(g2, expect) <= 4e-3
+
+
+def test_validation_sampler_matches_oracle():
+    """CFG + flow-match Euler latent sampler (the middle third of the reference's validate(), train_sana.py:135-147):
+    HIP model vs the oracle in bf16 and fp32 from the same initial latents, a few steps on a tiny configuration."""
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, sample_latents_ref, pad_embeddings, inference_schedule_ref
+    from yat_amd.sampler import sample_latents, inference_schedule
+    from yat_amd.scheduler import FlowMatchSchedule
+    ref_bf, ref_32, hip, _, embs = _setup(dict(num_layers=2), 2, 6, 10, [9, 30], 32, seed=3)
+    t_h, s_h = inference_schedule(FlowMatchSchedule(), 20)
+    t_r, s_r = inference_schedule_ref(RefSched(), 20)
+    assert torch.equal(t_h, t_r) and torch.equal(s_h, s_r) and s_h[-1] == 0 and abs(float(t_h[0]) - 1000.0) < 1e-3
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(2, ref_bf.cfg.in_channels, 6, 10, generator=g).to(BF)
+    enc, mask = pad_embeddings(embs, 32)
+    neg = torch.zeros_like(enc)
+    neg[:, :2] = torch.randn(2, 2, enc.shape[-1], generator=g).to(BF)
+    nmask = torch.zeros_like(mask)
+    nmask[:, :2] = 1
+    steps = 4
+    out = sample_latents(hip, enc, mask, neg, nmask, 6, 10, num_inference_steps=steps, guidance_scale=5.0, latents=x0)
+    o_bf = sample_latents_ref(ref_bf, RefSched(), x0, enc, mask, neg, nmask, steps, 5.0, BF)
+    o_32 = sample_latents_ref(ref_32, RefSched(), x0, enc, mask, neg, nmask, steps, 5.0, torch.float32)
+    e_hip, e_ref = rel(out, o_32), rel(o_bf, o_32)
+    print(f"[parity] sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
+    assert torch.isfinite(out.float()).all() and out.shape == x0.shape
+    assert e_hip <= 1.3 * e_ref + 2e-3

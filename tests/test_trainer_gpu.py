@@ -47,6 +47,11 @@ def test_trainer_runs_saves_and_reloads(tmp_path, monkeypatch):
         "batch_size: 4", "learning_rate: 1e-3", "steps: 6", "num_steps_per_validation: 3", "validation_prompts:", "  - x",
         "bfloat16: true", "gradient_accumulation_steps: 2", "warmup_steps: 2", "weight_decay: 0.01", "aspect_ratio: 1024",
         "use_ema: true", "train_unconditional_prob: 0.0", ""]))
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(1, 12, cfg.caption_channels, generator=g).to(BF)
+    torch.save([(pe, torch.ones(1, 12, dtype=torch.long), torch.zeros(1, 12, cfg.caption_channels, dtype=BF),
+                 torch.cat([torch.ones(1, 1, dtype=torch.long), torch.zeros(1, 11, dtype=torch.long)], 1))],
+               tmp_path / "validation_embeds.pt")
     monkeypatch.chdir(tmp_path)                       # the trainer writes models/<step>/ relative to the cwd
     params = TrainingParameters()
     params.read_yaml(str(yaml_path))
@@ -63,5 +68,8 @@ def test_trainer_runs_saves_and_reloads(tmp_path, monkeypatch):
     ck = tmp_path / "models" / saved[-1]
     assert (ck / "config.json").exists() and (ck / "diffusion_pytorch_model.safetensors").exists()
     assert json.loads((ck / "config.json").read_text())["_class_name"] == "SanaTransformer2DModel"
+    lat = torch.load(ck / "validation_latents.pt")    # 20-step CFG sampling from the cached validation embeddings
+    assert len(lat) == 1 and lat[0].shape == (1, cfg.in_channels, cfg.sample_size, cfg.sample_size)
+    assert torch.isfinite(lat[0].float()).all()
     re = SanaTransformer2DModelHIP.from_pretrained(str(ck), device="cuda")
     assert re.flat_param.shape == trainer.model.flat_param.shape and torch.isfinite(re.flat_param.float()).all()

@@ -7,8 +7,8 @@ train_sana.py:221-237), driving the MI355X-native hot path.
 
 ``pretrained_model_path`` (or ``pretrained_pipe_path``/transformer) must be a LOCAL diffusers directory
 (config.json + diffusion_pytorch_model.safetensors); with neither present the 1.6B architecture is random-initialised
-(there is no network here).  Feature extraction (VAE / text encoder, ``extract_features`` / ``compute_features``) and
-validation image sampling are outside the hot-path scope: training consumes cached-feature shards.
+(there is no network here).  Feature extraction (VAE / text encoder, ``extract_features`` / ``compute_features``) is outside the hot-path scope:
+training consumes cached-feature shards; validation samples latents from cached prompt embeddings (no VAE decode).
 """
 import argparse
 import json
@@ -52,6 +52,28 @@ class SanaModel(Model):
 
     def extract_embeddings(self, captions):
         raise NotImplementedError("text encoding is outside the hot-path scope; train from cached-feature shards")
+
+    def validate(self):
+        """Middle third of train_sana.py:99-161: 20-step flow-match Euler sampling with CFG 5.0 over the HIP transformer,
+        generator seeded 42 (:108).  The text encoder and the VAE are outside this build's scope, so the prompt embeddings
+        come from a cached file (``validation_embeds.pt`` next to the shards or in the cwd: a list of
+        (prompt_embeds [1,T,C], mask [1,T], negative_embeds, negative_mask) tuples as ``pipe.encode_prompt`` returns them)
+        and the result is the latents (``output_type='latent'``), stored under models/<step>/."""
+        from yat_amd.sampler import sample_latents
+        cands = [os.path.join(os.path.dirname(p), "validation_embeds.pt") for p in (self.params.local_shard_paths or [])]
+        path = next((c for c in cands + ["validation_embeds.pt"] if os.path.isfile(c)), None)
+        if path is None:
+            raise NotImplementedError("no cached validation embeddings (text encoding is outside the hot-path scope)")
+        embeds = torch.load(path, map_location="cpu")
+        gen = torch.Generator(device=self.accelerator.device).manual_seed(42)
+        side = self.model.config.sample_size
+        out = []
+        for pe, pm, ne, nm in embeds:
+            out.append(sample_latents(self.model, pe, pm, ne, nm, side, side, num_inference_steps=20, guidance_scale=5.0,
+                                      generator=gen, schedule=self.scheduler).cpu())
+        os.makedirs(f"models/{self.global_step}", exist_ok=True)
+        torch.save(out, f"models/{self.global_step}/validation_latents.pt")
+        return out
 
     def optimize(self, ratio, latents, embeddings, repa_tokens, generator: torch.Generator = None):
         """train_sana.py:163-219 on the HIP path (yat_amd.recipe.SanaRecipe.optimize)."""

@@ -1,0 +1,62 @@
+"""Latent sampler for the validation pass (train_sana.py:99-161 calls ``self.pipe(..., guidance_scale=5.0,
+num_inference_steps=20, output_type='latent')``): classifier-free guidance over the HIP transformer with a
+flow-match Euler integrator.
+
+What it restates [RECALL, diffusers SanaPipeline.__call__ / FlowMatchEulerDiscreteScheduler]:
+* ``set_timesteps(n)``: n timesteps linearly spaced from t(sigma_max) to t(sigma_min) of the TRAINING table, divided by
+  1000, pushed through the static shift once more, times 1000; sigmas get a trailing 0;
+* initial latents: N(0,1) in the model dtype from the given generator (init_noise_sigma = 1);
+* per step: the latents are duplicated (unconditional | conditional), one transformer call with the timestep expanded
+  to the batch, ``v = v_u + g (v_c - v_u)``, Euler update ``x <- x + (sigma_next - sigma) v`` in fp32, cast back.
+Text encoding (Gemma) and VAE decoding are outside the hot-path scope: the caller passes prompt embeddings and gets
+latents back, exactly the middle third of the reference's validate().
+"""
+from __future__ import annotations
+
+import torch
+
+from .scheduler import FlowMatchSchedule
+
+BF16 = torch.bfloat16
+
+
+def inference_schedule(sched: FlowMatchSchedule, num_inference_steps: int):
+    """-> (timesteps f32 [n], sigmas f32 [n+1])."""
+    n_train = sched.num_train_timesteps
+    smax, smin = float(sched.sigmas[0]), float(sched.sigmas[-1])
+    ts = torch.linspace(smax * n_train, smin * n_train, num_inference_steps, dtype=torch.float32)
+    sig = ts / n_train
+    sig = sched.shift * sig / (1 + (sched.shift - 1) * sig)
+    return sig * n_train, torch.cat([sig, torch.zeros(1)])
+
+
+@torch.no_grad()
+def sample_latents(model, prompt_embeds, prompt_mask, negative_embeds, negative_mask, height, width, *,
+                   num_inference_steps=20, guidance_scale=5.0, generator=None, schedule: FlowMatchSchedule | None = None,
+                   latents=None):
+    """prompt_embeds / negative_embeds: [B, T, C] bf16, masks [B, T] (1 keep); height, width in latent pixels.
+    Returns latents [B, C_in, height, width] (bf16, on the model's device)."""
+    sched = schedule or FlowMatchSchedule()
+    dev = model.device
+    B = prompt_embeds.shape[0]
+    cin = model.cfg.in_channels
+    if latents is None:
+        if generator is not None and generator.device.type == "cuda":
+            latents = torch.randn(B, cin, height, width, generator=generator, device=dev, dtype=BF16)
+        else:
+            latents = torch.randn(B, cin, height, width, generator=generator, dtype=BF16).to(dev)
+    latents = latents.to(device=dev, dtype=BF16)
+    enc = torch.cat([negative_embeds, prompt_embeds]).to(device=dev, dtype=BF16)
+    mask = torch.cat([negative_mask, prompt_mask]).to(dev)
+    timesteps, sigmas = inference_schedule(sched, num_inference_steps)
+    do_cfg = guidance_scale > 1.0
+    for i in range(num_inference_steps):
+        x_in = torch.cat([latents, latents]) if do_cfg else latents
+        t = timesteps[i].expand(x_in.shape[0]).to(dev)
+        v = model(x_in, encoder_hidden_states=enc if do_cfg else enc[B:], timestep=t,
+                  encoder_attention_mask=mask if do_cfg else mask[B:]).sample
+        if do_cfg:
+            v_u, v_c = v.float().chunk(2)
+            v = (v_u + guidance_scale * (v_c - v_u)).to(BF16)       # the pipeline combines in the model dtype
+        latents = (latents.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(BF16)
+    return latents
