@@ -221,9 +221,11 @@ int yat_mse_fwd_bwd(int64_t n, const void* pred, const void* target, float gscal
 uint64_t yat_gradnorm_workspace_bytes(int64_t n, int nseg);
 int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_start, float max_norm, float* norm_out,
                       float* clip_coef, void* workspace, yat_stream_t stream);
+/* background: 0 = full-width launch (the update alone on the GPU); N > 0 = at most N workgroups of a 48-VGPR variant
+ * that can share a CU with two resident GEMM waves -- for an update that runs under the next forward's GEMMs. */
 int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_avg_sq, const float* clip_coef,
                    double lr, double beta1, double beta2, double eps, double weight_decay, int step, int zero_grad,
-                   void* ema_shadow, double ema_decay, yat_stream_t stream);
+                   void* ema_shadow, double ema_decay, int background, yat_stream_t stream);
 
 #ifdef __cplusplus
 }

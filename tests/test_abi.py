@@ -66,7 +66,7 @@ def test_bad_arguments_are_rejected_without_a_gpu(built_lib):
     # argument validation happens before any launch, so it is testable on the CPU box
     assert lib.yat_gemm_bf16(0, 0, 0, 8, 8, None, 8, None, 8, None, 8, None, None) == -1
     assert lib.yat_gemm_bf16(0, 0, 8, 8, 12, 1, 16, 1, 16, 1, 8, None, None) == -1  # K % 8 != 0
-    assert lib.yat_adamw_step(7, 1, 1, 1, 1, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1, None, 0.0, None) == -1
+    assert lib.yat_adamw_step(7, 1, 1, 1, 1, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1, None, 0.0, 0, None) == -1
     assert lib.yat_ln_modulate_fwd(4, 7, 4, 1e-6, 1, 1, 1, 8, 1, 1, 1, None) == -1     # D % 8 != 0
 
 

@@ -190,4 +190,8 @@ def test_optimizer_full_size_halves_equal_whole(ops):
         ops.adamw_step(*(t[sl] for t in halves), coef, 1e-4, 0.9, 0.999, 1e-8, 0.01, 3, zero_grad=False)
     for a, b_ in zip(whole, halves):
         assert torch.equal(a, b_)
+    bg = [t.clone() for t in (p, gr, m, v)]      # the 48-VGPR background variant (one workgroup per CU): same bits
+    ops.adamw_step(*bg, coef, 1e-4, 0.9, 0.999, 1e-8, 0.01, 3, zero_grad=False, background=256)
+    for a, b_ in zip(whole, bg):
+        assert torch.equal(a, b_)
     assert not torch.equal(whole[0], p)         # the step moved the parameters

@@ -67,6 +67,21 @@ struct AdamP {
     int use_wd, zero_grad;
 };
 
+// one parameter's update: torch's single-tensor AdamW op sequence with a bf16 rounding after every op
+__device__ __forceinline__ void adamw_elem(float& pr, float g, float& mr_, float& vr_, float coef, bool clip, const AdamP& a) {
+    const float gr = clip ? rbf(g * coef) : g;                      // grads.mul_(clip_coef_clamped)
+    if (a.use_wd) pr = rbf(pr * a.wd_mul);                          // param.mul_(1 - lr*wd)
+    const float mr = rbf(mr_ + a.w1 * (gr - mr_));                  // exp_avg.lerp_(grad, 1-beta1)
+    float vr = rbf(vr_ * a.beta2);                                  // exp_avg_sq.mul_(beta2)
+    vr = rbf(vr + a.om_b2 * gr * gr);                               //   .addcmul_(grad, grad, value=1-beta2)
+    float den = rbf(sqrtf(vr));                                     // exp_avg_sq.sqrt()
+    den = rbf(den / a.bc2_sqrt);                                    //   / bias_correction2_sqrt
+    den = rbf(den + a.eps);                                         //   .add_(eps)
+    pr = rbf(pr + a.neg_step_size * mr / den);                      // param.addcdiv_(exp_avg, denom, -step_size)
+    mr_ = mr;
+    vr_ = vr;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(int64_t nvec, bf16_t* p, bf16_t* g, bf16_t* m, bf16_t* v,
                                                     const float* clip_coef, bf16_t* ema, AdamP a) {
     const float coef = clip_coef ? clip_coef[0] : 1.0f;
@@ -79,19 +94,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(int64_t nvec, bf16_t* p, bf1
         if (ema) unpack8(*reinterpret_cast<const u32x4*>(ema + i * 8), ss);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float gr = clip_coef ? rbf(gg[e] * coef) : gg[e];          // grads.mul_(clip_coef_clamped)
-            float pr = pp[e];
-            if (a.use_wd) pr = rbf(pr * a.wd_mul);                      // param.mul_(1 - lr*wd)
-            const float mr = rbf(mm[e] + a.w1 * (gr - mm[e]));          // exp_avg.lerp_(grad, 1-beta1)
-            float vr = rbf(vv[e] * a.beta2);                            // exp_avg_sq.mul_(beta2)
-            vr = rbf(vr + a.om_b2 * gr * gr);                           //   .addcmul_(grad, grad, value=1-beta2)
-            float den = rbf(sqrtf(vr));                                 // exp_avg_sq.sqrt()
-            den = rbf(den / a.bc2_sqrt);                                //   / bias_correction2_sqrt
-            den = rbf(den + a.eps);                                     //   .add_(eps)
-            pr = rbf(pr + a.neg_step_size * mr / den);                  // param.addcdiv_(exp_avg, denom, -step_size)
-            pp[e] = pr; mm[e] = mr; vv[e] = vr;
+            adamw_elem(pp[e], gg[e], mm[e], vv[e], coef, clip_coef != nullptr, a);
             if (ema) {                                                  // s.sub_(one_minus_decay * (s - p))
-                const float d = rbf(ss[e] - pr);
+                const float d = rbf(ss[e] - pp[e]);
                 ss[e] = rbf(ss[e] - rbf(a.ema_omd * d));
             }
         }
@@ -100,6 +105,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(int64_t nvec, bf16_t* p, bf1
         *reinterpret_cast<u32x4*>(v + i * 8) = pack8(vv);
         if (ema) *reinterpret_cast<u32x4*>(ema + i * 8) = pack8(ss);
         if (a.zero_grad) *reinterpret_cast<u32x4*>(g + i * 8) = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+// Background variant for the update that runs UNDER the next forward: one 256-thread workgroup per CU, 4 elements per
+// thread and iteration, capped at 48 VGPRs -- what two resident waves of a 256-row GEMM workgroup (<= 232 VGPRs each)
+// leave free on a SIMD, so it can share a CU with the GEMM instead of queueing for a whole one.  Same arithmetic.
+__global__ __launch_bounds__(256, 10) void adamw_bg_kernel(int64_t nvec4, bf16_t* p, bf16_t* g, bf16_t* m, bf16_t* v,
+                                                           const float* clip_coef, bf16_t* ema, AdamP a) {
+    const float coef = clip_coef ? clip_coef[0] : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec4; i += (int64_t)gridDim.x * blockDim.x) {
+        float pp[4], gg[4], mm[4], vv[4], ss[4];
+        unpack4(*reinterpret_cast<const u32x2*>(p + i * 4), pp);
+        unpack4(*reinterpret_cast<const u32x2*>(g + i * 4), gg);
+        unpack4(*reinterpret_cast<const u32x2*>(m + i * 4), mm);
+        unpack4(*reinterpret_cast<const u32x2*>(v + i * 4), vv);
+        if (ema) unpack4(*reinterpret_cast<const u32x2*>(ema + i * 4), ss);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            adamw_elem(pp[e], gg[e], mm[e], vv[e], coef, clip_coef != nullptr, a);
+            if (ema) {
+                const float d = rbf(ss[e] - pp[e]);
+                ss[e] = rbf(ss[e] - rbf(a.ema_omd * d));
+            }
+        }
+        *reinterpret_cast<u32x2*>(p + i * 4) = pack4(pp[0], pp[1], pp[2], pp[3]);
+        *reinterpret_cast<u32x2*>(m + i * 4) = pack4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<u32x2*>(v + i * 4) = pack4(vv[0], vv[1], vv[2], vv[3]);
+        if (ema) *reinterpret_cast<u32x2*>(ema + i * 4) = pack4(ss[0], ss[1], ss[2], ss[3]);
+        if (a.zero_grad) *reinterpret_cast<u32x2*>(g + i * 4) = u32x2{0u, 0u};
     }
 }
 
@@ -129,7 +163,7 @@ int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_
 
 int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_avg_sq, const float* clip_coef, double lr,
                    double beta1, double beta2, double eps, double weight_decay, int step, int zero_grad, void* ema_shadow,
-                   double ema_decay, yat_stream_t stream) {
+                   double ema_decay, int background, yat_stream_t stream) {
     if (n <= 0 || (n & 7) || step < 1 || !param || !grad || !exp_avg || !exp_avg_sq) return YAT_EINVAL;
     // scalar prep in double exactly as torch's python does, then narrowed to the kernels' opmath (float)
     const double dlr = lr, db1 = beta1, db2 = beta2;
@@ -145,6 +179,15 @@ int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_
     a.eps = (float)eps;
     a.ema_omd = (float)(1.0 - ema_decay);
     a.zero_grad = zero_grad;
+    if (background) {
+        const int64_t nvec4 = n >> 2;
+        int64_t nbg = (nvec4 + 255) / 256;
+        if (nbg > background) nbg = background;                 // `background` = workgroups (e.g. 256: one per CU)
+        hipLaunchKernelGGL(adamw_bg_kernel, dim3((unsigned)nbg), dim3(256), 0, (hipStream_t)stream, nvec4, (bf16_t*)param,
+                           (bf16_t*)grad, (bf16_t*)exp_avg, (bf16_t*)exp_avg_sq, clip_coef, (bf16_t*)ema_shadow, a);
+        YAT_CHECK_LAUNCH();
+        return YAT_OK;
+    }
     const int64_t nvec = n >> 3;
     int64_t nb = (nvec + 255) / 256;
     if (nb > 8192) nb = 8192;

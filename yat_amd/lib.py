@@ -63,7 +63,7 @@ SIGNATURES = {
     "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
     "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
     "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
-    "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, P]),
+    "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),
 }
 
 

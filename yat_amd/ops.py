@@ -369,7 +369,8 @@ def gradnorm_clip(grad_flat, seg_start_i64, max_norm, norm_out, clip_coef, works
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, clip_coef, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True,
-               ema_shadow=None, ema_decay=0.0):
+               ema_shadow=None, ema_decay=0.0, background=0):
     rc = _lib().yat_adamw_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(clip_coef), lr, beta1,
-                               beta2, eps, weight_decay, step, int(zero_grad), _p(ema_shadow), ema_decay, _stream())
+                               beta2, eps, weight_decay, step, int(zero_grad), _p(ema_shadow), ema_decay, int(background),
+                               _stream())
     _l.check(rc, "yat_adamw_step")

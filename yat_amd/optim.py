@@ -7,6 +7,8 @@ device: the clip coefficient is a device scalar consumed by the AdamW kernel, so
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -36,6 +38,8 @@ class FlatAdamW:
         # event per bucket; the next forward waits per bucket, so this HBM-bound pass hides under the forward GEMMs.
         # Anything else that reads parameters first calls model.join_pending_update().
         self.overlap_update = overlap_update and dev.type == "cuda"
+        # overlapped update: workgroups of the 48-VGPR background kernel (0 = the full-width kernel); see yat_adamw_step
+        self.background_blocks = int(os.environ.get("YAT_ADAMW_BG", "0"))
         self._stream = None
 
     def _ema_decay_now(self):
@@ -59,13 +63,15 @@ class FlatAdamW:
             self.ema_steps += 1
             ema_decay = self._ema_decay_now()
 
+        bg = self.background_blocks if self.overlap_update else 0
+
         def update(lo, hi):
             # no gradient clear: every backward overwrites the whole flat gradient (accumulate_grads=False on the
             # first micro-step), like the reference's zero_grad(set_to_none=True) which writes nothing either
             ops.adamw_step(m.flat_param[lo:hi], m.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], coef,
                            g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
                            zero_grad=False, ema_shadow=None if self.ema_shadow is None else self.ema_shadow[lo:hi],
-                           ema_decay=ema_decay)
+                           ema_decay=ema_decay, background=bg)
 
         if not self.overlap_update:
             update(0, m.numel_flat)

@@ -168,6 +168,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         self.keep_glu_u = os.environ.get("YAT_KEEP_GLU_U", "1") != "0"         # keep the depthwise-conv output (183 MB/block)
         self.fwd_chains = int(os.environ.get("YAT_FWD_CHAINS", "2"))           # independent forward chains (image ranges)
         self._chains = {}
+        self.group_big_wgrad = os.environ.get("YAT_GROUP_BIG_WGRAD", "0") != "0"
         self.group_small_wgrad = os.environ.get("YAT_GROUP_SMALL_WGRAD", "1") != "0"   # D x D weight gradients grouped
         self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
         self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
@@ -555,11 +556,16 @@ class SanaTransformer2DModelHIP(nn.Module):
 
             small = []                                        # the three D x D weight gradients: one grouped launch
 
+            big = []                                          # experiment: conv_inverted + conv_point + kv in one launch
+
             def emit(dy_, x_, gw_, bias=None, group=False):
                 if self.defer_wgrad or side is None:
                     deferred.append((dy_, x_, gw_))
                     return
-                if group and self.group_small_wgrad:
+                if group == "big" and self.group_big_wgrad:
+                    big.append((dy_, x_, gw_, bias))
+                    return
+                if group is True and self.group_small_wgrad:
                     small.append((dy_, x_, gw_, bias))
                     return
 
@@ -572,7 +578,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             # x3 = x2 + gate_mlp * lin3
             dlin3 = buf(f"dlin3.{par}", (M, D))
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
-            emit(dlin3, A.y, G[pre + "ff.conv_point.weight"].view(D, Hc))
+            emit(dlin3, A.y, G[pre + "ff.conv_point.weight"].view(D, Hc), group="big")
             dz = buf(f"dz.{par}", (M, 2 * Hc))
             if A.u is not None:
                 # the GLU backward runs in the epilogue of the GEMM that produces dy (dy itself never reaches memory);
@@ -585,7 +591,7 @@ class SanaTransformer2DModelHIP(nn.Module):
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
                                dz_colsum=G[pre + "ff.conv_inverted.bias"], du=du_)        # bias gradient in the same pass
-            emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D))
+            emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), group="big")
             dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf(f"dh2.{par}", (M, D)))
             other = dxb if dx is dxa else dxa
             # LayerNorm backward: dx on the chain; the shift/scale gradients (column statistics) feed only the
@@ -612,7 +618,15 @@ class SanaTransformer2DModelHIP(nn.Module):
             dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
-            emit(dkv2, S.encn, gkv, gbkv)
+            emit(dkv2, S.encn, gkv, gbkv, group="big")
+            if big:
+                def big_grads(big=big):
+                    ops.wgrad_grouped(sorted([(a, b_, c) for a, b_, c, _ in big], key=lambda it: -it[0].shape[0]),
+                                      accumulate=acc)
+                    for a, _, _, bias_ in big:
+                        if bias_ is not None:
+                            ops.colsum(a, bias_, ws_col, accumulate=acc)
+                off_chain(big_grads)
             # x1 = x + gate_msa * lin1
             dlin1 = buf(f"dlin1.{par}", (M, D))
             ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin1, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate,
