@@ -73,6 +73,36 @@ def test_shard_roundtrip(tmp_path):
     assert out[0]["emb.pt"].shape[1] == 16
 
 
+def test_legacy_cache_roundtrip_and_sampler(tmp_path):
+    """cache/{idx}.npy tuples of the reference (common/cache.py:70-85): (ratio, latent, (emb padded to 300, mask))."""
+    from yat_amd.common.shards import write_legacy_sample, read_legacy_sample, iter_legacy_cache
+    g = torch.Generator().manual_seed(1)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    want = []
+    for i in range(10):
+        r = ["1.0", "0.5"][i % 2]
+        H, W = ASPECT_RATIO_1024_BIN[r]
+        lat = torch.randn(8, int(H) // 256, int(W) // 256, generator=g).to(torch.bfloat16)
+        emb = torch.randn(3 + i, 16, generator=g).to(torch.bfloat16)
+        write_legacy_sample(str(cache / f"{i}.npy"), float(r), lat, emb, compress=(i % 3 == 0))
+        want.append((float(r), lat, emb))
+    # the file is exactly the tuple the reference's loader expects
+    ratio, latent, (padded, mask) = torch.load(str(cache / "1.npy"), weights_only=False)
+    assert padded.shape == (300, 16) and mask.shape == (300,) and int(mask.sum()) == 4 and ratio == 0.5
+    assert torch.equal(padded[:4], want[1][2]) and padded[4:].abs().max() == 0
+    got = list(iter_legacy_cache(str(cache)))
+    assert [s["__key__"] for s in got] == [str(i) for i in range(10)]
+    for s, (r, lat, emb) in zip(got, want):
+        assert s["ratio"] == r and torch.equal(s["latent.pt"], lat) and torch.equal(s["emb.pt"], emb)
+    assert [s["__key__"] for s in iter_legacy_cache(str(cache), rank=1, world=2)] == ["1", "3", "5", "7", "9"]
+    assert torch.equal(read_legacy_sample(str(cache / "0.npy"))["emb.pt"], want[0][2])          # gzip variant
+    model = type("M", (), {"aspect_ratios": ASPECT_RATIO_1024_BIN})()
+    s = BucketSampler([], HipAccelerator(1, device="cpu"), batch_size=2, model=model, seed=0, legacy_cache_dir=str(cache))
+    b = next(iter(s))
+    assert b.vae_features.shape[0] == 2 and len(b.embeddings) == 2 and b.ratio in (1.0, 0.5)
+
+
 def test_bucket_sampler_single_process(tmp_path):
     paths = _make_shards(tmp_path)
     model = type("M", (), {"aspect_ratios": ASPECT_RATIO_1024_BIN})()

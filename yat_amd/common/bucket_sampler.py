@@ -23,7 +23,7 @@ from collections import deque
 import torch
 import torch.distributed as dist
 
-from .shards import read_shard
+from .shards import iter_legacy_cache, read_shard
 
 
 class Batch:
@@ -38,7 +38,7 @@ class Batch:
 
 class BucketSampler:
     def __init__(self, shards, accelerator, batch_size, model=None, seed=0, local_paths=None, features_path=None,
-                 max_read_ahead=4096):
+                 max_read_ahead=4096, legacy_cache_dir=None):
         self.accelerator = accelerator
         self.process_index = accelerator.process_index
         self.num_processes = accelerator.num_processes
@@ -48,6 +48,10 @@ class BucketSampler:
         keys = list(model.aspect_ratios.keys()) if model is not None else []
         self.keys = [float(k) for k in keys]                      # table order = consensus priority order
         self.buckets = {k: deque() for k in self.keys}
+        self.legacy_cache_dir = legacy_cache_dir                  # cache/{idx}.npy tuples (common/cache.py) instead of shards
+        if legacy_cache_dir:
+            self.paths = []
+            return
         if local_paths:
             paths = [p for p in local_paths if os.path.exists(p)]
             if self.num_processes > 1 and len(paths) >= self.num_processes:
@@ -60,6 +64,12 @@ class BucketSampler:
 
     def _shard_stream(self):
         rng = random.Random(self.seed + self.process_index)
+        while self.legacy_cache_dir:
+            samples = list(iter_legacy_cache(self.legacy_cache_dir, self.process_index, self.num_processes))
+            if not samples:
+                raise FileNotFoundError(f"no cache/<idx>.npy sample for rank {self.process_index} in {self.legacy_cache_dir}")
+            rng.shuffle(samples)
+            yield from samples
         while True:
             order = list(self.paths)
             rng.shuffle(order)

@@ -7,7 +7,9 @@ BucketSampler decodes (common/bucket_sampler.py:138-156): a POSIX tar whose memb
 """
 from __future__ import annotations
 
+import gzip
 import io
+import os
 import tarfile
 
 import torch
@@ -59,3 +61,49 @@ def read_shard(path):
 
 def _complete(s):
     return "ratio" in s and "latent.pt" in s and "emb.pt" in s
+
+
+# ---- legacy cache: one file per sample ------------------------------------------------------------------------------
+# common/cache.py:70-85 (CacheLoadFeatures.run) writes ``cache/{idx}.npy`` = torch.save((ratio, latent, (emb, mask)))
+# with the embedding ZERO-PADDED to [300, C] and a float mask [300]; CacheFeaturesCompute (:28-45) keeps the same tuple
+# gzip-compressed under ``datasets/<url>/<file>.npy``.  Despite the extension these are torch pickles, not numpy files.
+LEGACY_PAD = 300
+
+
+def write_legacy_sample(path, ratio, latent, emb, pad_to=LEGACY_PAD, compress=False):
+    """Write one sample in the legacy tuple layout (emb: unpadded [L, C])."""
+    L, C = emb.shape
+    if L > pad_to:
+        raise ValueError(f"embedding longer than the legacy pad length {pad_to}")
+    padded = torch.zeros(pad_to, C, dtype=emb.dtype)
+    padded[:L] = emb
+    mask = torch.zeros(pad_to)
+    mask[:L] = 1.0
+    obj = (ratio, latent.detach().cpu(), (padded, mask))
+    if compress:
+        with gzip.open(path, "wb") as f:
+            torch.save(obj, f)
+    else:
+        torch.save(obj, path)
+
+
+def read_legacy_sample(path):
+    """-> the same dict a shard sample decodes to: {__key__, ratio, 'latent.pt', 'emb.pt' (mask-true rows only)}."""
+    with open(path, "rb") as f:
+        gz = f.read(2) == b"\x1f\x8b"
+    if gz:
+        with gzip.open(path, "rb") as f:
+            obj = torch.load(io.BytesIO(f.read()), map_location="cpu", weights_only=False)
+    else:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+    ratio, latent, (emb, mask) = obj
+    keep = int(mask.sum().item())
+    return {"__key__": os.path.splitext(os.path.basename(path))[0], "ratio": float(ratio),
+            "latent.pt": latent if latent.dim() == 3 else latent.squeeze(0), "emb.pt": emb[:keep].contiguous()}
+
+
+def iter_legacy_cache(cache_dir, rank=0, world=1):
+    """Samples ``{idx}.npy`` of a legacy cache directory in index order, strided over ranks (cache.py:57-63)."""
+    idx = sorted(int(n[:-4]) for n in os.listdir(cache_dir) if n.endswith(".npy") and n[:-4].isdigit())
+    for i in idx[rank::world]:
+        yield read_legacy_sample(os.path.join(cache_dir, f"{i}.npy"))

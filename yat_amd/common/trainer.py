@@ -174,8 +174,13 @@ class Model:
         """Cached-feature sampler over this rank's shard range (the intended path of :165-181)."""
         from .bucket_sampler import BucketSampler
         shards = [f"shard-{i:06d}.tar" for i in range(self.shard_index_begin, self.shard_index_end)]
+        # a legacy per-sample cache (cache/{idx}.npy tuples written by the reference's common/cache.py) is used when
+        # present and no shard list is configured
+        legacy = "cache" if (not self.params.local_shard_paths and os.path.isdir("cache")
+                             and any(n.endswith(".npy") for n in os.listdir("cache"))) else None
         return BucketSampler(shards, self.accelerator, self.params.batch_size, model=self,
-                             seed=self.params.dataset_seed, local_paths=self.params.local_shard_paths)
+                             seed=self.params.dataset_seed, local_paths=self.params.local_shard_paths,
+                             legacy_cache_dir=legacy)
 
     # ---- :126-281
     def initialize(self):
