@@ -194,6 +194,8 @@ def main():
     noise_gen = torch.Generator(device=dev).manual_seed(99 + rank)   # throughput mode: advancing device stream
     ts_gen = torch.Generator().manual_seed(77 + rank)
 
+    OPT_TIMER = None
+
     def step(i):
         b = batches[i % len(batches)]
         ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)                       # train_sana.py:168-180
@@ -203,7 +205,14 @@ def main():
         recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, sig_dev, loss_dev, kv_work=b["work"])  # :206-218 + bwd
         if ddp:
             ddp.wait()
-        opt.step()                                                                                  # trainer.py:347-356
+        if OPT_TIMER is not None:           # roofline pass only: HIP events around clip + AdamW on its stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            opt.step()
+            e1.record()
+            OPT_TIMER.append((e0, e1))
+        else:
+            opt.step()                                                                              # trainer.py:347-356
         return b["h"] * b["w"]
 
     def barrier():
@@ -256,10 +265,12 @@ def main():
         torch.cuda.synchronize()
         timer = []
         ops.GEMM_TIMER = timer
+        OPT_TIMER = []
         for i in range(args.roofline_steps):
             step(1 + i)
         torch.cuda.synchronize()
         ops.GEMM_TIMER = None
+        opt_timer, OPT_TIMER = OPT_TIMER, None
         model.side_wgrad, opt.overlap_update, model.fwd_chains = saved
         barrier()
 
@@ -298,6 +309,16 @@ def main():
                                "mode": f"serialized-stream pass of {args.roofline_steps} steps after the timed region",
                                "launches": len(timer), "avg_launch_us": 1e3 * gms / len(timer),
                                "gemm_ms_per_step_serialized": gms / args.roofline_steps}
+        if timer:
+            # second roofline, for the dominant HBM-bound pass: gradient norm + clip + AdamW over the flat buffers
+            # (algorithmic 2 B/param read for the norm + 14 B/param for the update; PMC: profiles/r01_g_pmc_per_kernel.txt
+            # shows exactly 12.8 GB fetched + 9.6 GB written by adamw_kernel per step)
+            oms = sum(a.elapsed_time(b_) for a, b_ in opt_timer) / max(1, len(opt_timer))
+            obytes = 16.0 * model.numel_flat
+            res["roofline_hbm"] = {"bound": "hbm", "kernel": "gradnorm_partial_kernel + adamw_kernel (clip + AdamW step)",
+                                   "achieved": obytes / (oms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": obytes / (oms * 1e-3) / 1e9 / 8000.0, "traffic": 14.0 * model.numel_flat + 2.0 * model.numel_flat,
+                                   "ms": oms, "mode": "serialized-stream pass"}
         if timer and args.gemm_detail:
             agg = {}
             for fl, e0, e1, key, *_ in timer:
