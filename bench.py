@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 2: 8)")
     ap.add_argument("--layers", type=int, default=20, help="debug only; anything but 20 is not the headline config")
+    ap.add_argument("--lokr", type=int, default=0, metavar="RANK",
+                    help="BASELINE config 5 instead of config 2: LoKr adapters of this rank on the README target modules "
+                         "(alpha = rank, module dropout 0.05), frozen base; not the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
@@ -165,9 +168,15 @@ def main():
     cfg = SanaConfig(num_layers=args.layers)
     log(f"rank {rank}/{world}: building SANA ({args.layers} blocks) on {dev}")
     model = SanaTransformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
-    opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
+    trained = model
+    if args.lokr:
+        from yat_amd.lokr import LoKrAdapters
+        trained = LoKrAdapters(model, ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2",
+                                       "proj"], r=args.lokr, alpha=float(args.lokr), module_dropout=0.05)
+        log(f"LoKr rank {args.lokr}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
+    opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
                     overlap_update=os.environ.get("YAT_OVERLAP_ADAMW", "1") != "0")
-    ddp = HipDDP(model, force=force_ddp) if (world > 1 or force_ddp) else None
+    ddp = HipDDP(trained, force=force_ddp) if (world > 1 or force_ddp) else None
     if ddp:
         ddp.broadcast_parameters()
     recipe = SanaRecipe(model, pad_to=512, device=dev)
@@ -281,7 +290,9 @@ def main():
             "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("train_sana.py: SANA-1.6B (D=2240, 20 blocks) 1024px, bf16, full fine-tune, "
+            "config": {"workload": ("train_sana.py: SANA-1.6B (D=2240, 20 blocks) 1024px, bf16, "
+                                    + (f"LoKr rank {args.lokr} adapters on a frozen base (BASELINE config 5), " if args.lokr
+                                       else "full fine-tune, ") +
                                     f"cached latents/text embeds, aspect buckets {BUCKETS} round-robin, T=512, AdamW+clip"),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",
                        "num_layers": cfg.num_layers, "params": model.numel_flat},

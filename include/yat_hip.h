@@ -41,6 +41,9 @@ typedef struct yat_gemm_epilogue {
     const void* glu_u;     /* bf16 [M, ld_glu_u] = [u_a | u_g] (N columns each) or NULL.  GLU backward fused into the */
     int ld_glu_u;          /* GEMM that produces dy (GLUMBConv conv_point dgrad): with d = bf16(result), C is [M, 2N]:  */
                            /* C[m,n] = d*bf16(SiLU(u_g)), C[m,N+n] = bf16(d*u_a)*SiLU'(u_g); excludes the other options */
+    const void* pre_add;   /* bf16 [M, ld_pre_add] or NULL (forward layout only): added to the rounded Linear output      */
+    int ld_pre_add;        /* before aux_out / activation / gate / residual -- a PEFT adapter's                          */
+                           /* base_layer(x) + F.linear(x, delta_w) (peft LoKr/LoRA wrap at common/trainer.py:212-238)     */
 } yat_gemm_epilogue;
 
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
@@ -177,6 +180,21 @@ uint64_t yat_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
 int yat_gate_bwd(int M, int D, int rows_per_batch, const void* dout, const void* lin, const void* gate, int gate_ld,
                  void* dlin, float* dgate_acc, int acc_ld, void* dbias_bf16, int accumulate_bias, void* workspace,
                  yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * LoKr adapters (BASELINE config 5; peft LoKrConfig wrap at common/trainer.py:226-238).
+ * For a target weight [out = out_l*out_k, in = in_m*in_n]:  w1 bf16 [out_l, in_m], w2_a [out_k, r], w2_b [r, in_n].
+ *   yat_lokr_delta:   delta[(i,k),(j,n)] = bf16( bf16(w1[i,j] * bf16((w2_a w2_b)[k,n])) * scale )   (scale = alpha / r)
+ *   yat_lokr_project: from d_delta [out, ld] (= dy^T x, a yat_gemm wgrad): d_w1, d_w2_a, d_w2_b as autograd of the
+ *                     line above produces them (fp32 sums in a fixed order, one bf16 rounding per autograd op).
+ * The dense products with delta run on yat_gemm_bf16 (yat_gemm_epilogue.pre_add folds the adapter output in).
+ * ------------------------------------------------------------------------------------------ */
+int yat_lokr_delta(int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2_a, const void* w2_b,
+                   float scale, void* delta, int ld, yat_stream_t stream);
+uint64_t yat_lokr_project_workspace_bytes(int out_l, int out_k, int in_n);
+int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2_a, const void* w2_b,
+                     float scale, const void* d_delta, int ld, void* d_w1, void* d_w2_a, void* d_w2_b, void* workspace,
+                     yat_stream_t stream);
 
 /* elementwise helpers: y = act(x) and dx = dy * act'(x) on bf16 (time-embed / caption MLPs);
  * act: 1 SiLU, 2 GELU(tanh).  add: out = bf16(a + b).  f32->bf16 convert. */

@@ -86,4 +86,4 @@ def test_no_kernel_uses_scratch(built_lib):
         assert r.get("ScratchSize [bytes/lane]", 0) == 0, (name, r)
         assert r.get("VGPRs Spill", 0) == 0, (name, r)
     gemm = {k: v for k, v in res.items() if "gemm256_kernel" in k}
-    assert len(gemm) == 10 and all(v["VGPRs"] + v.get("AGPRs", 0) <= 256 for v in gemm.values())     # 2 waves per SIMD
+    assert len(gemm) >= 10 and all(v["VGPRs"] + v.get("AGPRs", 0) <= 256 for v in gemm.values())     # 2 waves per SIMD

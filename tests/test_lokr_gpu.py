@@ -1,0 +1,146 @@
+"""LoKr adapters (BASELINE config 5) on the HIP path against the oracle's restatement of the peft wrap -- GPU.
+
+peft is absent from the container, so the adapter arithmetic is [RECALL] on both sides (parity unpinned, see
+oracle/lokr_ref.py); what these tests pin is that the HIP path and the CPU restatement agree: kernels bit-for-bit with
+the op-by-op bf16 formula, the adapted training step as close to the fp32 truth as the oracle's own bf16 run."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda"
+TARGETS = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def test_factorization_matches_restatement():
+    from oracle.lokr_ref import factorization as ref
+    from yat_amd.lokr import factorization as hip
+    for d in (32, 96, 128, 256, 2240, 2304, 4480, 5600, 6720, 11200):
+        assert hip(d) == ref(d)
+    assert hip(2240) == (40, 56) and hip(11200) == (100, 112) and hip(5600) == (70, 80) and hip(32) == (4, 8)
+
+
+@pytest.mark.parametrize("out_dim,in_dim,scale", [(2240, 2240, 1.0), (448, 96, 0.5), (11200, 2240, 1.0), (2240, 5600, 2.0)])
+def test_lokr_kernels_bit_exact(out_dim, in_dim, scale):
+    """delta_w and its autograd: the kernels follow torch's bf16 op sequence (matmul, kron, scale) exactly."""
+    from yat_amd import ops
+    from yat_amd.lokr import factorization
+    (out_l, out_k), (in_m, in_n), r = factorization(out_dim), factorization(in_dim), 8
+    g = torch.Generator().manual_seed(out_dim + in_dim)
+    w1 = (torch.randn(out_l, in_m, generator=g) * 0.1).to(BF)
+    wa, wb = (torch.randn(out_k, r, generator=g) * 0.3).to(BF), (torch.randn(r, in_n, generator=g) * 0.3).to(BF)
+    dd = (torch.randn(out_dim, in_dim, generator=g) * 0.01).to(BF)
+    # reference: stock torch bf16 autograd on the CPU
+    t1, ta, tb = (t.clone().requires_grad_(True) for t in (w1, wa, wb))
+    reb = torch.kron(t1, (ta @ tb).contiguous())
+    if scale != 1:
+        reb = reb * scale
+    reb.backward(dd)
+    delta = torch.empty(out_dim, in_dim, dtype=BF, device=DEV)
+    ops.lokr_delta(w1.to(DEV), wa.to(DEV), wb.to(DEV), scale, delta)
+    assert torch.equal(delta.cpu(), reb.detach()), "delta_w differs from torch's bf16 kron"
+    g1, ga, gb = (torch.empty_like(t, device=DEV) for t in (w1, wa, wb))
+    ws = torch.empty(int(ops._lib().yat_lokr_project_workspace_bytes(out_l, out_k, in_n)), dtype=torch.uint8, device=DEV)
+    ops.lokr_project(w1.to(DEV), wa.to(DEV), wb.to(DEV), scale, dd.to(DEV), g1, ga, gb, ws)
+    # torch reduces in a different (blocked) order: compare to the fp64 truth with the bf16 tolerance instead of bits
+    d1, da, db = (t.double() for t in (w1, wa, wb))
+    ddd = dd.double() * scale
+    w2 = (wa.float() @ wb.float()).to(BF).double()
+    blk = ddd.view(out_l, out_k, in_m, in_n)
+    tw1 = torch.einsum("ikjn,kn->ij", blk, w2)
+    tw2 = torch.einsum("ikjn,ij->kn", blk, d1).float().to(BF).double()
+    for got, want, cpu, nm in ((g1, tw1, t1.grad, "d_w1"), (ga, tw2 @ db.T, ta.grad, "d_w2_a"), (gb, da.T @ tw2, tb.grad, "d_w2_b")):
+        e_hip, e_cpu = rel(got, want), rel(cpu, want)
+        print(f"[parity] lokr {nm} {out_dim}x{in_dim}: hip_vs_fp64={e_hip:.3e} torch_bf16_vs_fp64={e_cpu:.3e}")
+        assert e_hip <= 1.5 * e_cpu + 3e-3
+
+
+def test_lokr_training_step_matches_oracle():
+    """One adapted training step (tiny SANA, non-zero w1 so the adapters matter): loss / prediction / adapter gradients
+    on the HIP path vs the oracle's bf16 and fp32 runs of the peft-wrapped model, then one clip+AdamW step."""
+    from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
+    from oracle.lokr_ref import apply_lokr
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.lokr import LoKrAdapters
+    from yat_amd.optim import FlatAdamW
+    rcfg = RefCfg.tiny(num_layers=2)
+    ref = SanaTransformerRef(rcfg)
+    init_like_pretrained(ref, 0)
+    ref_bf = copy.deepcopy(ref).to(BF)
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV)
+    hip.load_state_dict(ref_bf.state_dict())
+    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=0.0)
+    g = torch.Generator().manual_seed(7)
+    for e in ad.entries:                                    # meaningful adapters: w1 away from its zero init
+        w1, _, _ = ad._views(e, ad.flat_param)
+        w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+    wrapped = apply_lokr(ref_bf, TARGETS, r=2, alpha=4.0)
+    assert sorted(wrapped) == sorted(e["module"] for e in ad.entries)
+    sd = ad.state_dict()
+    for name, w in wrapped.items():
+        pre = f"base_model.model.{name}."
+        assert (w.out_l, w.out_k, w.in_m, w.in_n) == next((e["out_l"], e["out_k"], e["in_m"], e["in_n"]) for e in ad.entries
+                                                          if e["module"] == name)
+        with torch.no_grad():
+            w.lokr_w1.copy_(sd[pre + "lokr_w1"].cpu())
+            w.lokr_w2_a.copy_(sd[pre + "lokr_w2_a"].cpu())
+            w.lokr_w2_b.copy_(sd[pre + "lokr_w2_b"].cpu())
+    ref_32 = copy.deepcopy(ref_bf).float()
+    B, h, w_ = 2, 6, 10
+    latents = (torch.randn(B, rcfg.in_channels, h, w_, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (9, 30)]
+    outs = {}
+    for tag, model, dt in (("bf16", ref_bf, BF), ("fp32", ref_32, torch.float32)):
+        model.train()
+        loss, pred, _ = optimize_ref(model, RefSched(), latents, embs, torch.Generator().manual_seed(3), pad_to=32, dtype=dt)
+        loss.backward()
+        outs[tag] = (loss.detach(), pred.detach(), {n: (m.lokr_w1.grad, m.lokr_w2_a.grad, m.lokr_w2_b.grad)
+                                                   for n, m in apply_names(model).items()})
+    recipe = SanaRecipe(hip, pad_to=32, device=DEV)
+    hip.train()
+    loss, pred, _ = recipe.optimize(latents, embs, torch.Generator().manual_seed(3), return_pred=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    l32, lbf, lh = float(outs["fp32"][0]), float(outs["bf16"][0]), float(loss.detach())
+    print(f"[parity] lokr loss hip={lh:.6f} oracle_bf16={lbf:.6f} fp32={l32:.6f}")
+    assert abs(lh - l32) <= 1.3 * abs(lbf - l32) + 2e-3 * abs(l32)
+    e_h, e_r = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
+    print(f"[parity] lokr pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
+    assert e_h <= 1.3 * e_r + 1e-3
+    # adapter gradients, all targets together
+    hip_g, bf_g, f_g = [], [], []
+    for e in ad.entries:
+        for t in ad._views(e, ad.flat_grad):
+            hip_g.append(t.float().flatten().cpu())
+        for k, store in ((0, bf_g), (1, f_g)):
+            pass
+        gb_, gf_ = outs["bf16"][2][e["module"]], outs["fp32"][2][e["module"]]
+        bf_g += [t.float().flatten() for t in gb_]
+        f_g += [t.float().flatten() for t in gf_]
+    hg, bg, fg = torch.cat(hip_g), torch.cat(bf_g), torch.cat(f_g)
+    e_h, e_r = rel(hg, fg), rel(bg, fg)
+    print(f"[parity] lokr adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
+    assert torch.isfinite(hg).all() and fg.abs().max() > 0
+    assert e_h <= 1.3 * e_r + 2e-3
+    # one optimizer step over the adapter set only; the base weights do not move
+    before = hip.flat_param.clone()
+    opt = FlatAdamW(ad, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    p0 = ad.flat_param.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(before, hip.flat_param) and not torch.equal(p0, ad.flat_param)
+
+
+def apply_names(model):
+    from oracle.lokr_ref import LoKrWrapped
+    return {n: m for n, m in model.named_modules() if isinstance(m, LoKrWrapped)}

@@ -168,7 +168,10 @@ class Model:
         return str(best)
 
     def save_model(self):
-        self.accelerator.unwrap_model(self.model).save_pretrained(f"models/{self.global_step}")
+        if getattr(self, "adapters", None) is not None:               # a PeftModel saves only its adapter
+            self.adapters.save_pretrained(f"models/{self.global_step}")
+        else:
+            self.accelerator.unwrap_model(self.model).save_pretrained(f"models/{self.global_step}")
 
     def make_sampler(self):
         """Cached-feature sampler over this rank's shard range (the intended path of :165-181)."""
@@ -194,12 +197,24 @@ class Model:
             os.makedirs("models", exist_ok=True)
         if self.sampler is None:
             self.sampler = self.make_sampler()
-        if getattr(p, "lora_rank", None) is not None:
-            raise NotImplementedError("PEFT adapters (lora/loha/lokr) are a later row of the scope table")
-        self.optimizer = FlatAdamW(self.model, lr=p.learning_rate, weight_decay=p.weight_decay, max_grad_norm=1.0,
+        self.adapters = None
+        if getattr(p, "lora_rank", None) is not None:                 # :212-241 (get_peft_model)
+            if getattr(p, "lora_algo", "lora") != "lokr":
+                raise NotImplementedError("only lora_algo: lokr (BASELINE config 5) is built; lora / loha / fourierft are not")
+            if getattr(p, "lora_pretrained", None):
+                raise NotImplementedError("resuming from a saved adapter (lora_pretrained) is not built")
+            from ..lokr import LoKrAdapters
+            self.adapters = LoKrAdapters(self.model, p.lora_target_modules, p.lora_rank, p.lora_alpha,
+                                         module_dropout=getattr(p, "lora_dropout", 0.0) or 0.0)
+            n_ad = self.adapters.num_parameters()
+            print(f"trainable params: {n_ad:,} || all params: {self.model.numel_flat + n_ad:,} || "
+                  f"trainable%: {100.0 * n_ad / (self.model.numel_flat + n_ad):.4f}")       # print_trainable_parameters (:239)
+        # with adapters only they are trained (the base has no gradients, so AdamW leaves it alone in the reference too)
+        trained = self.adapters if self.adapters is not None else self.model
+        self.optimizer = FlatAdamW(trained, lr=p.learning_rate, weight_decay=p.weight_decay, max_grad_norm=1.0,
                                    use_ema=bool(getattr(p, "use_ema", False)), ema_decay=0.999,
                                    overlap_update=True)
-        self.accelerator.prepare(self.model)
+        self.accelerator.prepare(trained)
         self.lr_scheduler = None
         if getattr(p, "warmup_steps", None) is not None:
             self.lr_scheduler = WarmupLR(self.optimizer, p.warmup_steps)
@@ -261,22 +276,23 @@ class Model:
         """:371-401: EMA mean across ranks, then rank 0 swaps EMA weights in, validates, saves, swaps back."""
         with torch.no_grad():
             opt = self.optimizer
-            self.model.join_pending_update()               # the overlapped AdamW/EMA update must have landed
+            trained = opt.model                            # the transformer, or its adapter set
+            trained.join_pending_update()                  # the overlapped AdamW/EMA update must have landed
             if opt.ema_shadow is not None and self.accelerator.num_processes > 1:
                 dist.all_reduce(opt.ema_shadow)            # one flat all-reduce instead of ~600 per-tensor calls
                 opt.ema_shadow /= self.accelerator.num_processes
             if self.accelerator.is_main_process:
                 stored = None
                 if opt.ema_shadow is not None:
-                    stored = self.model.flat_param.clone()
-                    self.model.flat_param.copy_(opt.ema_shadow)
+                    stored = trained.flat_param.clone()
+                    trained.flat_param.copy_(opt.ema_shadow)
                 try:
                     self.validate()
                 except NotImplementedError:
                     pass
                 self.save_model()
                 if stored is not None:
-                    self.model.flat_param.copy_(stored)
+                    trained.flat_param.copy_(stored)
 
 
 class WarmupLR:

@@ -75,7 +75,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int idx0, int kk, i
     }
 }
 
-template <bool A_T, bool B_T>
+template <bool A_T, bool B_T, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
             if (n >= p.N) continue;
-            gemm_epilogue_store(p, acc[i][j], m, n, b);
+            gemm_epilogue_store<PRE>(p, acc[i][j], m, n, b);
         }
     }
 }
@@ -192,6 +192,8 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
         p.act = ep->activation;
         if (p.act < 0 || p.act > 2) return YAT_EINVAL;
         if (p.gate && (p.gate_ld & 3)) return YAT_EINVAL;
+        p.pre_add = (const bf16_t*)ep->pre_add; p.ld_pre = ep->ld_pre_add;
+        if (p.pre_add && ((p.ld_pre & 3) || p.ld_pre < N)) return YAT_EINVAL;
         p.glu_u = (const bf16_t*)ep->glu_u; p.ld_glu = ep->ld_glu_u;
         if (p.glu_u && (p.bias || p.gate || p.res || p.aux || p.act || (p.ld_glu & 3) || p.ld_glu < 2 * N || ldc < 2 * N))
             return YAT_EINVAL;
@@ -230,7 +232,8 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (rc) return rc;
     }
     const bool wide_ok = !(N & 7) && !(ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
-                         !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7));
+                         !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7)) && !(p.pre_add && (p.ld_pre & 7));
+    if (p.pre_add && (a_t || b_t || p.glu_u)) return YAT_EINVAL;       // adapter addend: forward layout only
     if (p.glu_u) {                              // GLU-backward epilogue lives in the 256-row kernel only
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
         if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
@@ -241,6 +244,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
             double best = est_time_128(M, N, K);
             for (int v = 4; v <= 5; ++v)
                 for (int s = 1; s <= 4; s *= 2) {
+                    if (s > 1 && p.pre_add) continue;
                     if (s > 1 && (!workspace || !wide_ok || (uint64_t)s * M * N * 4 > workspace_bytes || K / s < 512)) continue;
                     const double t = est_time_256(M, N, K, v == 4 ? 256 : 320, s);
                     if (t < best) { best = t; variant = v; ksplit = s; }
@@ -262,12 +266,14 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return YAT_EINVAL;
         attr_set = true;
     }
     dim3 grid(p.nbm * p.nbn), block(256);
-    if (!a_t && !b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
+    if (p.pre_add) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true>), grid, block, LDS_BYTES, stream, p);
+    else if (!a_t && !b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
     else if (!a_t && b_t) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, LDS_BYTES, stream, p);
     else if (a_t && b_t) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, LDS_BYTES, stream, p);

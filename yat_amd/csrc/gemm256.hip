@@ -107,7 +107,7 @@ __device__ __forceinline__ int xcd_contiguous(int nwg) {
 }
 
 // One workgroup's whole job: `id` = work item inside problem p (tile x K slice, before the row-group swizzle).
-template <bool A_T, bool B_T, int NT, bool GLU = false>
+template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GLU backward, 2 standard + pre_add
 __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     using G = Geo<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -260,7 +260,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // loads and C / aux stores are 16 B per lane over whole 128..160-B row segments.
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
     const bool wide = !(p.N & 7) && !(p.ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
-                      !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7));
+                      !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7)) && !(p.pre_add && (p.ld_pre & 7));
     const bool split = p.ksplit > 1;           // host guarantees `wide` alignment when splitting
     if (wide || split) {
         constexpr int WCOLS = 16 * NT;             // columns per wave
@@ -293,8 +293,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                             *reinterpret_cast<f32x4*>(dst + 4) = hi;
                         } else {
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            if (GLU) glu_bwd_store<8>(p, v, m, n);
-                            else gemm_epilogue_store8(p, v, m, n, m / rpb);
+                            if (EPI == 1) glu_bwd_store<8>(p, v, m, n);
+                            else gemm_epilogue_store8<EPI == 2>(p, v, m, n, m / rpb);
                         }
                     }
                 }
@@ -312,19 +312,19 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (int j = 0; j < NT; ++j) {
             const int n = n0 + wc * 16 * NT + j * 16 + 4 * (lane >> 4);
             if (n >= p.N) continue;
-            if (GLU) {
+            if (EPI == 1) {
                 const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 glu_bwd_store<4>(p, v, m, n);
             } else {
-                gemm_epilogue_store(p, acc[i][j], m, n, b);
+                gemm_epilogue_store<EPI == 2>(p, acc[i][j], m, n, b);
             }
         }
     }
 }
 
-template <bool A_T, bool B_T, int NT, bool GLU = false>
+template <bool A_T, bool B_T, int NT, int EPI = 0>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
-    gemm256_body<A_T, B_T, NT, GLU>(p, xcd_contiguous(p.nbm * p.nbn * p.ksplit));
+    gemm256_body<A_T, B_T, NT, EPI>(p, xcd_contiguous(p.nbm * p.nbn * p.ksplit));
 }
 
 // Grouped launch: up to YAT_MAX_GROUP independent problems of one layout in ONE grid (problem g owns work items
@@ -373,7 +373,7 @@ int launch256_grouped(int ngroups, const GemmP* probs, hipStream_t stream) {
     return e == hipSuccess ? YAT_OK : (int)e;
 }
 
-template <bool A_T, bool B_T, int NT, bool GLU = false>
+template <bool A_T, bool B_T, int NT, int EPI = 0>
 int launch256(const GemmP& p0, hipStream_t stream) {
     using G = Geo<NT>;
     GemmP p = p0;
@@ -381,13 +381,13 @@ int launch256(const GemmP& p0, hipStream_t stream) {
     p.nbn = (p.N + G::BN - 1) / G::BN;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm256_kernel<A_T, B_T, NT, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gemm256_kernel<A_T, B_T, NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G::LDS) != hipSuccess)
             return YAT_EINVAL;
         attr_set = true;
     }
     if (p.ksplit < 1) p.ksplit = 1;
-    hipLaunchKernelGGL((gemm256_kernel<A_T, B_T, NT, GLU>), dim3(p.nbm * p.nbn * p.ksplit), dim3(512), G::LDS, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<A_T, B_T, NT, EPI>), dim3(p.nbm * p.nbn * p.ksplit), dim3(512), G::LDS, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? YAT_OK : (int)e;
 }
@@ -436,7 +436,11 @@ int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs
 int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream) {
     if (p.glu_u) {                 // GLU-backward epilogue: only the dgrad layout (dy W) is instantiated, no split-K
         if (a_t || !b_t || p.ksplit > 1) return YAT_EINVAL;
-        return nt_variant == 5 ? launch256<false, true, 5, true>(p, stream) : launch256<false, true, 4, true>(p, stream);
+        return nt_variant == 5 ? launch256<false, true, 5, 1>(p, stream) : launch256<false, true, 4, 1>(p, stream);
+    }
+    if (p.pre_add) {               // adapter addend: only the forward layout (x W^T) is instantiated, no split-K
+        if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;
+        return nt_variant == 5 ? launch256<false, false, 5, 2>(p, stream) : launch256<false, false, 4, 2>(p, stream);
     }
 #define YAT_CASE(AT, BT)                                                     \
     if (a_t == AT && b_t == BT)                                              \

@@ -17,6 +17,8 @@ struct GemmP {
     float* partial;        // [ksplit][M][N] fp32 (caller workspace)
     const bf16_t* glu_u;   // GLU backward epilogue: u = [u_a | u_g] of the depthwise conv, [M, ld_glu]; C is [M, 2N]
     int ld_glu;
+    const bf16_t* pre_add; // adapter path: [M, ld_pre] added to the rounded Linear output before aux / activation / gate
+    int ld_pre;
 };
 
 // GLU backward fused into the producer of dy (= this GEMM's result d, rounded to bf16 like the Linear's output):
@@ -53,6 +55,9 @@ __device__ __forceinline__ void glu_bwd_store(const GemmP& p, const float (&v)[W
 
 // One lane's 4 consecutive output columns of row m (swapped-operand MFMA result):
 // +bias -> round bf16 (the Linear's output) -> aux store -> activation -> *gate (rounded) -> +residual -> store.
+// PRE (own template instantiation, like the GLU one): result = bf16( bf16(acc + bias) + pre_add[m,n] ) -- a PEFT adapter's
+// ``base_layer(x) + F.linear(x, delta_w)`` with the second term computed by a previous launch.
+template <bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4& a, int m, int n, int b) {
     float v[4] = {a[0], a[1], a[2], a[3]};
     if (p.bias) {
@@ -60,6 +65,12 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4&
         unpack4(*reinterpret_cast<const u32x2*>(p.bias + n), bb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bb[e];
+    }
+    if (PRE) {
+        float pa[4];
+        unpack4(*reinterpret_cast<const u32x2*>(p.pre_add + (int64_t)m * p.ld_pre + n), pa);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + pa[e];
     }
     if (p.aux || p.act || p.res) {
 #pragma unroll
@@ -89,12 +100,19 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4&
 }
 
 // Same for 8 consecutive columns (16-B accesses; n % 8 == 0 and every leading dimension % 8 == 0).
+template <bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[8], int m, int n, int b) {
     if (p.bias) {
         float bb[8];
         unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bb[e];
+    }
+    if (PRE) {
+        float pa[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.pre_add + (int64_t)m * p.ld_pre + n), pa);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]) + pa[e];
     }
     if (p.aux || p.act || p.res) {
 #pragma unroll

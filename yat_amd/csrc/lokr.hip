@@ -1,0 +1,147 @@
+// LoKr adapter support kernels for gfx950 (BASELINE config 5: ``lora_algo: lokr`` -> peft LoKrConfig(r, alpha,
+// module_dropout, target_modules) wrapped around the model at /root/reference/common/trainer.py:212-238).
+//
+// [RECALL peft/tuners/lokr/layer.py]  For a target Linear / 1x1 Conv with weight [out, in]:
+//   (out_l, out_k) = factorization(out), (in_m, in_n) = factorization(in);  w1 [out_l, in_m] (zeros at init),
+//   w2 = w2_a [out_k, r] @ w2_b [r, in_n] (both kaiming-uniform);  delta_w = kron(w1, w2) * (alpha / r);
+//   forward: base_layer(x) + F.linear(x, delta_w)   -- all in the module dtype (bf16), every op rounding.
+// The dense products (x delta_w^T, dy delta_w, d_delta = dy^T x) run on the GEMM kernels of this library; what is left
+// is HBM-bound glue, one launch per adapter:
+//   yat_lokr_delta   : w2 = bf16(w2_a w2_b);  delta[(i,k),(j,n)] = bf16( bf16(w1[i,j] * w2[k,n]) * scale )
+//   yat_lokr_project : autograd of the above from d_delta: d_w1, d_w2 (fp32 sums, fixed order), d_w2_a, d_w2_b.
+#include "common.hpp"
+#include "../../include/yat_hip.h"
+
+namespace {
+
+struct LokrP {
+    int out_l, out_k, in_m, in_n, r, ld;
+    float scale;
+    const bf16_t* w1; const bf16_t* w2a; const bf16_t* w2b;
+};
+
+__device__ __forceinline__ float w2_elem(const LokrP& p, int k, int n) {
+    float s = 0.f;
+    for (int q = 0; q < p.r; ++q) s += bf2f(p.w2a[k * p.r + q]) * bf2f(p.w2b[q * p.in_n + n]);
+    return rbf(s);                                             // the bf16 matmul w2_a @ w2_b
+}
+
+// grid (ceil(in / 256), out): one thread per element, consecutive threads along the row
+__global__ __launch_bounds__(256) void lokr_delta_kernel(LokrP p, bf16_t* delta) {
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    const int in = p.in_m * p.in_n;
+    if (col >= in) return;
+    const int i = row / p.out_k, k = row - i * p.out_k, j = col / p.in_n, n = col - j * p.in_n;
+    float v = rbf(bf2f(p.w1[i * p.in_m + j]) * w2_elem(p, k, n));          // torch.kron in bf16
+    if (p.scale != 1.0f) v = rbf(v * p.scale);                             // make_kron: rebuild * scale (skipped at 1)
+    delta[(int64_t)row * p.ld + col] = f2bf(v);
+}
+
+// d_w1[i,j] = sum_{k,n} dR[(i,k),(j,n)] * w2[k,n],  dR = bf16(d_delta * scale).  One workgroup per (i,j).
+__global__ __launch_bounds__(256) void lokr_dw1_kernel(LokrP p, const bf16_t* dd, bf16_t* dw1) {
+    __shared__ float red[4];
+    const int j = blockIdx.x, i = blockIdx.y;
+    float s = 0.f;
+    const int per = p.out_k * p.in_n;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int k = e / p.in_n, n = e - k * p.in_n;
+        float g = bf2f(dd[((int64_t)i * p.out_k + k) * p.ld + j * p.in_n + n]);
+        if (p.scale != 1.0f) g = rbf(g * p.scale);
+        s += g * w2_elem(p, k, n);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw1[i * p.in_m + j] = f2bf(red[0] + red[1] + red[2] + red[3]);
+}
+
+// partial[i][k*in_n + n] = sum_j dR[(i,k),(j,n)] * w1[i,j]   (one workgroup per i; summed over i by the next kernel)
+__global__ __launch_bounds__(256) void lokr_dw2_partial_kernel(LokrP p, const bf16_t* dd, float* partial) {
+    const int i = blockIdx.x;
+    const int per = p.out_k * p.in_n;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int k = e / p.in_n, n = e - k * p.in_n;
+        const bf16_t* row = dd + ((int64_t)i * p.out_k + k) * p.ld + n;
+        float s = 0.f;
+        for (int j = 0; j < p.in_m; ++j) {
+            float g = bf2f(row[j * p.in_n]);
+            if (p.scale != 1.0f) g = rbf(g * p.scale);
+            s += g * bf2f(p.w1[i * p.in_m + j]);
+        }
+        partial[(int64_t)i * per + e] = s;
+    }
+}
+
+// d_w2 = bf16(sum_i partial[i]);  then d_w2_a = bf16(d_w2 w2_b^T), d_w2_b = bf16(w2_a^T d_w2) -- one workgroup, the
+// d_w2 tile staged in LDS (out_k * in_n <= 16 K elements for every SANA target).
+__global__ __launch_bounds__(256) void lokr_dw2_final_kernel(LokrP p, const float* partial, bf16_t* dw2a, bf16_t* dw2b) {
+    extern __shared__ float dw2[];
+    const int per = p.out_k * p.in_n;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        float s = 0.f;
+        for (int i = 0; i < p.out_l; ++i) s += partial[(int64_t)i * per + e];
+        dw2[e] = rbf(s);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < p.out_k * p.r; e += 256) {          // d_w2_a[k, q] = sum_n d_w2[k, n] * w2_b[q, n]
+        const int k = e / p.r, q = e - k * p.r;
+        float s = 0.f;
+        for (int n = 0; n < p.in_n; ++n) s += dw2[k * p.in_n + n] * bf2f(p.w2b[q * p.in_n + n]);
+        dw2a[e] = f2bf(s);
+    }
+    for (int e = threadIdx.x; e < p.r * p.in_n; e += 256) {           // d_w2_b[q, n] = sum_k w2_a[k, q] * d_w2[k, n]
+        const int q = e / p.in_n, n = e - q * p.in_n;
+        float s = 0.f;
+        for (int k = 0; k < p.out_k; ++k) s += bf2f(p.w2a[k * p.r + q]) * dw2[k * p.in_n + n];
+        dw2b[e] = f2bf(s);
+    }
+}
+
+int fill(LokrP& p, int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2a, const void* w2b,
+         float scale, int ld) {
+    if (out_l <= 0 || out_k <= 0 || in_m <= 0 || in_n <= 0 || r <= 0 || r > 64 || !w1 || !w2a || !w2b ||
+        ld < in_m * in_n || out_l * out_k > 65535)
+        return YAT_EINVAL;
+    p.out_l = out_l; p.out_k = out_k; p.in_m = in_m; p.in_n = in_n; p.r = r; p.ld = ld; p.scale = scale;
+    p.w1 = (const bf16_t*)w1; p.w2a = (const bf16_t*)w2a; p.w2b = (const bf16_t*)w2b;
+    return YAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yat_lokr_delta(int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2_a, const void* w2_b,
+                   float scale, void* delta, int ld, yat_stream_t stream) {
+    LokrP p;
+    if (fill(p, out_l, out_k, in_m, in_n, r, w1, w2_a, w2_b, scale, ld) || !delta) return YAT_EINVAL;
+    hipLaunchKernelGGL(lokr_delta_kernel, dim3((in_m * in_n + 255) / 256, out_l * out_k), dim3(256), 0, (hipStream_t)stream, p,
+                       (bf16_t*)delta);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+uint64_t yat_lokr_project_workspace_bytes(int out_l, int out_k, int in_n) {
+    return (uint64_t)out_l * out_k * in_n * sizeof(float);
+}
+
+int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2_a, const void* w2_b,
+                     float scale, const void* d_delta, int ld, void* d_w1, void* d_w2_a, void* d_w2_b, void* workspace,
+                     yat_stream_t stream) {
+    LokrP p;
+    if (fill(p, out_l, out_k, in_m, in_n, r, w1, w2_a, w2_b, scale, ld) || !d_delta || !d_w1 || !d_w2_a || !d_w2_b ||
+        !workspace || (uint64_t)out_k * in_n * sizeof(float) > 65536)
+        return YAT_EINVAL;
+    hipLaunchKernelGGL(lokr_dw1_kernel, dim3(in_m, out_l), dim3(256), 0, (hipStream_t)stream, p, (const bf16_t*)d_delta,
+                       (bf16_t*)d_w1);
+    YAT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(lokr_dw2_partial_kernel, dim3(out_l), dim3(256), 0, (hipStream_t)stream, p, (const bf16_t*)d_delta,
+                       (float*)workspace);
+    YAT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(lokr_dw2_final_kernel, dim3(1), dim3(256), out_k * in_n * sizeof(float), (hipStream_t)stream, p,
+                       (const float*)workspace, (bf16_t*)d_w2_a, (bf16_t*)d_w2_b);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+}  // extern "C"

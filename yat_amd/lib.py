@@ -18,7 +18,7 @@ P, I, I64, U64, F, D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
                 ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I),
-                ("glu_u", P), ("ld_glu_u", I)]
+                ("glu_u", P), ("ld_glu_u", I), ("pre_add", P), ("ld_pre_add", I)]
 
 
 class GemmProblem(C.Structure):
@@ -32,6 +32,9 @@ SIGNATURES = {
     "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
     "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P, U64, P]),
     "yat_gemm_grouped_bf16": (I, [I, I, I, C.POINTER(GemmProblem), P]),
+    "yat_lokr_delta": (I, [I, I, I, I, I, P, P, P, F, P, I, P]),
+    "yat_lokr_project_workspace_bytes": (U64, [I, I, I]),
+    "yat_lokr_project": (I, [I, I, I, I, I, P, P, P, F, P, I, P, P, P, P, P]),
     "yat_colsum_workspace_bytes": (U64, [I, I]),
     "yat_colsum_bf16": (I, [I, I, P, I, P, I, P, P]),
     "yat_modulation_fwd": (I, [I, I, I, P, P, I, I, P, P]),

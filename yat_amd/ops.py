@@ -60,17 +60,18 @@ def _chk_bf16(*ts):
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
          activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
-         glu_u=None):
+         glu_u=None, pre_add=None):
     """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
-    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u)
+    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add)
     lda = lda if lda is not None else (M if a_t else K)
     ldb = ldb if ldb is not None else (N if b_t else K)
     ldc = ldc if ldc is not None else N
     ep = None
     if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None \
-            or glu_u is not None:
+            or glu_u is not None or pre_add is not None:
         ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
-                             ld_residual, rows_per_batch, _p(glu_u), 0 if glu_u is None else glu_u.stride(0))
+                             ld_residual, rows_per_batch, _p(glu_u), 0 if glu_u is None else glu_u.stride(0),
+                             _p(pre_add), 0 if pre_add is None else pre_add.stride(0))
     timer = GEMM_TIMER
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -136,7 +137,7 @@ def wgrad_grouped(items, accumulate=False):
         pr.M, pr.N, pr.K = N, K, M
         pr.A, pr.lda, pr.B, pr.ldb, pr.C, pr.ldc = _p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), K
         if accumulate:
-            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out), 0, 0, K, 0, None, 0)
+            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out), 0, 0, K, 0, None, 0, None, 0)
             pr.epilogue = C.pointer(eps[i])
         flops += 2.0 * M * N * K
     timer = GEMM_TIMER
@@ -148,6 +149,22 @@ def wgrad_grouped(items, accumulate=False):
         e1.record()
         timer.append((flops, e0, e1, ("tt", 0, 0, 0, f"grouped x{n}", False, accumulate, False)))
     _l.check(rc, "yat_gemm_grouped_bf16")
+
+
+def lokr_delta(w1, w2a, w2b, scale, delta2d):
+    """delta2d [out, in] (a view with row stride) <- kron(w1, w2a @ w2b) * scale, bf16 op by op (yat_lokr_delta)."""
+    (out_l, in_m), (out_k, r), in_n = w1.shape, w2a.shape, w2b.shape[1]
+    assert delta2d.shape == (out_l * out_k, in_m * in_n)
+    rc = _lib().yat_lokr_delta(out_l, out_k, in_m, in_n, r, _p(w1), _p(w2a), _p(w2b), float(scale), _p(delta2d),
+                               delta2d.stride(0), _stream())
+    _l.check(rc, "yat_lokr_delta")
+
+
+def lokr_project(w1, w2a, w2b, scale, d_delta2d, dw1, dw2a, dw2b, workspace):
+    (out_l, in_m), (out_k, r), in_n = w1.shape, w2a.shape, w2b.shape[1]
+    rc = _lib().yat_lokr_project(out_l, out_k, in_m, in_n, r, _p(w1), _p(w2a), _p(w2b), float(scale), _p(d_delta2d),
+                                 d_delta2d.stride(0), _p(dw1), _p(dw2a), _p(dw2b), _p(workspace), _stream())
+    _l.check(rc, "yat_lokr_project")
 
 
 def colsum(x2d, out, workspace, accumulate=False):

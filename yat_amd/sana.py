@@ -173,6 +173,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
         self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
         self._side = None
+        self.adapters = None              # yat_amd.lokr.LoKrAdapters when the config asks for PEFT adapters
         self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
         self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
         self._arena = {}
@@ -299,6 +300,18 @@ class SanaTransformer2DModelHIP(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None      # per-bucket events of an AdamW update still in flight
+        ad = self.adapters
+        if ad is not None:
+            ad.materialize(self.training)                     # delta_w of every target for this step (yat_amd/lokr.py)
+
+        def lin(x_, w_, bias_=None, out=None, **ep):
+            """Linear of a (possibly adapted) target: with adapters, x delta_w^T is computed first and folded into the
+            base GEMM right after its bias rounding (peft: base_layer(x) + F.linear(x, delta_w))."""
+            if ad is None:
+                return ops.linear_fwd(x_, w_, bias_, out=out, **ep)
+            tmp = torch.empty(x_.shape[0], w_.shape[0], dtype=BF16, device=x_.device)
+            ops.linear_fwd(x_, ad.delta_like(w_), None, out=tmp)
+            return ops.linear_fwd(x_, w_, bias_, out=out, pre_add=tmp, **ep)
 
         def params_ready(bucket, stream=main):
             if pev is not None:
@@ -309,9 +322,9 @@ class SanaTransformer2DModelHIP(nn.Module):
         # the main chain leave idle.
         def text_branch():
             S.zc1 = buf("cap_z1", (Mt, D))
-            S.c1 = ops.linear_fwd(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
+            S.c1 = lin(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
                                   out=buf("cap_c1", (Mt, D)), activation="gelu_tanh", aux_out=S.zc1)
-            S.c2 = ops.linear_fwd(S.c1, P["caption_projection.linear_2.weight"], P["caption_projection.linear_2.bias"],
+            S.c2 = lin(S.c1, P["caption_projection.linear_2.weight"], P["caption_projection.linear_2.bias"],
                                   out=buf("cap_c2", (Mt, D)))
             S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, buf("cap_n", (Mt, D)),
                                                  buf("cap_rstd", (Mt,), torch.float32))
@@ -322,7 +335,7 @@ class SanaTransformer2DModelHIP(nn.Module):
                 params_ready(i + 1, cur)
                 wkv, _ = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
                 bkv, _ = self._fused(pre + "attn2.to_k.bias", 2 * D)
-                S.kv2.append(ops.linear_fwd(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D))))
+                S.kv2.append(lin(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D))))
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(cur)
@@ -338,15 +351,15 @@ class SanaTransformer2DModelHIP(nn.Module):
 
         # 1. patch embed (1x1 conv == Linear over channels) on token-major rows
         S.x_tok = ops.transpose(latents.view(B, Cin, N), buf("x_tok", (B, N, Cin))).view(M, Cin)
-        x = ops.linear_fwd(S.x_tok, P["patch_embed.proj.weight"].view(D, Cin), P["patch_embed.proj.bias"],
+        x = lin(S.x_tok, P["patch_embed.proj.weight"].view(D, Cin), P["patch_embed.proj.bias"],
                            out=buf("x0", (M, D)))
         # 2. timestep embedding (AdaLayerNormSingle)
         S.tproj = ops.timestep_embed(t_f32, 256, buf("tproj", (B, 256)))
         S.z1 = buf("te_z1", (B, D))
-        S.e1 = ops.linear_fwd(S.tproj, P["time_embed.emb.timestep_embedder.linear_1.weight"],
+        S.e1 = lin(S.tproj, P["time_embed.emb.timestep_embedder.linear_1.weight"],
                               P["time_embed.emb.timestep_embedder.linear_1.bias"], out=buf("te_e1", (B, D)),
                               activation="silu", aux_out=S.z1)
-        S.embedded = ops.linear_fwd(S.e1, P["time_embed.emb.timestep_embedder.linear_2.weight"],
+        S.embedded = lin(S.e1, P["time_embed.emb.timestep_embedder.linear_2.weight"],
                                     P["time_embed.emb.timestep_embedder.linear_2.bias"], out=buf("te_emb", (B, D)))
         S.se = ops.act_fwd(S.embedded, "silu", buf("te_se", (B, D)))
         S.tmod = ops.linear_fwd(S.se, P["time_embed.linear.weight"], P["time_embed.linear.bias"],
@@ -370,7 +383,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             A.h2, A.mean2, A.rstd2 = buf(f"b{i}.h2", (M, D)), buf(f"b{i}.mean2", (M,), f32), buf(f"b{i}.rstd2", (M,), f32)
             A.z, A.s = buf(f"b{i}.z", (M, 2 * Hc)), buf(f"b{i}.s", (M, 2 * Hc))          # z: pre-activation, for SiLU'
             A.y, A.lin3, A.x3 = buf(f"b{i}.y", (M, Hc)), buf(f"b{i}.lin3", (M, D)), buf(f"b{i}.x3", (M, D))
-            A.u = buf(f"b{i}.u", (M, 2 * Hc)) if self.keep_glu_u else None      # depthwise-conv output, for the backward
+            A.u = buf(f"b{i}.u", (M, 2 * Hc)) if (self.keep_glu_u and ad is None) else None      # depthwise-conv output, for the backward
             A.x_in = x if i == 0 else S.blocks[i - 1].x3
             S.blocks.append(A)
         S.x_last = S.blocks[-1].x3 if cfg.num_layers else x
@@ -393,27 +406,27 @@ class SanaTransformer2DModelHIP(nn.Module):
                 ops.ln_modulate_fwd(xin, mod2d[:, 0:D], mod2d[:, D:2 * D], 6 * D, N, cfg.norm_eps, A.h1[rs], A.mean1[rs],
                                     A.rstd1[rs])
                 wqkv, _ = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
-                ops.linear_fwd(A.h1[rs], wqkv, out=A.qkv[rs])
+                lin(A.h1[rs], wqkv, out=A.qkv[rs])
                 ops.linear_attn_fwd(A.qkv[rs], nb, N, H1, D, 2 * D, A.attn[rs],
                                     A.la_state[b0 * la_per_image:b1 * la_per_image])
-                ops.linear_fwd(A.attn[rs], P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"], out=A.x1[rs],
+                lin(A.attn[rs], P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"], out=A.x1[rs],
                                aux_out=A.lin1[rs], gate=mod2d[:, 2 * D:3 * D], ld_gate=6 * D, residual=xin,
                                rows_per_batch=N)
-                ops.linear_fwd(A.x1[rs], P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"], out=A.q2[rs])
+                lin(A.x1[rs], P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"], out=A.q2[rs])
                 if side is not None:
                     stream.wait_event(S.kv_ready[i])
                 kv = A.kv2[ts]
                 ops.sdpa_fwd(A.q2[rs], kv[:, :D], kv[:, D:], nb, N, T, H2, dh2, scale2, key_bias[bs], kv_len[bs], A.o2[rs],
                              A.lse[bs])
-                ops.linear_fwd(A.o2[rs], P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"], out=A.x2[rs],
+                lin(A.o2[rs], P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"], out=A.x2[rs],
                                residual=A.x1[rs])
                 ops.ln_modulate_fwd(A.x2[rs], mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, A.h2[rs],
                                     A.mean2[rs], A.rstd2[rs])
-                ops.linear_fwd(A.h2[rs], P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), P[pre + "ff.conv_inverted.bias"],
+                lin(A.h2[rs], P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), P[pre + "ff.conv_inverted.bias"],
                                out=A.s[rs], activation="silu", aux_out=A.z[rs])
                 ops.dwconv_glu_fwd(A.s[rs], nb, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                    P[pre + "ff.conv_depth.bias"], A.y[rs], u_out=None if A.u is None else A.u[rs])
-                ops.linear_fwd(A.y[rs], P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=A.x3[rs], aux_out=A.lin3[rs],
+                lin(A.y[rs], P[pre + "ff.conv_point.weight"].view(D, Hc), None, out=A.x3[rs], aux_out=A.lin3[rs],
                                gate=mod2d[:, 5 * D:6 * D], ld_gate=6 * D, residual=A.x2[rs], rows_per_batch=N)
             # output head: modulated norm + proj_out + unpatchify
             ops.modulation_fwd(P["scale_shift_table"], S.embedded[bs], 0, S.modf[bs])
@@ -482,6 +495,14 @@ class SanaTransformer2DModelHIP(nn.Module):
         ws_dw = buf("ws_dw", (ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc),), u8)
         la_ws = buf("la_ws", (ops.linear_attn_workspace_bytes(B, N, H1),), u8)
         scale2 = 1.0 / math.sqrt(dh2)
+        ad = self.adapters
+
+        def dgrad(dy_, w_, out=None, residual=None):
+            """Input gradient through a (possibly adapted) target: dy W, plus dy delta_w accumulated in place."""
+            r_ = ops.linear_dgrad(dy_, w_, out=out, residual=residual)
+            if ad is not None:
+                ops.linear_dgrad(dy_, ad.delta_like(w_), out=r_, residual=r_)
+            return r_
 
         # Weight/bias gradients are off the critical path (nothing in backward reads them): they go to a second
         # stream so their blocks fill the CUs the single-round dgrad launches leave idle, and their prologue/epilogue
@@ -586,13 +607,13 @@ class SanaTransformer2DModelHIP(nn.Module):
                 du_, dy = ops.linear_dgrad_glu(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), A.u,
                                                buf("du", (M, 2 * Hc))), None
             else:
-                du_, dy = None, ops.linear_dgrad(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
+                du_, dy = None, dgrad(dlin3, P[pre + "ff.conv_point.weight"].view(D, Hc), out=buf("dy", (M, Hc)))
             ops.dwconv_glu_bwd(A.s, A.z, B, h, w, Hc, P[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
                                dz_colsum=G[pre + "ff.conv_inverted.bias"], du=du_)        # bias gradient in the same pass
             emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), group="big")
-            dh2_ = ops.linear_dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf(f"dh2.{par}", (M, D)))
+            dh2_ = dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf(f"dh2.{par}", (M, D)))
             other = dxb if dx is dxa else dxa
             # LayerNorm backward: dx on the chain; the shift/scale gradients (column statistics) feed only the
             # modulation tables and go to the side stream
@@ -604,7 +625,7 @@ class SanaTransformer2DModelHIP(nn.Module):
                     *ln2, None, None, dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln, parts=2))
             # x2 = x1 + to_out(o2)
             emit(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"], group=True)
-            do2 = ops.linear_dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf(f"do2.{par}", (M, D)))
+            do2 = dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf(f"do2.{par}", (M, D)))
             dq2 = buf(f"dq2.{par}", (M, D))
             dkv2 = buf(f"dkv2.{par}", (Mt, 2 * D))
             delta = buf(f"delta.{par}", (B, H2, N), f32)
@@ -615,7 +636,7 @@ class SanaTransformer2DModelHIP(nn.Module):
             if side is not None:
                 off_chain(lambda sd=sd: ops.sdpa_bwd(*sd, work=S.kv_work, parts=2))
             emit(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"], group=True)
-            dx1 = ops.linear_dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
+            dx1 = dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
             emit(dkv2, S.encn, gkv, gbkv, group="big")
@@ -641,12 +662,12 @@ class SanaTransformer2DModelHIP(nn.Module):
                         if bias_ is not None:
                             ops.colsum(a, bias_, ws_col, accumulate=acc)
                 off_chain(small_grads)
-            dattn = ops.linear_dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
+            dattn = dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf(f"dqkv.{par}", (M, 3 * D))
             ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
             emit(dqkv, A.h1, gqkv)
-            dh1 = ops.linear_dgrad(dqkv, wqkv, out=buf(f"dh1.{par}", (M, D)))
+            dh1 = dgrad(dqkv, wqkv, out=buf(f"dh1.{par}", (M, D)))
             ln1 = (A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1)
             dx = ops.ln_modulate_bwd(*ln1, dx1, dx, dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln,
                                      parts=1 if side is not None else 3)
@@ -670,7 +691,7 @@ class SanaTransformer2DModelHIP(nn.Module):
                     ops.colsum(dq2, G[pre + "attn2.to_q.bias"], ws_col, accumulate=acc)
                     ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
                 # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
-                ops.linear_dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
+                dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
 
             if side is None:
                 block_grads()
@@ -699,7 +720,7 @@ class SanaTransformer2DModelHIP(nn.Module):
         ops.rmsnorm_bwd(S.c2, P["caption_norm.weight"], S.enc_rstd, denc, dc2, G["caption_norm.weight"], ws_rms,
                         accumulate_dw=acc)
         wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D), "caption_projection.linear_2.bias")
-        dc1 = ops.linear_dgrad(dc2, P["caption_projection.linear_2.weight"], out=denc)
+        dc1 = dgrad(dc2, P["caption_projection.linear_2.weight"], out=denc)
         dzc1 = ops.act_bwd(S.zc1, dc1, "gelu_tanh", dc2)
         wgrad(dzc1, S.enc2d, "caption_projection.linear_1.weight", (D, cfg.caption_channels), "caption_projection.linear_1.bias")
         # timestep branch
@@ -710,11 +731,13 @@ class SanaTransformer2DModelHIP(nn.Module):
         demb_b = ops.f32_to_bf16(demb, buf("te_d3", (B, D)))
         d_emb = ops.add_bf16(demb_a, demb_b, buf("te_d1", (B, D)))
         wgrad(d_emb, S.e1, "time_embed.emb.timestep_embedder.linear_2.weight", (D, D), "time_embed.emb.timestep_embedder.linear_2.bias")
-        de1 = ops.linear_dgrad(d_emb, P["time_embed.emb.timestep_embedder.linear_2.weight"], out=buf("te_d2", (B, D)))
+        de1 = dgrad(d_emb, P["time_embed.emb.timestep_embedder.linear_2.weight"], out=buf("te_d2", (B, D)))
         dz1 = ops.act_bwd(S.z1, de1, "silu", buf("te_d3", (B, D)))
         wgrad(dz1, S.tproj, "time_embed.emb.timestep_embedder.linear_1.weight", (D, 256), "time_embed.emb.timestep_embedder.linear_1.bias")
         if self.grad_ready is not None:
             self.grad_ready(0)
+        if ad is not None:
+            ad.project()                  # d_delta_w (flat gradient slots of the frozen targets) -> adapter gradients
 
     # ------------------------------------------------------------------ checkpoint I/O (diffusers layout)
     def save_pretrained(self, path):
