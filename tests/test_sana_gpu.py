@@ -45,17 +45,18 @@ def _setup(cfg_kw, B, h, w, lens, pad_to, seed=0):
     return ref_bf, ref_32, hip, latents, embs
 
 
-@pytest.mark.parametrize("B,h,w,lens,pad_to,layers", [
-    (2, 4, 4, [5, 16], 16, 2),
-    (3, 6, 10, [7, 40, 1], 64, 2),
-    (2, 16, 8, [100, 33], 128, 3),
+@pytest.mark.parametrize("B,h,w,lens,pad_to,layers,modified", [
+    (2, 4, 4, [5, 16], 16, 2, []),
+    (3, 6, 10, [7, 40, 1], 64, 2, []),
+    (2, 16, 8, [100, 33], 128, 3, []),
+    (2, 6, 10, [7, 40], 64, 3, [0, 2]),          # blocks 0 and 2 with softmax self-attention (modified_blocks)
 ])
-def test_step_matches_oracle(B, h, w, lens, pad_to, layers):
+def test_step_matches_oracle(B, h, w, lens, pad_to, layers, modified):
     from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
     from yat_amd.recipe import SanaRecipe
     from yat_amd.scheduler import FlowMatchSchedule
     from yat_amd.optim import FlatAdamW
-    ref_bf, ref_32, hip, latents, embs = _setup(dict(num_layers=layers), B, h, w, lens, pad_to)
+    ref_bf, ref_32, hip, latents, embs = _setup(dict(num_layers=layers, modified_blocks=list(modified)), B, h, w, lens, pad_to)
     sched = RefSched()
     # the reference creates a fresh, unseeded CPU generator every step (common/trainer.py:325)
     loss_bf, pred_bf, _ = optimize_ref(ref_bf, sched, latents, embs, torch.Generator(), pad_to, BF)

@@ -72,8 +72,8 @@ class SanaConfig:
             raise ValueError("linear attention kernel is built for head dim 32 (SANA)")
         if self.patch_size != 1:
             raise ValueError("patch_size 1 only (SANA)")
-        if self.modified_blocks:
-            raise NotImplementedError("softmax self-attention blocks (modified_blocks) are not built yet")
+        if any(not (0 <= int(b) < self.num_layers) for b in self.modified_blocks):
+            raise ValueError("modified_blocks out of range")
         if self.num_cross_attention_heads * self.cross_attention_head_dim != D or self.cross_attention_dim != D:
             raise ValueError("cross attention inner dim must equal the model dim")
         if D % 8 or self.ffn_hidden % 8 or self.caption_channels % 8 or self.in_channels % 8 or self.out_channels % 4:
@@ -377,6 +377,8 @@ class SanaTransformer2DModelHIP(nn.Module):
             A.h1, A.mean1, A.rstd1 = buf(f"b{i}.h1", (M, D)), buf(f"b{i}.mean1", (M,), f32), buf(f"b{i}.rstd1", (M,), f32)
             A.qkv = buf(f"b{i}.qkv", (M, 3 * D))
             A.la_state = buf(f"b{i}.la_state", (B * H1 * 33 * 32,), f32)                  # kept for the backward
+            A.softmax1 = i in cfg.modified_blocks             # attn1 as softmax attention (patch_sana_attention_layers.py:125-131)
+            A.lse1 = buf(f"b{i}.lse1", (B, H1, N), f32) if A.softmax1 else None
             A.attn, A.lin1, A.x1, A.q2 = (buf(f"b{i}.{n}", (M, D)) for n in ("attn", "lin1", "x1", "q2"))
             A.kv2 = S.kv2[i]
             A.o2, A.lse, A.x2 = buf(f"b{i}.o2", (M, D)), buf(f"b{i}.lse", (B, H2, N), f32), buf(f"b{i}.x2", (M, D))
@@ -392,6 +394,10 @@ class SanaTransformer2DModelHIP(nn.Module):
         out_tok = buf("out_tok", (M, Cout))
         pred = torch.empty(B, Cout, N, dtype=BF16, device=dev)
         la_per_image = H1 * 33 * 32
+        if cfg.modified_blocks:
+            zero_bias = buf("sa_zero_bias", (B, N), f32).zero_()
+            full_len = torch.full((B,), N, dtype=torch.int32, device=dev)
+            S.zero_bias, S.full_len = zero_bias, full_len
 
         def run_chain(b0, b1, stream):
             nb = b1 - b0
@@ -407,8 +413,15 @@ class SanaTransformer2DModelHIP(nn.Module):
                                     A.rstd1[rs])
                 wqkv, _ = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
                 lin(A.h1[rs], wqkv, out=A.qkv[rs])
-                ops.linear_attn_fwd(A.qkv[rs], nb, N, H1, D, 2 * D, A.attn[rs],
-                                    A.la_state[b0 * la_per_image:b1 * la_per_image])
+                if A.softmax1:
+                    # AttnProcessor2_0 on attn1: plain softmax attention over the N tokens, 70 heads x 32, no mask --
+                    # the cross-attention kernel with q, k, v = the three column blocks of the fused projection
+                    qkv_ = A.qkv[rs]
+                    ops.sdpa_fwd(qkv_[:, :D], qkv_[:, D:2 * D], qkv_[:, 2 * D:], nb, N, N, H1, D // H1, 1.0 / math.sqrt(D // H1),
+                                 zero_bias[bs], full_len[bs], A.attn[rs], A.lse1[bs])
+                else:
+                    ops.linear_attn_fwd(A.qkv[rs], nb, N, H1, D, 2 * D, A.attn[rs],
+                                        A.la_state[b0 * la_per_image:b1 * la_per_image])
                 lin(A.attn[rs], P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"], out=A.x1[rs],
                                aux_out=A.lin1[rs], gate=mod2d[:, 2 * D:3 * D], ld_gate=6 * D, residual=xin,
                                rows_per_batch=N)
@@ -664,7 +677,12 @@ class SanaTransformer2DModelHIP(nn.Module):
                 off_chain(small_grads)
             dattn = dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf(f"dqkv.{par}", (M, 3 * D))
-            ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
+            if A.softmax1:
+                ops.sdpa_bwd(A.qkv[:, :D], A.qkv[:, D:2 * D], A.qkv[:, 2 * D:], B, N, N, H1, D // H1, 1.0 / math.sqrt(D // H1),
+                             S.zero_bias, S.full_len, A.attn, dattn, A.lse1, buf("delta1", (B, H1, N), f32), dqkv[:, :D],
+                             dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+            else:
+                ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
             emit(dqkv, A.h1, gqkv)
             dh1 = dgrad(dqkv, wqkv, out=buf(f"dh1.{par}", (M, D)))
