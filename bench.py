@@ -297,6 +297,7 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",
                        "num_layers": cfg.num_layers, "params": model.numel_flat},
             "loss": loss_val,
+            "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),
             "algorithmic_tflop_per_step": flops / args.steps / 1e12,
         }
