@@ -519,35 +519,22 @@ class SanaTransformer2DModelHIP(nn.Module):
 
         # Weight/bias gradients are off the critical path (nothing in backward reads them): they go to a second
         # stream so their blocks fill the CUs the single-round dgrad launches leave idle, and their prologue/epilogue
-        # phases overlap the other stream's MFMA phases.  ``pending`` maps a dy buffer to the event after which the
-        # main stream may overwrite it.
+        # phases overlap the other stream's MFMA phases.  Buffers they read are either written once per backward (head,
+        # embedders) or alternate between two sets by block parity (transformer blocks, below).
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
-        pending = {}
-
-        def on_side(dy_base, fn):
-            if side is None:
-                fn()
-                return
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                fn()
-                ev = torch.cuda.Event()
-                ev.record(side)
-            pending[dy_base.data_ptr()] = ev
-
-        def writes(*ts):
-            for t in ts:
-                ev = pending.pop(t.data_ptr(), None)
-                if ev is not None:
-                    main.wait_event(ev)
 
         def wgrad(dy, x, key, shape2d, bias_key=None):
             def run():
                 ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
                 if bias_key is not None:
                     ops.colsum(dy, G[bias_key], ws_col, accumulate=acc)
-            on_side(dy, run)
+            if side is None:
+                run()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                run()
 
         # ---- output head
         d_out_tok = ops.transpose(dpred.to(BF16).contiguous().view(B, Cout, N), buf("d_out_tok", (B, N, Cout))).view(M, Cout)
