@@ -73,6 +73,13 @@ def test_trainer_runs_saves_and_reloads(tmp_path, monkeypatch):
     assert torch.isfinite(lat[0].float()).all()
     re = SanaTransformer2DModelHIP.from_pretrained(str(ck), device="cuda")
     assert re.flat_param.shape == trainer.model.flat_param.shape and torch.isfinite(re.flat_param.float()).all()
+    # the TensorBoard event file (runs/<date>_<host>/events.out.tfevents.*) holds every step's loss and the latent preview
+    from yat_amd.common.tb_writer import read_events
+    ev = read_events(trainer.logger.path)
+    logged = [(e["step"], e["value"]) for e in ev if e.get("tag") == "train/loss"]
+    assert [s for s, _ in logged] == list(range(6))
+    assert all(abs(v - l) <= 1e-6 * max(1.0, abs(l)) for (_, v), l in zip(logged, losses))
+    assert any(e.get("tag") == "validation_latents/0" and "image" in e for e in ev)
 
 
 def test_overfits_a_fixed_batch():

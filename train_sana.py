@@ -73,6 +73,11 @@ class SanaModel(Model):
                                       generator=gen, schedule=self.scheduler).cpu())
         os.makedirs(f"models/{self.global_step}", exist_ok=True)
         torch.save(out, f"models/{self.global_step}/validation_latents.pt")
+        if self.logger is not None:                # :157 logs the decoded image; without the VAE: a latent preview
+            for idx, lat in enumerate(out):
+                x = lat[0, :3].float()
+                x = (x - x.amin()) / (x.amax() - x.amin()).clamp_min(1e-6)
+                self.logger.add_image(f"validation_latents/{idx}", x, self.global_step)
         return out
 
     def optimize(self, ratio, latents, embeddings, repa_tokens, generator: torch.Generator = None):

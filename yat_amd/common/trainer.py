@@ -12,8 +12,8 @@ What is different (MI355X-first, documented in DESIGN.md):
   with xGMI P2P left ENABLED (the reference disables it, :27-28 -- right for its dual consumer GPUs, wrong here);
 * DDP is ``yat_amd.ddp.HipDDP`` (flat bucketed all-reduce overlapped with backward), clip+AdamW+EMA+zero_grad are
   one fused launch pair, so ``clip_grad_norm_`` is a no-op hook here;
-* logging keeps the loss on the device until it is actually written (no per-step ``.item()`` stall unless a logger
-  is attached).
+* logging (``tb_writer.SummaryWriter``, TensorBoard event files) keeps the loss on the device and writes the
+  scalars YAT_LOG_FLUSH steps at a time, so there is no per-step ``.item()`` stall (:364).
 PEFT adapters, dual-GPU mode, Dreambooth, REPA and DeepSpeed are out of scope.
 """
 from __future__ import annotations
@@ -124,7 +124,14 @@ class Model:
         else:
             self.shard_index_begin, self.shard_index_end = 0, (n or 0)
         self.global_step = 0
+        # :137-138 -- the main process owns a SummaryWriter (runs/<date>_<host>/events.out.tfevents.*); YAT_TENSORBOARD=0
+        # turns it off.  Scalars are queued on the device and written LOG_FLUSH steps at a time (no per-step .item()).
         self.logger = None
+        if self.accelerator.is_main_process and os.environ.get("YAT_TENSORBOARD", "1") != "0":
+            from .tb_writer import SummaryWriter
+            self.logger = SummaryWriter()
+        self.log_flush = int(os.environ.get("YAT_LOG_FLUSH", "20"))
+        self._log_queue = []
         self.sampler = None
         self.optimizer = None
         self.lr_scheduler = None
@@ -259,18 +266,33 @@ class Model:
                     avg_loss = torch.zeros((), device=dev)
                     self.loss_history.append(mean_loss)
                     if self.logger is not None and self.accelerator.is_main_process:
-                        try:
-                            self.logger.add_scalar("train/loss", mean_loss.item(), self.global_step)
-                            if self.lr_scheduler is not None:
-                                self.logger.add_scalar("train/lr", self.lr_scheduler.get_last_lr()[0], self.global_step)
-                        except Exception as e:  # :363-369
-                            print(f"[Warning] logging failed: {e}")
+                        lr = self.lr_scheduler.get_last_lr()[0] if self.lr_scheduler is not None else None
+                        self._log_queue.append((self.global_step, mean_loss, lr))
+                        if len(self._log_queue) >= self.log_flush:
+                            self.flush_log()
                     if self.global_step % p.num_steps_per_validation == 0:
+                        self.flush_log()
                         self._validate_and_save()
                     self.global_step += 1
                     if self.global_step >= steps:
                         break
+        self.flush_log()
         self.finalize()
+
+    def flush_log(self):
+        """:362-369 -- ``add_scalar('train/loss' | 'train/lr', v, step)``; one device->host copy for the whole queue."""
+        queue, self._log_queue = self._log_queue, []
+        if not queue or self.logger is None:
+            return
+        try:
+            losses = torch.stack([q[1].float() for q in queue]).tolist()
+            for (step, _, lr), v in zip(queue, losses):
+                self.logger.add_scalar("train/loss", v, step)
+                if lr is not None:
+                    self.logger.add_scalar("train/lr", lr, step)
+            self.logger.flush()
+        except Exception as e:  # :368-369
+            print(f"[Warning] logging failed: {e}")
 
     def _validate_and_save(self):
         """:371-401: EMA mean across ranks, then rank 0 swaps EMA weights in, validates, saves, swaps back."""
