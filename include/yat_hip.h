@@ -227,6 +227,26 @@ int yat_mse_fwd_bwd(int64_t n, const void* pred, const void* target, float gscal
                     float* workspace_256, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * PixArt-Sigma recipe and embedding glue (BASELINE config 3: train_pixart_sigma.py:151-185 over
+ * utils/patch_pixart_sigma_transformer.py:124-198).
+ * ------------------------------------------------------------------------------------------ */
+/* NCHW [B,C,H,W] <-> token rows [B*(H/p)*(W/p), C*p*p].  channel_major=1: column c*p*p+pi*p+pj (PatchEmbed's
+ * Conv2d(k=p,s=p) weight [D,C,p,p] flattened, patch_pixart_sigma_transformer.py:130); channel_major=0: column
+ * (pi*p+pj)*C+c (unpatchify "nhwpqc->nchpwq", :186-191).  to_tokens=1 gathers image->tokens, 0 scatters tokens->image. */
+int yat_patch_rearrange(int B, int C, int H, int W, int p, int channel_major, int to_tokens, const void* src, void* dst,
+                        yat_stream_t stream);
+/* out[r,:] = bf16(x[r,:] + pos[r % N,:]): PatchEmbed's "(latent + pos_embed).to(latent.dtype)" with the fp32 sin-cos table */
+int yat_add_pos_embed(int64_t rows, int N, int D, const void* x, const float* pos, void* out, yat_stream_t stream);
+/* DDPMScheduler.add_noise (train_pixart_sigma.py:176): noisy = bf16(bf16(a[b]*x) + bf16(c[b]*n)); a, c: bf16 [B] */
+int yat_ddpm_add_noise(int B, int64_t per_sample, const void* x, const void* noise, const void* sqrt_alpha_prod,
+                       const void* sqrt_one_minus_alpha_prod, void* noisy, yat_stream_t stream);
+/* MSELoss()(pred.chunk(2,1)[0].to(bf16), noise) in bf16 (train_pixart_sigma.py:180-184): pred [B, stride] of which the first
+ * `used` elements per sample are compared with target [B, used]; loss[0] (fp32 slot holding the bf16-rounded value);
+ * dpred [B, stride] = bf16(bf16(bf16(2/n)*bf16(p-t)) * bf16(gscale)), zero in the dropped half.  dpred may be NULL. */
+int yat_mse_bf16_chunk(int B, int64_t used, int64_t stride, const void* pred, const void* target, float gscale, float* loss,
+                       void* dpred, float* workspace_256, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * optimizer (common/trainer.py:246-248,347-348,356 = torch clip_grad_norm_ + torch.optim.AdamW on
  * bf16 params with bf16 states), over ONE flat parameter buffer.
  *   seg_start: int64 [nseg+1] element offsets of each parameter tensor (16-B aligned starts).

@@ -1,0 +1,134 @@
+"""Flat-buffer parameter plumbing shared by the transformer classes of the HIP path (yat_amd/sana.py, yat_amd/pixart.py).
+
+All parameters of a model live in ONE flat bf16 HBM buffer in forward-execution order, gradients in a second one (``p.grad``
+are views of it): gradient norm + AdamW are single launches over the buffer, data-parallel buckets are contiguous slices
+(``bucket_bounds``), and consecutive tensors (to_q | to_k | to_v) can be addressed as one fused matrix while the checkpoint
+still sees the diffusers keys.  Activations kept for the backward live in a persistent arena (``_buf``).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+BF16 = torch.bfloat16
+
+
+class _Node(nn.Module):
+    """Anonymous container so parameter names can carry the diffusers dotted paths."""
+
+
+class FlatParamModule(nn.Module):
+    def _alloc_flat(self, specs, device):
+        """``specs``: [(diffusers key, shape)] in forward-execution order."""
+        self.dev = torch.device(device)
+        offs, off = [], 0
+        for _, shape in specs:
+            offs.append(off)
+            off += (math.prod(shape) + 7) // 8 * 8            # 16-byte aligned segment starts
+        self.numel_flat = off
+        self.flat_param = torch.zeros(off, dtype=BF16, device=self.dev)
+        self.flat_grad = torch.zeros(off, dtype=BF16, device=self.dev)
+        self.seg_start = torch.tensor(offs + [off], dtype=torch.int64)     # host copy (true tensor extents)
+        self._seg_numel = [math.prod(s) for _, s in specs]
+        self.P, self.G = {}, {}
+        for (name, shape), o in zip(specs, offs):
+            n = math.prod(shape)
+            param = nn.Parameter(self.flat_param[o:o + n].view(shape))
+            param.grad = self.flat_grad[o:o + n].view(shape)
+            self._register(name, param)
+            self.P[name], self.G[name] = param.data, param.grad
+        self._offset = dict(zip([n for n, _ in specs], offs))
+        self.grad_ready = None            # callable(bucket_index) set by HipDDP
+        self.adapters = None              # yat_amd.lokr.LoKrAdapters when the config asks for PEFT adapters
+        self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
+        self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
+        self._arena, self._chains, self._side = {}, {}, None
+        self._saved = None
+        self._anchor = torch.zeros((), device=self.dev, requires_grad=True)
+        self.gradient_checkpointing = False
+        return offs, off
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            if not hasattr(mod, part):
+                mod.add_module(part, _Node())
+            mod = getattr(mod, part)
+        mod.register_parameter(parts[-1], param)
+
+    def _block_buckets(self, specs, offs, total, num_layers, first_key="scale_shift_table"):
+        """bucket 0 = embedders; bucket i+1 = block i (the last one also holds the output head)."""
+        names = [n for n, _ in specs]
+        starts = [0]
+        for i in range(num_layers):
+            starts.append(offs[names.index(f"transformer_blocks.{i}.{first_key}")])
+        return [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)] + [(starts[-1], total)]
+
+    @property
+    def dtype(self):
+        return BF16
+
+    @property
+    def device(self):
+        return self.dev
+
+    def enable_gradient_checkpointing(self):
+        """Accepted for drop-in compatibility (train_sana.py:63, train_pixart_sigma.py:34); all activations fit in 288 GB
+        HBM, so nothing is recomputed."""
+        self.gradient_checkpointing = True
+
+    def _apply(self, fn, *a, **k):
+        # parameters are views of flat device buffers; .to()/.cuda()/.bfloat16() must not re-materialise them
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        missing = [k for k in self.P if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self.P]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k in self.P:
+                    self.P[k].copy_(v.to(device=self.dev, dtype=BF16).view(self.P[k].shape))
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    # ------------------------------------------------------------------ arena
+    def _buf(self, name, shape, dtype=BF16):
+        n = math.prod(shape)
+        t = self._arena.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+            self._arena[name] = t
+        return t[:n].view(shape)
+
+    def _fused(self, first_key, rows_total, cols=None):
+        """Contiguous view spanning consecutive parameter tensors (e.g. to_q|to_k|to_v -> [3D, D])."""
+        o = self._offset[first_key]
+        if cols is None:
+            return self.flat_param[o:o + rows_total], self.flat_grad[o:o + rows_total]
+        n = rows_total * cols
+        return self.flat_param[o:o + n].view(rows_total, cols), self.flat_grad[o:o + n].view(rows_total, cols)
+
+    # ------------------------------------------------------------------ streams
+    def join_pending_update(self):
+        """Make the current stream wait for an optimizer update still running on the optimizer's stream."""
+        pev, self.param_events = self.param_events, None
+        if pev is not None:
+            cur = torch.cuda.current_stream()
+            for ev in pev:
+                cur.wait_event(ev)
+
+    def _chain_stream(self, c):
+        if c not in self._chains:
+            self._chains[c] = torch.cuda.Stream(device=self.flat_param.device)
+        return self._chains[c]
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat_param.device)
+        return self._side

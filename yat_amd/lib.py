@@ -64,6 +64,10 @@ SIGNATURES = {
     "yat_pad_mask": (I, [I, I, I, P, P, P, P, P, P, P]),
     "yat_flow_mix": (I, [I, I64, P, P, P, P, P, P]),
     "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
+    "yat_patch_rearrange": (I, [I, I, I, I, I, I, I, P, P, P]),
+    "yat_add_pos_embed": (I, [I64, I, I, P, P, P, P]),
+    "yat_ddpm_add_noise": (I, [I, I64, P, P, P, P, P, P]),
+    "yat_mse_bf16_chunk": (I, [I, I64, I64, P, P, F, P, P, P, P]),
     "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
     "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
     "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),

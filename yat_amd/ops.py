@@ -373,6 +373,51 @@ def mse_fwd_bwd(pred, target, loss_f32, dpred, workspace_f32, gscale=1.0):
     return loss_f32
 
 
+def patch_rearrange(src, dst, B, C, H, W, p, channel_major, to_tokens):
+    """NCHW <-> rows of p x p patches (include/yat_hip.h: yat_patch_rearrange)."""
+    _chk_bf16(src, dst)
+    if src.numel() != B * C * H * W or dst.numel() != src.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("patch_rearrange: shape mismatch")
+    _l.check(_lib().yat_patch_rearrange(B, C, H, W, p, int(channel_major), int(to_tokens), _p(src), _p(dst), _stream()),
+           "patch_rearrange")
+    return dst
+
+
+def add_pos_embed(x2d, pos_f32, out=None):
+    _chk_bf16(x2d)
+    out = x2d if out is None else out
+    N, D = pos_f32.shape
+    if pos_f32.dtype != torch.float32 or x2d.shape[1] != D or x2d.shape[0] % N or not pos_f32.is_contiguous() \
+            or not x2d.is_contiguous() or not out.is_contiguous():
+        raise ValueError("add_pos_embed: shape mismatch")
+    _l.check(_lib().yat_add_pos_embed(x2d.shape[0], N, D, _p(x2d), _p(pos_f32), _p(out), _stream()), "add_pos_embed")
+    return out
+
+
+def ddpm_add_noise(x, noise, sqrt_alpha_prod_bf16, sqrt_one_minus_bf16, noisy=None):
+    _chk_bf16(x, noise, sqrt_alpha_prod_bf16, sqrt_one_minus_bf16)
+    B = x.shape[0]
+    if noise.shape != x.shape or sqrt_alpha_prod_bf16.numel() != B or sqrt_one_minus_bf16.numel() != B:
+        raise ValueError("ddpm_add_noise: shape mismatch")
+    noisy = torch.empty_like(x) if noisy is None else noisy
+    _l.check(_lib().yat_ddpm_add_noise(B, x.numel() // B, _p(x), _p(noise), _p(sqrt_alpha_prod_bf16), _p(sqrt_one_minus_bf16),
+                                     _p(noisy), _stream()), "ddpm_add_noise")
+    return noisy
+
+
+def mse_bf16_chunk(pred, target, loss_f32, dpred, workspace_f32, gscale=1.0):
+    """pred [B, C2, H, W] of which channels [: target.shape[1]] are compared with target [B, C, H, W] (bf16 MSELoss)."""
+    _chk_bf16(pred, target)
+    B = pred.shape[0]
+    stride, used = pred.numel() // B, target.numel() // B
+    if target.shape[0] != B or used > stride or pred.shape[2:] != target.shape[2:] or workspace_f32.numel() < 256 \
+            or not (pred.is_contiguous() and target.is_contiguous()) or (dpred is not None and dpred.shape != pred.shape):
+        raise ValueError("mse_bf16_chunk: shape mismatch")
+    _l.check(_lib().yat_mse_bf16_chunk(B, used, stride, _p(pred), _p(target), float(gscale), _p(loss_f32),
+                                     _p(dpred) if dpred is not None else None, _p(workspace_f32), _stream()), "mse_bf16_chunk")
+    return loss_f32
+
+
 # ----------------------------------------------------------------------------------------------- optimizer
 def gradnorm_workspace_bytes(n, nseg):
     return int(_lib().yat_gradnorm_workspace_bytes(n, nseg))

@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .scheduler import FlowMatchSchedule
+from .scheduler import DDPMSchedule, FlowMatchSchedule
 
 BF16 = torch.bfloat16
 
@@ -124,3 +124,64 @@ class SanaRecipe:
 
     def _dpred(self, like):
         return self._scratch("_dpred_buf", like)
+
+
+class PixArtRecipe(SanaRecipe):
+    """``PixartSigmaTrainer.optimize`` (train_pixart_sigma.py:151-185) on the HIP path: pad the T5 embeddings to 300 rows +
+    mask (:158-168) -> noise in bf16 (:170) -> logit-normal index -> ``scheduler.timesteps[index]`` (:172-174) ->
+    ``add_noise`` (:176) -> model (:178-182) -> ``.chunk(2, 1)[0]`` against the noise, MSE evaluated in bf16 (:183-184).
+    The pad / mask staging is SanaRecipe's; mix and loss(+dL/dpred) are one launch each."""
+
+    def __init__(self, model, scheduler: DDPMSchedule | None = None, pad_to: int = 300, device="cuda"):
+        super().__init__(model, scheduler or DDPMSchedule(), pad_to=pad_to, device=device)
+
+    def draw(self, shape, generator=None, noise=None):
+        """The reference draws the noise on the device from the global RNG (randn_tensor without a generator, :170) and the
+        timestep indices on the host from the global CPU RNG (:172); a generator, when given, replaces the global streams
+        (device generator -> noise, CPU generator -> both)."""
+        if noise is None:
+            if generator is not None and generator.device.type != "cuda":
+                noise = torch.randn(shape, generator=generator, device="cpu", dtype=BF16).to(self.dev, non_blocking=True)
+            else:
+                noise = torch.randn(shape, generator=generator, device=self.dev, dtype=BF16)
+        cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
+        t, a, c = self.scheduler.sample(shape[0], cpu_gen)
+        return noise.to(self.dev), t.to(self.dev, non_blocking=True), a.to(self.dev, non_blocking=True), \
+            c.to(self.dev, non_blocking=True)
+
+    def optimize(self, latents, embeddings, generator=None, return_pred=False, noise=None):
+        enc, mask, bias, kvl = self.pad_embeddings(embeddings)
+        latents = latents.to(device=self.dev, dtype=BF16).contiguous()
+        noise, timesteps, a, c = self.draw(latents.shape, generator, noise)
+        noisy = ops.ddpm_add_noise(latents, noise, a, c)
+        self.model.next_kv_work = self.kv_work
+        out = self.model(noisy, encoder_hidden_states=enc, timestep=timesteps, encoder_attention_mask=mask).sample
+        loss = _MseBf16Chunk.apply(out, noise, self._mse_ws)
+        return (loss, out, noise) if return_pred else loss
+
+    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, coef_a, coef_c, loss_out, kv_work=None):
+        """Straight-line step on device-resident inputs (bench.py): mix, forward, loss + dL/dpred, backward."""
+        bias, kvl = mask_bias_kvl
+        noisy = ops.ddpm_add_noise(latents, noise, coef_a, coef_c, self._noisy(latents))
+        out = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
+        dpred = self._dpred(out)
+        ops.mse_bf16_chunk(out, noise, loss_out, dpred, self._mse_ws)
+        self.model.backward_impl(dpred)
+        return loss_out
+
+
+class _MseBf16Chunk(torch.autograd.Function):
+    """MSELoss()(out.chunk(2, 1)[0], noise) in bf16, with the gradient (zero on the dropped half) from the same launch."""
+
+    @staticmethod
+    def forward(ctx, out, target, ws):
+        loss = torch.zeros(1, dtype=torch.float32, device=out.device)
+        dpred = torch.empty_like(out)
+        ops.mse_bf16_chunk(out.contiguous(), target, loss, dpred, ws)
+        ctx.save_for_backward(dpred)
+        return loss[0].to(BF16)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g.to(dpred.dtype), None, None

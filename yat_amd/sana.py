@@ -36,6 +36,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .flat import FlatParamModule
 
 BF16 = torch.bfloat16
 
@@ -116,10 +117,6 @@ def _param_specs(cfg: SanaConfig):
     return specs
 
 
-class _Node(nn.Module):
-    """Anonymous container so parameter names can carry the diffusers dotted paths."""
-
-
 class _WholeModel(torch.autograd.Function):
     """One autograd node for the whole transformer: backward = the hand-scheduled HIP backward."""
 
@@ -135,97 +132,24 @@ class _WholeModel(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
-class SanaTransformer2DModelHIP(nn.Module):
+class SanaTransformer2DModelHIP(FlatParamModule):
     def __init__(self, cfg: SanaConfig | None = None, device="cuda", **cfg_kw):
         super().__init__()
         cfg = cfg or SanaConfig(**cfg_kw)
         cfg.validate()
         self.cfg = cfg
         self.config = SimpleNamespace(**asdict(cfg))          # diffusers-style `.config.sample_size`
-        self.dev = torch.device(device)
         specs = _param_specs(cfg)
-        offs, off = [], 0
-        for _, shape in specs:
-            offs.append(off)
-            off += (math.prod(shape) + 7) // 8 * 8            # 16-byte aligned segment starts
-        self.numel_flat = off
-        self.flat_param = torch.zeros(off, dtype=BF16, device=self.dev)
-        self.flat_grad = torch.zeros(off, dtype=BF16, device=self.dev)
-        self.seg_start = torch.tensor(offs + [off], dtype=torch.int64)     # host copy (true tensor extents)
-        self._seg_numel = [math.prod(s) for _, s in specs]
-        self.P, self.G = {}, {}
-        for (name, shape), o in zip(specs, offs):
-            n = math.prod(shape)
-            param = nn.Parameter(self.flat_param[o:o + n].view(shape))
-            param.grad = self.flat_grad[o:o + n].view(shape)
-            self._register(name, param)
-            self.P[name], self.G[name] = param.data, param.grad
-        self._offset = dict(zip([n for n, _ in specs], offs))
+        offs, total = self._alloc_flat(specs, device)
         # bucket boundaries for data parallel reduction: head | one per block (+tail on the last)
-        self.bucket_bounds = self._make_buckets(specs, offs, off)
-        self.grad_ready = None            # callable(bucket_index) set by HipDDP
+        self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers)
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"   # weight gradients on a second stream
         self.keep_glu_u = os.environ.get("YAT_KEEP_GLU_U", "1") != "0"         # keep the depthwise-conv output (183 MB/block)
         self.fwd_chains = int(os.environ.get("YAT_FWD_CHAINS", "2"))           # independent forward chains (image ranges)
-        self._chains = {}
         self.group_big_wgrad = os.environ.get("YAT_GROUP_BIG_WGRAD", "0") != "0"
         self.group_small_wgrad = os.environ.get("YAT_GROUP_SMALL_WGRAD", "1") != "0"   # D x D weight gradients grouped
         self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
         self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
-        self._side = None
-        self.adapters = None              # yat_amd.lokr.LoKrAdapters when the config asks for PEFT adapters
-        self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
-        self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
-        self._arena = {}
-        self._saved = None
-        self._anchor = torch.zeros((), device=self.dev, requires_grad=True)
-        self.gradient_checkpointing = False
-
-    # ------------------------------------------------------------------ nn.Module plumbing
-    def _register(self, dotted, param):
-        mod = self
-        parts = dotted.split(".")
-        for part in parts[:-1]:
-            if not hasattr(mod, part):
-                mod.add_module(part, _Node())
-            mod = getattr(mod, part)
-        mod.register_parameter(parts[-1], param)
-
-    def _make_buckets(self, specs, offs, total):
-        names = [n for n, _ in specs]
-        starts = [0]
-        for i in range(self.cfg.num_layers):
-            starts.append(offs[names.index(f"transformer_blocks.{i}.scale_shift_table")])
-        bounds = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)] + [(starts[-1], total)]
-        return bounds        # bucket 0 = embedders; bucket i+1 = block i (last one also holds the output head)
-
-    @property
-    def dtype(self):
-        return BF16
-
-    @property
-    def device(self):
-        return self.dev
-
-    def enable_gradient_checkpointing(self):
-        """Accepted for drop-in compatibility (train_sana.py:63); all activations fit in 288 GB HBM,
-        so nothing is recomputed."""
-        self.gradient_checkpointing = True
-
-    def _apply(self, fn, *a, **k):
-        # parameters are views of flat device buffers; .to()/.cuda()/.bfloat16() must not re-materialise them
-        return self
-
-    def load_state_dict(self, state_dict, strict=True, assign=False):
-        missing = [k for k in self.P if k not in state_dict]
-        unexpected = [k for k in state_dict if k not in self.P]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f"load_state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
-        with torch.no_grad():
-            for k, v in state_dict.items():
-                if k in self.P:
-                    self.P[k].copy_(v.to(device=self.dev, dtype=BF16).view(self.P[k].shape))
-        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
     def init_synthetic(self, seed: int = 0):
         """Deterministic random weights of the right scale (no checkpoints offline): weights ~ N(0, 1/fan_in),
@@ -242,23 +166,6 @@ class SanaTransformer2DModelHIP(nn.Module):
                 else:
                     p.copy_(torch.randn(p.shape, generator=g, device=self.dev) / math.sqrt(p[0].numel()))
         return self
-
-    # ------------------------------------------------------------------ arena
-    def _buf(self, name, shape, dtype=BF16):
-        n = math.prod(shape)
-        t = self._arena.get(name)
-        if t is None or t.numel() < n or t.dtype != dtype:
-            t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
-            self._arena[name] = t
-        return t[:n].view(shape)
-
-    def _fused(self, first_key, rows_total, cols=None):
-        """Contiguous view spanning consecutive parameter tensors (e.g. to_q|to_k|to_v -> [3D, D])."""
-        o = self._offset[first_key]
-        if cols is None:
-            return self.flat_param[o:o + rows_total], self.flat_grad[o:o + rows_total]
-        n = rows_total * cols
-        return self.flat_param[o:o + n].view(rows_total, cols), self.flat_grad[o:o + n].view(rows_total, cols)
 
     # ------------------------------------------------------------------ public forward (reference call contract)
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, encoder_attention_mask=None,
@@ -470,24 +377,6 @@ class SanaTransformer2DModelHIP(nn.Module):
                 main.wait_event(ev)
         self._saved = S
         return pred.view(B, Cout, h, w)
-
-    def join_pending_update(self):
-        """Make the current stream wait for an optimizer update still running on the optimizer's stream."""
-        pev, self.param_events = self.param_events, None
-        if pev is not None:
-            cur = torch.cuda.current_stream()
-            for ev in pev:
-                cur.wait_event(ev)
-
-    def _chain_stream(self, c):
-        if c not in self._chains:
-            self._chains[c] = torch.cuda.Stream(device=self.flat_param.device)
-        return self._chains[c]
-
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat_param.device)
-        return self._side
 
     # ------------------------------------------------------------------ backward
     def backward_impl(self, dpred):
