@@ -146,3 +146,52 @@ def test_trainer_lokr_config(tmp_path, monkeypatch):
     assert "base_model.model.transformer_blocks.1.attn2.to_out.0.lokr_w1" in sd
     assert "base_model.model.patch_embed.proj.lokr_w2_a" in sd and len(sd) == 3 * len(trainer.adapters.entries)
     assert any(v.abs().max() > 0 for k, v in sd.items() if k.endswith("lokr_w1")), "w1 never left its zero init"
+
+
+def test_pixart_trainer_runs_and_saves(tmp_path, monkeypatch):
+    """BASELINE config 3 through the same trainer loop: `train_pixart_sigma.py` entry class on a tiny PixArt-Sigma
+    configuration (cached latents at VAE compression 8, DDPM epsilon-prediction recipe, bf16 loss), checkpoint in the
+    diffusers layout, reload."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from train_pixart_sigma import PixartSigmaTrainer
+    from yat_amd.common.training_parameters_reader import TrainingParameters
+    from yat_amd.common.shards import write_shard
+    from yat_amd.common.aspect_ratios import ASPECT_RATIO_1024_BIN
+    from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
+    cfg = PixArtConfig(num_layers=2, num_attention_heads=2, attention_head_dim=24, cross_attention_dim=48,
+                       caption_channels=64, sample_size=128)
+    g = torch.Generator().manual_seed(0)
+    paths = []
+    for s in range(2):
+        samples = []
+        for i in range(16):
+            r = ["1.0", "0.5", "2.0"][(i + s) % 3]
+            H, W = ASPECT_RATIO_1024_BIN[r]
+            L = int(torch.randint(3, 40, (1,), generator=g))
+            samples.append(dict(__key__=f"{s:03d}{i:05d}", ratio=r,          # 1024 px bucket / 32: small latents, same ratios
+                                latent=(torch.randn(4, int(H) // 32, int(W) // 32, generator=g) * 0.5).to(BF),
+                                emb=torch.randn(L, cfg.caption_channels, generator=g).to(BF)))
+        p = str(tmp_path / f"shard-{s:06d}.tar")
+        write_shard(p, samples)
+        paths.append(p)
+    yaml_path = tmp_path / "config.yaml"
+    yaml_path.write_text("\n".join([
+        "urls:", "  - unused", "local_shard_paths:", *[f"  - {p}" for p in paths], "num_shards: 2", "dataset_seed: 7",
+        "batch_size: 4", "learning_rate: 1e-3", "steps: 5", "num_steps_per_validation: 4", "validation_prompts:", "  - x",
+        "bfloat16: true", "gradient_accumulation_steps: 1", "warmup_steps: 2", "weight_decay: 0.0", "aspect_ratio: 1024",
+        "train_unconditional_prob: 0.0", ""]))
+    monkeypatch.chdir(tmp_path)
+    params = TrainingParameters()
+    params.read_yaml(str(yaml_path))
+    trainer = PixartSigmaTrainer(params, config=cfg)
+    before = trainer.model.flat_param.clone()
+    trainer.run()
+    torch.cuda.synchronize()
+    losses = [float(l) for l in trainer.loss_history]
+    assert len(losses) == 5 and all(l == l and l < 1e3 for l in losses), losses
+    assert not torch.equal(before, trainer.model.flat_param)
+    saved = sorted(os.listdir(tmp_path / "models"), key=int)
+    ck = tmp_path / "models" / saved[-1]
+    assert json.loads((ck / "config.json").read_text())["_class_name"] == "PixArtTransformer2DModel"
+    re = PixArtTransformer2DModelHIP.from_pretrained(str(ck), device="cuda")
+    assert re.flat_param.shape == trainer.model.flat_param.shape and torch.isfinite(re.flat_param.float()).all()
