@@ -23,6 +23,10 @@ LIB = os.path.join(HERE, "libyat_hip.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "rowops.hip", "elementwise.hip", "optim.hip", "linear_attn.hip", "sdpa.hip", "dwconv_glu.hip", "lokr.hip", "pixart_ops.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value"]
+# Per-source additions.  sdpa.hip: keep the MFMA accumulators in ordinary VGPRs -- the softmax reads every score and rescales
+# every output accumulator between MFMAs, and with the default AGPR form that was ~150 v_accvgpr_read/write moves per key tile
+# per wave (more VALU cycles than the softmax itself); gfx950's MFMA takes VGPR operands directly.
+EXTRA_FLAGS = {"sdpa.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -41,6 +45,7 @@ def _digest() -> str:
             with open(path, "rb") as f:
                 h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -60,7 +65,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # -Rpass-analysis=kernel-resource-usage: per-kernel VGPRs / spills / scratch as compiler remarks (free), kept in
         # build/resources.json.  A kernel that silently starts using scratch (an innocent-looking epilogue branch did that
         # to every 256x320 GEMM once: +11 ms per step) fails the build instead of the benchmark.
-        cmd = [hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c",
+               os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -16,6 +16,7 @@
 //   forward : workgroup = 64 queries (4 waves x 16), loop over 64-key tiles, online softmax.
 //   backward: dq kernel (same decomposition, recomputes P, also emits delta = rowsum(dO*O));
 //             dkv kernel (workgroup = 64 keys, loops over 64-query tiles); no atomics.
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/yat_hip.h"
 
@@ -27,12 +28,12 @@ constexpr int DKV_STAGE = 2 * TILE + 512;   // one query-tile stage of the dK/dV
 enum { IMG_ROW = 0, IMG_TR = 1 };
 
 // stage a [64 rows][128 cols] bf16 tile (rows past row_limit / cols past dh read as zero)
-template <int IMG>
+template <int IMG, int NW = 4>
 __device__ __forceinline__ void stage64x128(__amdgpu_buffer_rsrc_t rsrc, char* lds, int64_t row0, int64_t row_limit,
                                             int ld, int col0, int dh, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int piece = j * 4 + wave;
+    for (int j = 0; j < 16 / NW; ++j) {
+        const int piece = j * NW + wave;
         const int r = piece * 4 + (lane >> 4);
         const int slot = lane & 15;
         const int chunk = IMG == IMG_ROW ? (slot ^ (r & 15)) : (slot ^ ((r & 7) << 1));
@@ -89,6 +90,18 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+constexpr float LOG2E = 1.4426950408889634f;
+// exp(x - m) as one FMA + v_exp_f32: exp2(x * log2e - m * log2e); `nm2` = -m * log2e is per row
+__device__ __forceinline__ float exp_sub(float x, float nm2) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, LOG2E, nm2)); }
+// keys past T in the last key tile: their scores must vanish from the softmax.  The DMA range check zero-fills their
+// bias slot; one wave rewrites those slots to -1e30 (finite: exp2 of it is 0) so the per-score loop needs no bounds test.
+__device__ __forceinline__ void mask_tail_bias(char* bias_slot, int k0, int T, int wave, int lane) {
+    if (k0 + 64 > T) {                           // uniform
+        if (wave == 0 && k0 + lane >= T) reinterpret_cast<float*>(bias_slot)[lane] = -1e30f;
+        __syncthreads();
+    }
+}
+
 struct SdpaP {
     int N, T, H, dh; float scale;
     const bf16_t* q; int ldq; const bf16_t* k; const bf16_t* v; int ldkv;
@@ -107,12 +120,16 @@ struct SdpaP {
 // 4-byte LDS-DMA -- an ordinary global load inside the loop would drain the DMAs with its vmcnt(0)) is in flight while
 // tile t is consumed, one barrier per tile.  With ~3 live key tiles per image the loop is latency, not MFMA, bound.
 constexpr int FWD_STAGE = 2 * TILE + 256;
+template <int KS, int DT, int QS>
 __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
+    // QS = 16-query sub-tiles per wave: the workgroup covers 64*QS queries.  With QS = 2 every K / V fragment read from LDS
+    // feeds two MFMAs and the per-tile costs (9 LDS-DMA issues per wave, the barrier) are shared by twice the work -- the
+    // long-sequence variant (self-attention over thousands of keys); QS = 1 keeps more workgroups for short key loops.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
@@ -130,15 +147,22 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     };
     stage(0, smem);
 
-    bf16x8 qf[4];
+    bf16x8 qf[QS][KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = frag_global(p.q, (int64_t)b * p.N + q0 + li, (int64_t)b * p.N + p.N, p.ldq, col0, p.dh, ks, lane);
+    for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[qs][ks] = frag_global(p.q, (int64_t)b * p.N + q0 + qs * 16 + li, (int64_t)b * p.N + p.N, p.ldq, col0, p.dh, ks, lane);
 
-    f32x4 o[8];
+    f32x4 o[QS][DT];
+    float m[QS], l[QS];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -1e30f, l = 0.f;
+    for (int qs = 0; qs < QS; ++qs) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[qs] = -1e30f;
+        l[qs] = 0.f;
+    }
 
     int it = 0;
     for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
@@ -146,63 +170,84 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // tile `it` landed for every wave; stage (it+1)&1 is free
         if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * FWD_STAGE);
+        mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
         const char* Ks = cur;
         const char* Vs = cur + TILE;
         const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
 
-        f32x4 s[4];
+        f32x4 s[QS][4];
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj) {
-            s[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[nj] = mfma16(frag_row(Ks, nj * 16, ks, lane), qf[ks], s[nj]);
-        }
-        float mx = -1e30f;
+            for (int qs = 0; qs < QS; ++qs) s[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfrag = frag_row(Ks, nj * 16, ks, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + nj * 16 + 4 * g + r;
-                float v = key < p.T ? s[nj][r] * p.scale + bv[r] : -1e30f;
-                s[nj][r] = v;
-                mx = fmaxf(mx, v);
+                for (int qs = 0; qs < QS; ++qs) s[qs][nj] = mfma16(kfrag, qf[qs][ks], s[qs][nj]);
             }
         }
-        mx = group_max(mx);
-        const float mn = fmaxf(m, mx);
-        const float alpha = __expf(m - mn);
-        float rs = 0.f;
+        bf16x8 pf0[QS], pf1[QS];
+        float alpha[QS];
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj)
+        for (int qs = 0; qs < QS; ++qs) {
+            float mx = -1e30f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[nj][r] - mn);
-                s[nj][r] = e;
-                rs += e;
+            for (int nj = 0; nj < 4; ++nj) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = __builtin_fmaf(s[qs][nj][r], p.scale, bv[r]);
+                    s[qs][nj][r] = v;
+                    mx = fmaxf(mx, v);
+                }
             }
-        rs = group_sum(rs);
-        l = l * alpha + rs;
-        m = mn;
-        const bf16x8 pf0 = acc_to_frag(s[0], s[1]), pf1 = acc_to_frag(s[2], s[3]);
+            mx = group_max(mx);
+            const float mn = fmaxf(m[qs], mx);
+            const float nm2 = -mn * LOG2E;
+            alpha[qs] = exp_sub(m[qs], nm2);
+            float rs = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
+            for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-            o[dt] = mfma16(frag_tr_acc(Vs, 0, dt * 16, lane), pf0, o[dt]);
-            o[dt] = mfma16(frag_tr_acc(Vs, 32, dt * 16, lane), pf1, o[dt]);
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp_sub(s[qs][nj][r], nm2);
+                    s[qs][nj][r] = e;
+                    rs += e;
+                }
+            rs = group_sum(rs);
+            l[qs] = l[qs] * alpha[qs] + rs;
+            m[qs] = mn;
+            pf0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
+            pf1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 v0 = frag_tr_acc(Vs, 0, dt * 16, lane), v1 = frag_tr_acc(Vs, 32, dt * 16, lane);
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qs][dt][r] *= alpha[qs];
+                o[qs][dt] = mfma16(v0, pf0[qs], o[qs][dt]);
+                o[qs][dt] = mfma16(v1, pf1[qs], o[qs][dt]);
+            }
         }
     }
-    const int qi = q0 + li;
-    if (qi < p.N) {
-        const float inv = 1.0f / l;
-        bf16_t* op = p.out + ((int64_t)b * p.N + qi) * p.ldo + col0;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            const int d = dt * 16 + 4 * g;
-            if (d < p.dh) *reinterpret_cast<u32x2*>(op + d) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    for (int qs = 0; qs < QS; ++qs) {
+        const int qi = q0 + qs * 16 + li;
+        if (qi < p.N) {
+            const float inv = 1.0f / l[qs];
+            bf16_t* op = p.out + ((int64_t)b * p.N + qi) * p.ldo + col0;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + 4 * g;
+                if (d < p.dh)
+                    *reinterpret_cast<u32x2*>(op + d) =
+                        pack4(o[qs][dt][0] * inv, o[qs][dt][1] * inv, o[qs][dt][2] * inv, o[qs][dt][3] * inv);
+            }
+            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m[qs] + __logf(l[qs]);
         }
-        if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m + __logf(l);
     }
 }
 
@@ -210,19 +255,19 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
 // Stage = K (TR-swizzled image: read row-wise for S = Q K^T and transposed for dQ = dS K), V (ROW image), key bias.
 // Two stages, one barrier per key tile, as in the forward.
 constexpr int DQ_STAGE = 2 * TILE + 256;
+template <int KS, int DT, int QS>
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);       // QS 16-query sub-tiles per wave, as in the forward
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
-    const int64_t qrow = (int64_t)b * p.N + q0 + li, qlim = (int64_t)b * p.N + p.N;
-    const int qi = q0 + li;
+    const int64_t qlim = (int64_t)b * p.N + p.N;
 
     auto stage = [&](int k0, char* base) {
         const int64_t r0 = (int64_t)b * p.T + k0, rl = (int64_t)b * p.T + p.T;
@@ -236,23 +281,28 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     };
     stage(0, smem);
 
-    bf16x8 qf[4], dof[4];
-    float dl = 0.f;
+    bf16x8 qf[QS][KS], dof[QS][KS];
+    float dl[QS], nlse2[QS];                     // nlse2 = -lse * log2e (queries past N: -1e30 -> P = 0)
+    f32x4 acc[QS][DT];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = frag_global(p.q, qrow, qlim, p.ldq, col0, p.dh, ks, lane);
-        dof[ks] = frag_global(p.dout, qrow, qlim, p.lddo, col0, p.dh, ks, lane);
-        const bf16x8 of = frag_global(p.out, qrow, qlim, p.ldo, col0, p.dh, ks, lane);
+    for (int qs = 0; qs < QS; ++qs) {
+        const int qi = q0 + qs * 16 + li;
+        const int64_t qrow = (int64_t)b * p.N + qi;
+        float d_ = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[e];
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qs][ks] = frag_global(p.q, qrow, qlim, p.ldq, col0, p.dh, ks, lane);
+            dof[qs][ks] = frag_global(p.dout, qrow, qlim, p.lddo, col0, p.dh, ks, lane);
+            const bf16x8 of = frag_global(p.out, qrow, qlim, p.ldo, col0, p.dh, ks, lane);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d_ += (float)dof[qs][ks][e] * (float)of[e];
+        }
+        dl[qs] = group_sum(d_);
+        nlse2[qs] = qi < p.N ? -p.lse[((int64_t)b * p.H + h) * p.N + qi] * LOG2E : -1e30f;
+        if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = dl[qs];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    dl = group_sum(dl);
-    const float lse = qi < p.N ? p.lse[((int64_t)b * p.H + h) * p.N + qi] : 1e30f;
-    if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = dl;
-
-    f32x4 acc[8];
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int it = 0;
     for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
@@ -260,56 +310,80 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * DQ_STAGE);
+        mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
         const char* Kt = cur;
         const char* Vs = cur + TILE;
         const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
 
-        f32x4 s[4], dp[4];
+        f32x4 s[QS][4], dp[QS][4];
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj) {
-            s[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s[nj] = mfma16(frag_row_tr(Kt, nj * 16, ks, lane), qf[ks], s[nj]);
-                dp[nj] = mfma16(frag_row(Vs, nj * 16, ks, lane), dof[ks], dp[nj]);
+            for (int qs = 0; qs < QS; ++qs) {
+                s[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfr = frag_row_tr(Kt, nj * 16, ks, lane), vfr = frag_row(Vs, nj * 16, ks, lane);
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs) {
+                    s[qs][nj] = mfma16(kfr, qf[qs][ks], s[qs][nj]);
+                    dp[qs][nj] = mfma16(vfr, dof[qs][ks], dp[qs][nj]);
+                }
             }
         }
+        bf16x8 f0[QS], f1[QS];
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
+        for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + nj * 16 + 4 * g + r;
-                float pr = 0.f;
-                if (key < p.T) pr = __expf(s[nj][r] * p.scale + bv[r] - lse);
-                s[nj][r] = pr * (dp[nj][r] - dl);   // dS (w.r.t. the scaled logits)
+            for (int nj = 0; nj < 4; ++nj) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = exp_sub(__builtin_fmaf(s[qs][nj][r], p.scale, bv[r]), nlse2[qs]);
+                    s[qs][nj][r] = pr * (dp[qs][nj][r] - dl[qs]);   // dS (w.r.t. the scaled logits)
+                }
             }
+            f0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
+            f1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
         }
-        const bf16x8 f0 = acc_to_frag(s[0], s[1]), f1 = acc_to_frag(s[2], s[3]);
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            acc[dt] = mfma16(frag_tr_acc(Kt, 0, dt * 16, lane), f0, acc[dt]);
-            acc[dt] = mfma16(frag_tr_acc(Kt, 32, dt * 16, lane), f1, acc[dt]);
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 k0f = frag_tr_acc(Kt, 0, dt * 16, lane), k1f = frag_tr_acc(Kt, 32, dt * 16, lane);
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) {
+                acc[qs][dt] = mfma16(k0f, f0[qs], acc[qs][dt]);
+                acc[qs][dt] = mfma16(k1f, f1[qs], acc[qs][dt]);
+            }
         }
     }
-    if (qi < p.N) {
-        bf16_t* dp_ = p.dq + ((int64_t)b * p.N + qi) * p.lddq + col0;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            const int d = dt * 16 + 4 * g;
-            if (d < p.dh)
-                *reinterpret_cast<u32x2*>(dp_ + d) =
-                    pack4(acc[dt][0] * p.scale, acc[dt][1] * p.scale, acc[dt][2] * p.scale, acc[dt][3] * p.scale);
+    for (int qs = 0; qs < QS; ++qs) {
+        const int qi = q0 + qs * 16 + li;
+        if (qi < p.N) {
+            bf16_t* dp_ = p.dq + ((int64_t)b * p.N + qi) * p.lddq + col0;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + 4 * g;
+                if (d < p.dh)
+                    *reinterpret_cast<u32x2*>(dp_ + d) = pack4(acc[qs][dt][0] * p.scale, acc[qs][dt][1] * p.scale,
+                                                               acc[qs][dt][2] * p.scale, acc[qs][dt][3] * p.scale);
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
+template <int KS, int DT, int KB, int NW>
+__global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // stage layout: Q | dO (TR-swizzled images, read row-wise for S / dP and transposed for dK / dV) | lse[64] | delta[64]
     // (staging a ROW and a TR image of each, as before, made the loop LDS-DMA bound: 64 KB per query tile per CU)
+    // KB = 16-key sub-tiles per wave, NW = waves: the workgroup owns KT = 16*KB*NW keys.  NW = 8 is the long-sequence
+    // variant (dense grid only): every Q / dO tile staged in LDS serves 128 keys, so the per-wave LDS-DMA issue cost (the
+    // bound of this loop at NW = 4: ~18 issues per 44 MFMAs) halves while the per-wave register footprint stays put.
+    constexpr int KT = 16 * KB * NW;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     // Work decomposition: launching early-exit workgroups of this LDS-heavy kernel is NOT free (measured: ~0.24 us
@@ -318,28 +392,28 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     const int h = blockIdx.y;
     const int b = p.work ? p.work[2 * blockIdx.x] : blockIdx.z;
     const int tile = p.work ? p.work[2 * blockIdx.x + 1] : blockIdx.x;
-    const int k0 = tile * 64 + wave * 16;
+    const int k0 = tile * KT + wave * (16 * KB);
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
-    const int ntiles = (klim + 63) / 64;
+    const int ntiles = (klim + KT - 1) / KT;
     const int col0 = h * p.dh;
-    const int key = k0 + li;
-    bf16_t* dkp = p.dk + ((int64_t)b * p.T + key) * p.lddkv + col0;
-    bf16_t* dvp = p.dv + ((int64_t)b * p.T + key) * p.lddkv + col0;
 
     if (tile >= ntiles) return;                 // dense-grid fallback only: masked tile, zeros written by its owner below
     // exact zero gradients for the fully masked key tiles of this (b, h): tile t owns tiles t + ntiles, t + 2 ntiles, ...
-    for (int tz = tile + ntiles; tz * 64 < p.T; tz += ntiles) {
-        const int kz = tz * 64 + wave * 16 + li;
-        if (kz < p.T) {
-            bf16_t* zk = p.dk + ((int64_t)b * p.T + kz) * p.lddkv + col0;
-            bf16_t* zv = p.dv + ((int64_t)b * p.T + kz) * p.lddkv + col0;
+    for (int tz = tile + ntiles; tz * KT < p.T; tz += ntiles) {
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const int d = dt * 16 + 4 * g;
-                if (d < p.dh) {
-                    *reinterpret_cast<u32x2*>(zk + d) = u32x2{0u, 0u};
-                    *reinterpret_cast<u32x2*>(zv + d) = u32x2{0u, 0u};
+        for (int kb = 0; kb < KB; ++kb) {
+            const int kz = tz * KT + wave * (16 * KB) + kb * 16 + li;
+            if (kz < p.T) {
+                bf16_t* zk = p.dk + ((int64_t)b * p.T + kz) * p.lddkv + col0;
+                bf16_t* zv = p.dv + ((int64_t)b * p.T + kz) * p.lddkv + col0;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int d = dt * 16 + 4 * g;
+                    if (d < p.dh) {
+                        *reinterpret_cast<u32x2*>(zk + d) = u32x2{0u, 0u};
+                        *reinterpret_cast<u32x2*>(zv + d) = u32x2{0u, 0u};
+                    }
                 }
             }
         }
@@ -347,25 +421,31 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes), rdo = make_rsrc(p.dout, p.do_bytes);
     const uint64_t stat_bytes = p.stat_bytes;
     const __amdgpu_buffer_rsrc_t rlse = make_rsrc(p.lse, stat_bytes), rdel = make_rsrc(p.delta, stat_bytes);
-    const int64_t krow = (int64_t)b * p.T + key, klimrow = (int64_t)b * p.T + p.T;
-    bf16x8 kf[4], vf[4];
+    const int64_t klimrow = (int64_t)b * p.T + p.T;
+    bf16x8 kf[KB][KS], vf[KB][KS];
+    float kb_[KB];
+    bool kvalid[KB];
+    f32x4 adk[KB][DT], adv[KB][DT];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = frag_global(p.k, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
-        vf[ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = k0 + kb * 16 + li;
+        const int64_t krow = (int64_t)b * p.T + key;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[kb][ks] = frag_global(p.k, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
+            vf[kb][ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
+        }
+        kvalid[kb] = key < p.T;
+        kb_[kb] = kvalid[kb] ? p.bias[(int64_t)b * p.T + key] : -1e30f;        // keys past T: P = exp2(-huge) = 0
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { adk[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    const float kb = key < p.T ? p.bias[(int64_t)b * p.T + key] : 0.f;
-    const bool kvalid = key < p.T;
-
-    f32x4 adk[8], adv[8];
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) { adk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // double-buffered query tiles: tile qt+1 is DMA'd while tile qt is consumed
     auto stage_q = [&](int q0, char* base) {
         const int64_t r0 = (int64_t)b * p.N + q0, rl = (int64_t)b * p.N + p.N;
-        stage64x128<IMG_TR>(rq, base, r0, rl, p.ldq, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR, NW>(rq, base, r0, rl, p.ldq, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR, NW>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
         // lse / delta rows by 4-byte LDS-DMA as well: an ordinary VGPR load here would make the compiler wait
         // vmcnt(0) for it -- draining the 16 tile DMAs just issued and undoing the double buffering.  Rows past N read
         // as 0 (range check); their Q and dO rows are zero too, so P stays finite and dS = P * (0 - 0) = 0.
@@ -388,50 +468,142 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_kernel(SdpaP p) {
         const float* lse_s = reinterpret_cast<const float*>(cur + 2 * TILE);
         const float* del_s = lse_s + 64;
 
-        f32x4 s[4], dp[4];
+        f32x4 s[KB][4], dp[KB][4];
 #pragma unroll
         for (int nq = 0; nq < 4; ++nq) {
-            s[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s[nq] = mfma16(frag_row_tr(Qt, nq * 16, ks, lane), kf[ks], s[nq]);     // [q = 16nq+4g+r][key = li]
-                dp[nq] = mfma16(frag_row_tr(Ot, nq * 16, ks, lane), vf[ks], dp[nq]);
+            for (int kb = 0; kb < KB; ++kb) {
+                s[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qfr = frag_row_tr(Qt, nq * 16, ks, lane), ofr = frag_row_tr(Ot, nq * 16, ks, lane);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    s[kb][nq] = mfma16(qfr, kf[kb][ks], s[kb][nq]);     // [q = 16nq+4g+r][key = li]
+                    dp[kb][nq] = mfma16(ofr, vf[kb][ks], dp[kb][nq]);
+                }
             }
         }
+        bf16x8 pf0[KB], pf1[KB], sf0[KB], sf1[KB];
+        float nl2[4][4];
 #pragma unroll
         for (int nq = 0; nq < 4; ++nq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = nq * 16 + 4 * g + r;
-                const float pr = kvalid ? __expf(s[nq][r] * p.scale + kb - lse_s[ql]) : 0.f;
-                s[nq][r] = pr;                                  // P
-                dp[nq][r] = pr * (dp[nq][r] - del_s[ql]);       // dS
-            }
-        const bf16x8 pf0 = acc_to_frag(s[0], s[1]), pf1 = acc_to_frag(s[2], s[3]);
-        const bf16x8 sf0 = acc_to_frag(dp[0], dp[1]), sf1 = acc_to_frag(dp[2], dp[3]);
+            for (int r = 0; r < 4; ++r) nl2[nq][r] = -lse_s[nq * 16 + 4 * g + r] * LOG2E;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            adv[dt] = mfma16(frag_tr_acc(Ot, 0, dt * 16, lane), pf0, adv[dt]);
-            adv[dt] = mfma16(frag_tr_acc(Ot, 32, dt * 16, lane), pf1, adv[dt]);
-            adk[dt] = mfma16(frag_tr_acc(Qt, 0, dt * 16, lane), sf0, adk[dt]);
-            adk[dt] = mfma16(frag_tr_acc(Qt, 32, dt * 16, lane), sf1, adk[dt]);
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int nq = 0; nq < 4; ++nq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = nq * 16 + 4 * g + r;
+                    const float pr = exp_sub(__builtin_fmaf(s[kb][nq][r], p.scale, kb_[kb]), nl2[nq][r]);
+                    s[kb][nq][r] = pr;                                      // P
+                    dp[kb][nq][r] = pr * (dp[kb][nq][r] - del_s[ql]);       // dS
+                }
+            pf0[kb] = acc_to_frag(s[kb][0], s[kb][1]); pf1[kb] = acc_to_frag(s[kb][2], s[kb][3]);
+            sf0[kb] = acc_to_frag(dp[kb][0], dp[kb][1]); sf1[kb] = acc_to_frag(dp[kb][2], dp[kb][3]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 o0 = frag_tr_acc(Ot, 0, dt * 16, lane), o1 = frag_tr_acc(Ot, 32, dt * 16, lane);
+            const bf16x8 q0f = frag_tr_acc(Qt, 0, dt * 16, lane), q1f = frag_tr_acc(Qt, 32, dt * 16, lane);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                adv[kb][dt] = mfma16(o0, pf0[kb], adv[kb][dt]);
+                adv[kb][dt] = mfma16(o1, pf1[kb], adv[kb][dt]);
+                adk[kb][dt] = mfma16(q0f, sf0[kb], adk[kb][dt]);
+                adk[kb][dt] = mfma16(q1f, sf1[kb], adk[kb][dt]);
+            }
         }
     }
-    if (kvalid) {
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
+    for (int kb = 0; kb < KB; ++kb) {
+        if (!kvalid[kb]) continue;
+        const int key = k0 + kb * 16 + li;
+        bf16_t* dkp = p.dk + ((int64_t)b * p.T + key) * p.lddkv + col0;
+        bf16_t* dvp = p.dv + ((int64_t)b * p.T + key) * p.lddkv + col0;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + 4 * g;
             if (d < p.dh) {
-                *reinterpret_cast<u32x2*>(dvp + d) = pack4(adv[dt][0], adv[dt][1], adv[dt][2], adv[dt][3]);
-                *reinterpret_cast<u32x2*>(dkp + d) =
-                    pack4(adk[dt][0] * p.scale, adk[dt][1] * p.scale, adk[dt][2] * p.scale, adk[dt][3] * p.scale);
+                *reinterpret_cast<u32x2*>(dvp + d) = pack4(adv[kb][dt][0], adv[kb][dt][1], adv[kb][dt][2], adv[kb][dt][3]);
+                *reinterpret_cast<u32x2*>(dkp + d) = pack4(adk[kb][dt][0] * p.scale, adk[kb][dt][1] * p.scale,
+                                                           adk[kb][dt][2] * p.scale, adk[kb][dt][3] * p.scale);
             }
         }
     }
 }
 
 constexpr int FWD_LDS = 2 * FWD_STAGE, DQ_LDS = 2 * DQ_STAGE, DKV_LDS = 2 * DKV_STAGE;
+
+// The LDS images stay 128 columns wide (columns past dh are zero-filled by the DMA range check); what the head dim decides
+// is how many of the 32-wide k-steps (KS) and 16-wide output tiles (DT) carry data.  Instantiations: dh <= 32 (SANA's
+// softmax variant of attn1), <= 64, <= 80 (PixArt-Sigma: 72), <= 112 (SANA cross-attention), <= 128.
+template <int KS, int DT, int QS>
+int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)sdpa_fwd_kernel<KS, DT, QS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                FWD_LDS) != hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sdpa_fwd_kernel<KS, DT, QS>), dim3((p.N + 64 * QS - 1) / (64 * QS), p.H, B), dim3(256), FWD_LDS, stream,
+                       p);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+template <int KS, int DT>
+int launch_fwd(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    return wide ? launch_fwd_qs<KS, DT, 2>(p, B, stream) : launch_fwd_qs<KS, DT, 1>(p, B, stream);
+}
+template <int KS, int DT, int QS>
+int launch_dq_qs(const SdpaP& p, int B, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<KS, DT, QS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DQ_LDS) != hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS>), dim3((p.N + 64 * QS - 1) / (64 * QS), p.H, B), dim3(256), DQ_LDS,
+                       stream, p);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+template <int KS, int DT>
+int launch_dq(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    return wide ? launch_dq_qs<KS, DT, 2>(p, B, stream) : launch_dq_qs<KS, DT, 1>(p, B, stream);
+}
+template <int KS, int DT, int KB, int NW>
+int launch_dkv_kb(const SdpaP& p, int B, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel<KS, DT, KB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DKV_LDS) != hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
+    constexpr int KT = 16 * KB * NW;
+    const dim3 grid = p.work ? dim3(p.n_work, p.H, 1) : dim3((p.T + KT - 1) / KT, p.H, B);
+    hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<KS, DT, KB, NW>), grid, dim3(64 * NW), DKV_LDS, stream, p);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+template <int KS, int DT>
+int launch_dkv(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    if (wide == 2) return launch_dkv_kb<KS, DT, 2, 4>(p, B, stream);      // 32 keys per wave: measured slower, see below
+    return wide ? launch_dkv_kb<KS, DT, 1, 8>(p, B, stream) : launch_dkv_kb<KS, DT, 1, 4>(p, B, stream);
+}
+#define YAT_SDPA_DISPATCH(fn, dh, ...)                      \
+    ((dh) <= 32    ? fn<1, 2>(__VA_ARGS__)                  \
+     : (dh) <= 64  ? fn<2, 4>(__VA_ARGS__)                  \
+     : (dh) <= 80  ? fn<3, 5>(__VA_ARGS__)                  \
+     : (dh) <= 112 ? fn<4, 7>(__VA_ARGS__)                  \
+                   : fn<4, 8>(__VA_ARGS__))
 
 int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv) {
     if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7)) return YAT_EINVAL;
@@ -446,20 +618,15 @@ extern "C" {
 int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream) {
     if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 3) || !q || !k || !v || !key_bias || !out) return YAT_EINVAL;
-    static bool fwd_attr_set = false;
-    if (!fwd_attr_set) {
-        if (hipFuncSetAttribute((const void*)sdpa_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
-            return YAT_EINVAL;
-        fwd_attr_set = true;
-    }
     SdpaP p{};
     p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
     p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = lse;
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
-    hipLaunchKernelGGL(sdpa_fwd_kernel, dim3((N + 63) / 64, H, B), dim3(256), FWD_LDS, (hipStream_t)stream, p);
-    YAT_CHECK_LAUNCH();
-    return YAT_OK;
+    // 128-query workgroups once there are enough of them to fill the chip twice over (PixArt-Sigma: N = 4096)
+    static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
+    const int wide = wide_env >= 0 ? wide_env : ((int64_t)((N + 127) / 128) * H * B >= 1024);
+    return YAT_SDPA_DISPATCH(launch_fwd, dh, p, B, wide, (hipStream_t)stream);
 }
 
 int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
@@ -470,15 +637,6 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
         !key_bias || !out || !dout || !lse || !delta || !dq || !dk || !dv)
         return YAT_EINVAL;
     if ((uint64_t)B * N * lddo * 2 > 0x7fffffffull) return YAT_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS) !=
-                hipSuccess)
-            return YAT_EINVAL;
-        attr_set = true;
-    }
     SdpaP p{};
     p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
@@ -489,19 +647,22 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.bias_bytes = (uint64_t)B * T * 4;
     p.stat_bytes = (uint64_t)B * H * N * 4;
     if (parts < 1 || parts > 3) return YAT_EINVAL;
+    static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
     if (parts & 1) {                               // dQ, and delta = rowsum(dO * O) which the dK/dV part reads
-        hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), DQ_LDS, (hipStream_t)stream, p);
-        YAT_CHECK_LAUNCH();
+        const int wide = wide_env >= 0 ? wide_env : ((int64_t)((N + 127) / 128) * H * B >= 1024);
+        const int rc = YAT_SDPA_DISPATCH(launch_dq, dh, p, B, wide, (hipStream_t)stream);
+        if (rc != YAT_OK) return rc;
     }
     if (!(parts & 2)) return YAT_OK;
-    if (work_list && n_work > 0) {
-        p.work = work_list; p.n_work = n_work;
-        hipLaunchKernelGGL(sdpa_bwd_dkv_kernel, dim3(n_work, H, 1), dim3(256), DKV_LDS, (hipStream_t)stream, p);
-    } else {
-        hipLaunchKernelGGL(sdpa_bwd_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), DKV_LDS, (hipStream_t)stream, p);
-    }
-    YAT_CHECK_LAUNCH();
-    return YAT_OK;
+    if (work_list && n_work > 0) { p.work = work_list; p.n_work = n_work; }
+    // 128-key workgroups: dense grid only (the host's compact work list counts 64-key tiles)
+    // dK/dV keeps 64-key workgroups.  Both 128-key variants measured slower at N = T = 4096, dh 72 (dense grid only; the
+    // host's compact work list counts 64-key tiles) and stay behind YAT_SDPA_WIDE_KV: 1 = 8 waves x 16 keys (1.97 ms vs
+    // 1.80 ms: one workgroup per CU, eight waves per barrier), 2 = 4 waves x 32 keys (3.19 ms vs 2.37 ms before the VALU
+    // trims: 330 registers leave one wave per SIMD).
+    static const int wide_kv_env = getenv("YAT_SDPA_WIDE_KV") ? atoi(getenv("YAT_SDPA_WIDE_KV")) : 0;
+    const int wide_kv = p.work ? 0 : wide_kv_env;
+    return YAT_SDPA_DISPATCH(launch_dkv, dh, p, B, wide_kv, (hipStream_t)stream);
 }
 
 }  // extern "C"
