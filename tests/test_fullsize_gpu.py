@@ -195,3 +195,37 @@ def test_optimizer_full_size_halves_equal_whole(ops):
     for a, b_ in zip(whole, bg):
         assert torch.equal(a, b_)
     assert not torch.equal(whole[0], p)         # the step moved the parameters
+
+
+def test_pixart_self_attention_full_size(ops):
+    """PixArt-Sigma attn1 at 1024 px: 16 heads x 72 over N = T = 4096 tokens, q | k | v = the column blocks of the fused
+    projection, 128-query workgroups (the long-sequence variant).  Forward and all three gradients against torch (fp32
+    truth and torch's own bf16 kernel as the yardstick) on two images; ragged N (4096 - 40) exercises the tail masking."""
+    Bp, Hp, dh = 2, 16, 72
+    Dp = Hp * dh
+    scale = 1 / math.sqrt(dh)
+    for Np in (4096, 4096 - 40):
+        qkv = grnd(Bp * Np, 3 * Dp, seed=31)
+        dout = grnd(Bp * Np, Dp, scale=0.1, seed=32)
+        out, lse = torch.empty(Bp * Np, Dp, dtype=BF, device=DEV), torch.empty(Bp, Hp, Np, device=DEV)
+        zero = torch.zeros(Bp, Np, device=DEV)
+        full = torch.full((Bp,), Np, dtype=torch.int32, device=DEV)
+        q, k, v = qkv[:, :Dp], qkv[:, Dp:2 * Dp], qkv[:, 2 * Dp:]
+        ops.sdpa_fwd(q, k, v, Bp, Np, Np, Hp, dh, scale, zero, full, out, lse)
+        dqkv = torch.full_like(qkv, float("nan"))
+        ops.sdpa_bwd(q, k, v, Bp, Np, Np, Hp, dh, scale, zero, full, out, dout, lse, torch.empty(Bp, Hp, Np, device=DEV),
+                     dqkv[:, :Dp], dqkv[:, Dp:2 * Dp], dqkv[:, 2 * Dp:])
+        assert torch.isfinite(dqkv.float()).all()
+
+        def torch_path(dt):
+            t = qkv.to(dt).clone().requires_grad_(True)
+            heads = lambda x: x.reshape(Bp, Np, Hp, dh).transpose(1, 2)
+            o = F.scaled_dot_product_attention(heads(t[:, :Dp]), heads(t[:, Dp:2 * Dp]), heads(t[:, 2 * Dp:]))
+            o = o.transpose(1, 2).reshape(Bp * Np, Dp)
+            o.backward(dout.to(dt))
+            return o.detach(), t.grad
+        o32, g32 = torch_path(torch.float32)
+        obf, gbf = torch_path(BF)
+        as_good_as(out, obf, o32, f"pixart_sdpa_fwd N={Np}")
+        for name, sl in (("dq", slice(0, Dp)), ("dk", slice(Dp, 2 * Dp)), ("dv", slice(2 * Dp, 3 * Dp))):
+            as_good_as(dqkv[:, sl], gbf[:, sl], g32[:, sl], f"pixart_sdpa_{name} N={Np}")

@@ -22,6 +22,7 @@
 // works on a contiguous band of tiles.
 #include <math.h>
 #include "common.hpp"
+#include <cstdlib>
 #include "gemm_common.hpp"
 #include "../../include/yat_hip.h"
 
@@ -225,7 +226,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     int ksplit = 1;
     if (variant >= 100) { ksplit = variant / 100; variant %= 100; }     // tests / tuning: 100*ksplit + variant
     if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
-    if (ksplit != 1 && ksplit != 2 && ksplit != 4) return YAT_EINVAL;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4 && ksplit != 8) return YAT_EINVAL;
     GemmP p;
     {
         const int rc = fill_gemm_p(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, ep, p);
@@ -238,12 +239,13 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
         if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
     }
+    static const int max_ksplit = getenv("YAT_GEMM_MAX_KSPLIT") ? atoi(getenv("YAT_GEMM_MAX_KSPLIT")) : 8;
     if (variant == 0) {
         variant = 1;
         if (M >= 1024 && N >= 512 && K >= 256) {
             double best = est_time_128(M, N, K);
             for (int v = 4; v <= 5; ++v)
-                for (int s = 1; s <= 4; s *= 2) {
+                for (int s = 1; s <= max_ksplit; s *= 2) {      // 8: few-tile, very long-K weight gradients (1152 x 1152 x 32768)
                     if (s > 1 && p.pre_add) continue;
                     if (s > 1 && (!workspace || !wide_ok || (uint64_t)s * M * N * 4 > workspace_bytes || K / s < 512)) continue;
                     const double t = est_time_256(M, N, K, v == 4 ? 256 : 320, s);
