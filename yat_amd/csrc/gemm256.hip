@@ -188,6 +188,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // issued between groups of 4 MFMAs (the matrix pipe keeps draining queued MFMAs while the wave issues a DMA),
     // so the LOAD segments carry only the fragment reads and stay shorter than the partner's COMPUTE segment.
     constexpr bool DIC_ = A_T || B_T;
+    constexpr int GAP = (8 * NT) / NPIECE >= 4 ? 4 : 3;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
+    static_assert((8 * NT) / GAP >= NPIECE, "not enough MFMA slots for the DMA pieces of a tile");
     auto compute = [&](int dma_tile) {
         char* dst = smem + (dma_tile & 1) * G::STAGE;
         __builtin_amdgcn_s_setprio(1);
@@ -197,9 +199,9 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             for (int j = 0; j < NT; ++j) {
                 acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
                 const int idx = i * NT + j;
-                if (DIC_ && idx % 4 == 3 && idx / 4 < NPIECE) {
+                if (DIC_ && idx % GAP == GAP - 1 && idx / GAP < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (dma_tile >= 0) issue_piece(dma_tile, dst, idx / 4);
+                    if (dma_tile >= 0) issue_piece(dma_tile, dst, idx / GAP);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -432,7 +434,8 @@ int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs
     return YAT_EINVAL;
 }
 
-// variant: 4 -> BN=256, 5 -> BN=320
+// variant: 4 -> BN=256, 5 -> BN=320.  (A 256 x 192 tile -- no ragged column tile at N = 1152 / 3456 / 4608 -- was
+// instantiated and measured at the PixArt shapes: never faster than the policy's pick, 5-25 % slower than BN=320; removed.)
 int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStream_t stream) {
     if (p.glu_u) {                 // GLU-backward epilogue: only the dgrad layout (dy W) is instantiated, no split-K
         if (a_t || !b_t || p.ksplit > 1) return YAT_EINVAL;
