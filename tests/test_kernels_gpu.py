@@ -425,8 +425,13 @@ def _sdpa_ref(q, k, v, bias, B, N, T, H, dh, scale):
     return (p @ vf).transpose(1, 2).reshape(B * N, H * dh), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("B,N,T,H,dh,lens", [(2, 64, 64, 1, 32, [64, 20]), (2, 100, 128, 2, 112, [77, 128]),
-                                             (3, 130, 512, 2, 112, [300, 5, 0]), (1, 48, 40, 3, 64, [33])])
+@pytest.mark.parametrize("B,N,T,H,dh,lens", [
+    (2, 64, 64, 1, 32, [64, 20]), (2, 100, 128, 2, 112, [77, 128]), (3, 130, 512, 2, 112, [300, 5, 0]), (1, 48, 40, 3, 64, [33]),
+    (2, 70, 90, 2, 72, [90, 41]), (1, 40, 200, 2, 24, [130]), (2, 33, 64, 1, 128, [64, 9]),
+    # ceil(N/128) * H * B >= 1024: the 128-query workgroup variants of forward and dQ, one per head-dim instantiation
+    (8, 250, 200, 64, 32, [200, 7, 64, 65, 128, 199, 1, 100]), (16, 200, 100, 32, 64, [100, 3] * 8),
+    (16, 256, 150, 32, 72, [150, 149, 64, 1] * 4), (8, 130, 130, 64, 112, [130, 64, 65, 2] * 2),
+    (32, 130, 70, 16, 128, [70, 1, 64, 33] * 8)])
 def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
     D = H * dh
     scale = 1.0 / math.sqrt(dh)
