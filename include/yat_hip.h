@@ -44,6 +44,10 @@ typedef struct yat_gemm_epilogue {
     const void* pre_add;   /* bf16 [M, ld_pre_add] or NULL (forward layout only): added to the rounded Linear output      */
     int ld_pre_add;        /* before aux_out / activation / gate / residual -- a PEFT adapter's                          */
                            /* base_layer(x) + F.linear(x, delta_w) (peft LoKr/LoRA wrap at common/trainer.py:212-238)     */
+    const void* dact_z;    /* bf16 [M, ld_dact_z] or NULL (dgrad layout only): activation backward fused into the GEMM that   */
+    int ld_dact_z;         /* produces the activation's output gradient: C = bf16(bf16(result) * act'(z)), `activation`       */
+                           /* selecting act (1 SiLU, 2 GELU-tanh) -- FeedForward's GELU in PixArt-Sigma (net.0 -> net.2);      */
+                           /* excludes the other options                                                                       */
 } yat_gemm_epilogue;
 
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].

@@ -660,3 +660,19 @@ def test_clip_and_adamw_match_torch_cpu(ops):
         print(f"[parity] adamw step {step}: {bad} / {n} params differ bitwise from torch CPU")
         assert bad <= 0.002 * n
         assert flat["g"].abs().max().item() == 0.0     # zero_grad fused
+
+
+@pytest.mark.parametrize("act", ["gelu_tanh", "silu"])
+@pytest.mark.parametrize("M,N,K", [(300, 328, 96), (1024, 1152, 288), (520, 4608, 1152)])
+def test_dgrad_with_activation_backward_epilogue(ops, act, M, N, K):
+    """dz = (dy W) * act'(z) in the GEMM epilogue == linear_dgrad followed by act_bwd, bit for bit (the intermediate is
+    rounded to bf16 in both), and close to the fp32 formula."""
+    dy, w, z = rnd(M, K, seed=90), rnd(K, N, scale=K ** -0.5, seed=91), rnd(M, N, seed=92)
+    fused = ops.linear_dgrad_act(dy, w, z, act)
+    d = ops.linear_dgrad(dy, w)
+    unfused = ops.act_bwd(z, d, act)
+    assert torch.equal(fused, unfused)
+    zf = z.float().requires_grad_(True)
+    (F.gelu(zf, approximate="tanh") if act == "gelu_tanh" else F.silu(zf)).backward(rb(dy.float() @ w.float()))
+    # against torch: the bf16 rounding of the intermediate can flip with the accumulation order, so one extra ulp
+    close(fused, zf.grad.to(BF), f"dgrad_act_{act} {M}x{N}x{K}", ulps=3.0)

@@ -198,6 +198,9 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
         p.glu_u = (const bf16_t*)ep->glu_u; p.ld_glu = ep->ld_glu_u;
         if (p.glu_u && (p.bias || p.gate || p.res || p.aux || p.act || (p.ld_glu & 3) || p.ld_glu < 2 * N || ldc < 2 * N))
             return YAT_EINVAL;
+        p.dact_z = (const bf16_t*)ep->dact_z; p.ld_z = ep->ld_dact_z;
+        if (p.dact_z && (p.bias || p.gate || p.res || p.aux || p.glu_u || p.pre_add || !p.act || (p.ld_z & 3) || p.ld_z < N))
+            return YAT_EINVAL;
     }
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
@@ -235,6 +238,10 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     const bool wide_ok = !(N & 7) && !(ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
                          !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7)) && !(p.pre_add && (p.ld_pre & 7));
     if (p.pre_add && (a_t || b_t || p.glu_u)) return YAT_EINVAL;       // adapter addend: forward layout only
+    if (p.dact_z) {                             // activation-backward epilogue: 256-row kernel, dgrad layout only
+        if (ksplit != 1 || variant == 1 || a_t || !b_t) return YAT_EINVAL;
+        if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
+    }
     if (p.glu_u) {                              // GLU-backward epilogue lives in the 256-row kernel only
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
         if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;

@@ -107,7 +107,7 @@ __device__ __forceinline__ int xcd_contiguous(int nwg) {
 }
 
 // One workgroup's whole job: `id` = work item inside problem p (tile x K slice, before the row-group swizzle).
-template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GLU backward, 2 standard + pre_add
+template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GLU backward, 2 standard + pre_add, 3 act backward
 __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     using G = Geo<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -262,7 +262,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // loads and C / aux stores are 16 B per lane over whole 128..160-B row segments.
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
     const bool wide = !(p.N & 7) && !(p.ldc & 7) && !(p.res && (p.ldr & 7)) && !(p.aux && (p.ldaux & 7)) &&
-                      !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7)) && !(p.pre_add && (p.ld_pre & 7));
+                      !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7)) && !(p.pre_add && (p.ld_pre & 7)) &&
+                      !(p.dact_z && (p.ld_z & 7));
     const bool split = p.ksplit > 1;           // host guarantees `wide` alignment when splitting
     if (wide || split) {
         constexpr int WCOLS = 16 * NT;             // columns per wave
@@ -296,6 +297,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                         } else {
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             if (EPI == 1) glu_bwd_store<8>(p, v, m, n);
+                            else if (EPI == 3) act_bwd_store<8>(p, v, m, n);
                             else gemm_epilogue_store8<EPI == 2>(p, v, m, n, m / rpb);
                         }
                     }
@@ -314,9 +316,10 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (int j = 0; j < NT; ++j) {
             const int n = n0 + wc * 16 * NT + j * 16 + 4 * (lane >> 4);
             if (n >= p.N) continue;
-            if (EPI == 1) {
+            if (EPI == 1 || EPI == 3) {
                 const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                glu_bwd_store<4>(p, v, m, n);
+                if (EPI == 1) glu_bwd_store<4>(p, v, m, n);
+                else act_bwd_store<4>(p, v, m, n);
             } else {
                 gemm_epilogue_store<EPI == 2>(p, acc[i][j], m, n, b);
             }
@@ -440,6 +443,10 @@ int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStre
     if (p.glu_u) {                 // GLU-backward epilogue: only the dgrad layout (dy W) is instantiated, no split-K
         if (a_t || !b_t || p.ksplit > 1) return YAT_EINVAL;
         return nt_variant == 5 ? launch256<false, true, 5, 1>(p, stream) : launch256<false, true, 4, 1>(p, stream);
+    }
+    if (p.dact_z) {                // activation-backward epilogue: dgrad layout only, no split-K
+        if (a_t || !b_t || p.ksplit > 1) return YAT_EINVAL;
+        return nt_variant == 5 ? launch256<false, true, 5, 3>(p, stream) : launch256<false, true, 4, 3>(p, stream);
     }
     if (p.pre_add) {               // adapter addend: only the forward layout (x W^T) is instantiated, no split-K
         if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;

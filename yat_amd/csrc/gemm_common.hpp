@@ -19,6 +19,8 @@ struct GemmP {
     int ld_glu;
     const bf16_t* pre_add; // adapter path: [M, ld_pre] added to the rounded Linear output before aux / activation / gate
     int ld_pre;
+    const bf16_t* dact_z;  // activation-backward epilogue: z = the activation's input, [M, ld_z]; C = bf16(d) * act'(z)
+    int ld_z;
 };
 
 // GLU backward fused into the producer of dy (= this GEMM's result d, rounded to bf16 like the Linear's output):
@@ -51,6 +53,22 @@ __device__ __forceinline__ void glu_bwd_store(const GemmP& p, const float (&v)[W
         *reinterpret_cast<u32x2*>(cp) = pack4(da[0], da[1], da[2], da[3]);
         *reinterpret_cast<u32x2*>(cp + p.N) = pack4(dg[0], dg[1], dg[2], dg[3]);
     }
+}
+
+// Activation backward fused into the producer of the activation's output gradient (= this GEMM's result d, rounded to
+// bf16 like the Linear's output): dz = d * act'(z) -- the arithmetic of ew_kernel<1> (yat_act_bwd), which this replaces.
+// Its own template instantiation of gemm256 (EPI = 3), like the GLU one.
+template <int W>
+__device__ __forceinline__ void act_bwd_store(const GemmP& p, const float (&v)[W], int m, int n) {
+    float z[W], o[W];
+    const bf16_t* zp = p.dact_z + (int64_t)m * p.ld_z + n;
+    if (W == 8) unpack8(*reinterpret_cast<const u32x4*>(zp), z);
+    else unpack4(*reinterpret_cast<const u32x2*>(zp), z);
+#pragma unroll
+    for (int e = 0; e < W; ++e) o[e] = rbf(v[e]) * (p.act == 1 ? dsilu_f(z[e]) : dgelu_tanh_f(z[e]));
+    bf16_t* cp = p.C + (int64_t)m * p.ldc + n;
+    if (W == 8) *reinterpret_cast<u32x4*>(cp) = pack8(o);
+    else *reinterpret_cast<u32x2*>(cp) = pack4(o[0], o[1], o[2], o[3]);
 }
 
 // One lane's 4 consecutive output columns of row m (swapped-operand MFMA result):

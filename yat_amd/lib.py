@@ -18,7 +18,7 @@ P, I, I64, U64, F, D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
                 ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I),
-                ("glu_u", P), ("ld_glu_u", I), ("pre_add", P), ("ld_pre_add", I)]
+                ("glu_u", P), ("ld_glu_u", I), ("pre_add", P), ("ld_pre_add", I), ("dact_z", P), ("ld_dact_z", I)]
 
 
 class GemmProblem(C.Structure):

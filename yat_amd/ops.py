@@ -60,18 +60,19 @@ def _chk_bf16(*ts):
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
          activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
-         glu_u=None, pre_add=None):
+         glu_u=None, pre_add=None, dact_z=None):
     """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
-    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add)
+    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add, dact_z)
     lda = lda if lda is not None else (M if a_t else K)
     ldb = ldb if ldb is not None else (N if b_t else K)
     ldc = ldc if ldc is not None else N
     ep = None
     if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None \
-            or glu_u is not None or pre_add is not None:
+            or glu_u is not None or pre_add is not None or dact_z is not None:
         ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
                              ld_residual, rows_per_batch, _p(glu_u), 0 if glu_u is None else glu_u.stride(0),
-                             _p(pre_add), 0 if pre_add is None else pre_add.stride(0))
+                             _p(pre_add), 0 if pre_add is None else pre_add.stride(0),
+                             _p(dact_z), 0 if dact_z is None else dact_z.stride(0))
     timer = GEMM_TIMER
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,7 +83,7 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
     if timer is not None:
         e1.record()
         nbytes = 2.0 * (M * K + K * N + M * N * (1 + (residual is not None) + (aux_out is not None) +
-                                                 3 * (glu_u is not None)))
+                                                 3 * (glu_u is not None) + (dact_z is not None)))
         timer.append((2.0 * M * N * K, e0, e1, ("nt"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
                       gate is not None, residual is not None, aux_out is not None), nbytes))
     _l.check(rc, "yat_gemm_bf16")
@@ -112,6 +113,16 @@ def linear_dgrad_glu(dy2d, w, u, du):
     K = w.shape[1]
     assert u.shape == (M, 2 * K) and du.shape == (M, 2 * K)
     return gemm(dy2d, w, du, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=2 * K, glu_u=u)
+
+
+def linear_dgrad_act(dy2d, w, z, act, out=None):
+    """dz = (dy W) * act'(z): the activation backward in the epilogue of the dgrad GEMM that produces the activation's output
+    gradient (bit-identical to linear_dgrad followed by act_bwd; the intermediate never reaches memory)."""
+    M, N = dy2d.shape
+    K = w.shape[1]
+    assert z.shape == (M, K)
+    out = out if out is not None else torch.empty(M, K, dtype=BF16, device=dy2d.device)
+    return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, activation=act, dact_z=z)
 
 
 def linear_wgrad(dy2d, x2d, out, accumulate=False):

@@ -141,6 +141,11 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         offs, total = self._alloc_flat(specs, device)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers)
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"     # weight gradients / text branch on a 2nd stream
+        # GELU' in the ff.net.2 dgrad epilogue (yat_gemm_epilogue.dact_z): 92 us less kernel time per block when run alone
+        # (540 vs 448 + 184 us), but measured SLOWER in the step (same box, both orders: 267.3 vs 261.2, 292.6 vs 262.8 ms):
+        # the separate HBM-bound pass overlaps the second stream's MFMA-bound weight gradients for free, a longer epilogue
+        # in a one-workgroup-per-CU GEMM does not.  Off by default.
+        self.fuse_act_bwd = os.environ.get("YAT_FUSE_ACT_BWD", "0") != "0"
         self.pos_bf16_base = True         # the base-grid table is a module buffer: ``.to(bfloat16)`` rounds it (:52)
         self._pos = {}
 
@@ -384,8 +389,11 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate,
                          dbias=G[pre + "ff.net.2.bias"], accumulate_bias=acc)
             wgrad(dlin3, A.f1, G[pre + "ff.net.2.weight"])
-            df1 = dgrad(dlin3, P[pre + "ff.net.2.weight"], out=buf("df1", (M, 4 * D)))
-            dz = ops.act_bwd(A.z, df1, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
+            if self.fuse_act_bwd:               # see __init__: measured slower in the step, kept as a switch
+                dz = ops.linear_dgrad_act(dlin3, P[pre + "ff.net.2.weight"], A.z, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
+            else:
+                df1 = dgrad(dlin3, P[pre + "ff.net.2.weight"], out=buf("df1", (M, 4 * D)))
+                dz = ops.act_bwd(A.z, df1, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
             wgrad(dz, A.h2, G[pre + "ff.net.0.proj.weight"], G[pre + "ff.net.0.proj.bias"])
             dh2 = dgrad(dz, P[pre + "ff.net.0.proj.weight"], out=buf("dh", (M, D)))
             other = dxb if dx is dxa else dxa
