@@ -184,7 +184,7 @@ def test_gemm256_epilogue_and_identity(ops, variant):
     close(s_out, F.silu(linr).to(BF), f"gemm256v{variant}_epi_silu")
 
 
-@pytest.mark.parametrize("code", [204, 405, 205, 804])
+@pytest.mark.parametrize("code", [204, 405, 205, 804, 304, 1005])
 def test_gemm256_split_k(ops, code):
     """Split-K (fp32 slabs + reduce kernel with the fused epilogue), forced via variant = 100*ksplit + tile."""
     M, N, K = 520, 648, 2048 + 96                     # ragged everything; K tail lands in the last slice
