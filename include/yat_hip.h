@@ -200,6 +200,16 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
                      float scale, const void* d_delta, int ld, void* d_w1, void* d_w2_a, void* d_w2_b, void* workspace,
                      yat_stream_t stream);
 
+/* Factored application of a LoKr adapter (no dense delta_w): with x viewed as [rows = M*in_m, in_n],
+ *   T1 = x' w2_b^T            (yat_gemm_bf16, N = r)        P = kron(w1, w2_a) * scale  [out, in_m*r]  (yat_lokr_delta with
+ *   adapter(x) = T1_flat P^T  (yat_gemm_bf16, K = in_m*r)       w2_b := identity)
+ *   dx += (dy P)' w2_b,  d_P = dy^T T1_flat (then yat_lokr_project -> d_w1, d_w2_a),  d_w2_b = (dy P)'^T x'
+ * -- the last one has r x in_n outputs and a rows-long reduction: out[q, n] (+)= sum_row a[row, q] * x[row, n], q < r_out.
+ * a: bf16 [rows, R] (R = 8 or 16), x: bf16 [rows, N] (N <= 128, even), out: bf16 [r_out, N]. */
+uint64_t yat_lokr_small_wgrad_workspace_bytes(int R, int N);
+int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, void* out, int accumulate,
+                         void* workspace, yat_stream_t stream);
+
 /* elementwise helpers: y = act(x) and dx = dy * act'(x) on bf16 (time-embed / caption MLPs);
  * act: 1 SiLU, 2 GELU(tanh).  add: out = bf16(a + b).  f32->bf16 convert. */
 int yat_act_fwd(int64_t n, int act, const void* x, void* y, yat_stream_t stream);

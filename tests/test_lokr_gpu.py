@@ -62,9 +62,34 @@ def test_lokr_kernels_bit_exact(out_dim, in_dim, scale):
         assert e_hip <= 1.5 * e_cpu + 3e-3
 
 
-def test_lokr_training_step_matches_oracle():
+@pytest.mark.parametrize("rows,R,N,r_out,acc", [(1000, 8, 56, 8, False), (4096 * 40, 8, 56, 8, True), (777, 16, 128, 12, False),
+                                                (5000, 8, 8, 2, True)])
+def test_lokr_small_wgrad(rows, R, N, r_out, acc):
+    """out[q, n] (+)= sum_row a[row, q] x[row, n]: the r x in_n weight gradient of the factored path (d_w2_b)."""
+    from yat_amd import ops
+    g = torch.Generator().manual_seed(rows + N)
+    a, x = (torch.randn(rows, R, generator=g) * 0.1).to(BF).to(DEV), torch.randn(rows, N, generator=g).to(BF).to(DEV)
+    out0 = (torch.randn(r_out, N, generator=g) * 0.5).to(BF).to(DEV)
+    out = out0.clone()
+    ws = torch.empty(int(ops._lib().yat_lokr_small_wgrad_workspace_bytes(R, N)), dtype=torch.uint8, device=DEV)
+    ops.lokr_small_wgrad(a, x, out, ws, accumulate=acc)
+    want = (a.double().T @ x.double())[:r_out]
+    if acc:
+        want = want.float().to(BF).double() + out0.double()
+    e = rel(out, want)
+    print(f"[parity] lokr_small_wgrad rows={rows} R={R} N={N}: rel={e:.3e}")
+    assert e <= 3e-3
+    out2 = out0.clone()
+    ops.lokr_small_wgrad(a, x, out2, ws, accumulate=acc)
+    assert torch.equal(out, out2)                          # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("mode", ["factored", "dense"])
+def test_lokr_training_step_matches_oracle(mode):
     """One adapted training step (tiny SANA, non-zero w1 so the adapters matter): loss / prediction / adapter gradients
-    on the HIP path vs the oracle's bf16 and fp32 runs of the peft-wrapped model, then one clip+AdamW step."""
+    on the HIP path vs the oracle's bf16 and fp32 runs of the peft-wrapped model, then one clip+AdamW step.  Both
+    applications of the adapters: factored (T1 = x' w2_b^T, P = kron(w1, w2_a); the tiny caption projection with in_n = 12
+    falls back to dense inside it, and r = 2 exercises the rank padding) and dense (delta_w materialised, as peft does)."""
     from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
     from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
     from oracle.lokr_ref import apply_lokr
@@ -79,7 +104,9 @@ def test_lokr_training_step_matches_oracle():
     kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
     hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV)
     hip.load_state_dict(ref_bf.state_dict())
-    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=0.0)
+    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=0.0, mode=mode)
+    nf = sum(e["factored"] for e in ad.entries)
+    assert (nf == 0) if mode == "dense" else (0 < nf < len(ad.entries))
     g = torch.Generator().manual_seed(7)
     for e in ad.entries:                                    # meaningful adapters: w1 away from its zero init
         w1, _, _ = ad._views(e, ad.flat_param)

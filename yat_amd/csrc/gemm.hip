@@ -229,7 +229,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     int ksplit = 1;
     if (variant >= 100) { ksplit = variant / 100; variant %= 100; }     // tests / tuning: 100*ksplit + variant
     if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
-    if (ksplit < 1 || ksplit > 16) return YAT_EINVAL;
+    if (ksplit < 1 || ksplit > 32) return YAT_EINVAL;
     GemmP p;
     {
         const int rc = fill_gemm_p(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, ep, p);
@@ -246,11 +246,13 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
         if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
     }
-    static const int max_ksplit = getenv("YAT_GEMM_MAX_KSPLIT") ? atoi(getenv("YAT_GEMM_MAX_KSPLIT")) : 10;
+    static const int max_ksplit = getenv("YAT_GEMM_MAX_KSPLIT") ? atoi(getenv("YAT_GEMM_MAX_KSPLIT")) : 32;
     static const bool pow2_only = getenv("YAT_GEMM_KSPLIT_POW2") && atoi(getenv("YAT_GEMM_KSPLIT_POW2"));
     if (variant == 0) {
         variant = 1;
-        if (M >= 1024 && N >= 512 && K >= 256) {
+        // (N >= 256: one 256/320-wide column tile is fine when K is long enough to split -- the [out, in_m*r] weight
+        //  gradients of the factored LoKr path are 2240 x 320 x 32768: 9 tiles, split 28 ways)
+        if (M >= 1024 && (N >= 512 || (N >= 256 && K >= 8192)) && K >= 256) {
             double best = est_time_128(M, N, K);
             for (int v = 4; v <= 5; ++v)
                 for (int s = 1; s <= max_ksplit; s = pow2_only ? s * 2 : s + 1) {

@@ -97,6 +97,56 @@ __global__ __launch_bounds__(256) void lokr_dw2_final_kernel(LokrP p, const floa
     }
 }
 
+// Small-output weight gradient of the factored adapter path: out[q, n] (+)= sum_row A[row, q] * X[row, n] with a few
+// (R <= 16) x (N <= 128) outputs and a million-row reduction (rows = B*N_tokens*in_m) -- far outside what a tiled GEMM is
+// for.  HBM-bound streaming pass: a wave walks rows, a lane owns two adjacent columns of X and all R accumulators for them;
+// the four waves of a workgroup meet in LDS, every workgroup leaves one fp32 partial, a second launch sums the partials in a
+// fixed order (no atomics).
+template <int R>
+__global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int N, const bf16_t* A, const bf16_t* X,
+                                                               float* partial) {
+    __shared__ float red[4][R][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const int c = 2 * lane;
+    const bool live = c < N;
+    float a0[R], a1[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+        float av[R];
+#pragma unroll
+        for (int v = 0; v < R / 8; ++v) unpack8(*reinterpret_cast<const u32x4*>(A + r * R + v * 8), av + v * 8);
+        const uint32_t xx = live ? *reinterpret_cast<const uint32_t*>(X + r * N + c) : 0u;
+        const float x0 = __uint_as_float(xx << 16), x1 = __uint_as_float(xx & 0xffff0000u);
+#pragma unroll
+        for (int q = 0; q < R; ++q) { a0[q] += av[q] * x0; a1[q] += av[q] * x1; }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) { red[wave][q][c] = a0[q]; red[wave][q][c + 1] = a1[q]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < R * N; e += 256) {
+        const int q = e / N, n = e - q * N;
+        partial[(int64_t)blockIdx.x * R * N + e] = red[0][q][n] + red[1][q][n] + red[2][q][n] + red[3][q][n];
+    }
+}
+// out[q, n] = (accumulate ? out : 0) + sum_g partial[g][q*N + n], q < r_out.  One wave per 16 outputs: lane = (g-slice, e):
+// 4 slices of the partial list x 16 consecutive outputs (64-B runs), fixed order, then two shuffles.
+__global__ __launch_bounds__(256) void lokr_small_wgrad_final_kernel(int G, int RN, int n_out, const float* partial,
+                                                                     bf16_t* out, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = (blockIdx.x * 4 + wave) * 16 + (lane & 15), slice = lane >> 4;
+    float s = 0.f;
+    if (e < n_out)
+        for (int g = slice; g < G; g += 4) s += partial[(int64_t)g * RN + e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (e >= n_out || slice != 0) return;
+    if (accumulate) s = rbf(s) + bf2f(out[e]);
+    out[e] = f2bf(s);
+}
+
 int fill(LokrP& p, int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2a, const void* w2b,
          float scale, int ld) {
     if (out_l <= 0 || out_k <= 0 || in_m <= 0 || in_n <= 0 || r <= 0 || r > 64 || !w1 || !w2a || !w2b ||
@@ -140,6 +190,29 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(lokr_dw2_final_kernel, dim3(1), dim3(256), out_k * in_n * sizeof(float), (hipStream_t)stream, p,
                        (const float*)workspace, (bf16_t*)d_w2_a, (bf16_t*)d_w2_b);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+uint64_t yat_lokr_small_wgrad_workspace_bytes(int R, int N) { return (uint64_t)1024 * R * N * sizeof(float); }
+
+int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, void* out, int accumulate,
+                         void* workspace, yat_stream_t stream) {
+    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 1) || r_out <= 0 || r_out > R || !a || !x || !out ||
+        !workspace)
+        return YAT_EINVAL;
+    int64_t g64 = (rows + 255) / 256;
+    const int G = (int)(g64 > 512 ? 512 : g64);          // two workgroups per CU; every extra partial lengthens the final pass
+    if (R == 8)
+        hipLaunchKernelGGL((lokr_small_wgrad_kernel<8>), dim3(G), dim3(256), 0, (hipStream_t)stream, rows, N, (const bf16_t*)a,
+                           (const bf16_t*)x, (float*)workspace);
+    else
+        hipLaunchKernelGGL((lokr_small_wgrad_kernel<16>), dim3(G), dim3(256), 0, (hipStream_t)stream, rows, N, (const bf16_t*)a,
+                           (const bf16_t*)x, (float*)workspace);
+    YAT_CHECK_LAUNCH();
+    const int n_out = r_out * N;
+    hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, R * N,
+                       n_out, (const float*)workspace, (bf16_t*)out, accumulate);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

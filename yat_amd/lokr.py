@@ -13,6 +13,16 @@ module dropout drops the adapter for this step), the forward adds ``x delta_w^T`
 the backward adds ``dy delta_w`` to every input gradient, the ordinary weight-gradient GEMMs now produce d_delta_w in the
 model's flat gradient buffer (the base weights are frozen: nobody reads those slots as weight gradients), and
 ``project()`` folds each d_delta_w into (d_w1, d_w2_a, d_w2_b).
+
+That "dense" application costs 5/3 of the full fine-tune's GEMM FLOPs.  The default is the **factored** application
+(``mode='factored'``, per target when its dimensions allow 16-byte rows): the Kronecker structure is kept,
+    adapter(x) = T1_flat P^T,   T1 = x' w2_b^T  (x' = x viewed [M*in_m, in_n]),   P = kron(w1, w2_a) * alpha/r  [out, in_m*r]
+so a target costs two GEMMs with K = in_n and K = in_m*r (1/7 of the dense product at D = 2240, r = 8) in the forward, the
+mirrored pair for the input gradient, ``d_P = dy^T T1_flat`` (again 1/7) + ``yat_lokr_project`` for (d_w1, d_w2_a) and one
+streaming pass (``yat_lokr_small_wgrad``) for d_w2_b -- and the dense weight gradients of the frozen base are not computed at
+all.  P is built by ``yat_lokr_delta`` with w2_b := identity, d_P projected by ``yat_lokr_project`` the same way.  The
+adapter term is accumulated in fp32 and rounded once (peft rounds delta_w to bf16 first): at least as close to the fp32
+truth as the dense path, checked by the same oracle test in both modes.
 """
 from __future__ import annotations
 
@@ -53,9 +63,13 @@ def is_target(module_name: str, targets) -> bool:
 
 
 class LoKrAdapters:
-    def __init__(self, model, targets, r: int, alpha: float, module_dropout: float = 0.0):
+    def __init__(self, model, targets, r: int, alpha: float, module_dropout: float = 0.0, mode: str | None = None):
         self.model, self.r, self.alpha, self.scale = model, int(r), float(alpha), float(alpha) / int(r)
         self.targets, self.module_dropout = list(targets), float(module_dropout)
+        self.mode = mode or os.environ.get("YAT_LOKR_MODE", "factored")
+        if self.mode not in ("factored", "dense"):
+            raise ValueError(f"LoKr mode {self.mode!r}")
+        self.R = (self.r + 7) // 8 * 8                      # rank padded to 16-byte rows (zero columns / rows)
         dev = model.flat_param.device
         self.entries, off, segs = [], 0, [0]
 
@@ -77,6 +91,9 @@ class LoKrAdapters:
             e = dict(module=key[:-7], key=key, out=out_dim, inn=in_dim, out_l=out_l, out_k=out_k, in_m=in_m, in_n=in_n,
                      w_off=(w.data_ptr() - base_ptr) // 2, o1=take(out_l * in_m), oa=take(out_k * self.r),
                      ob=take(self.r * in_n), active=True)
+            # factored application needs 16-byte rows in every small GEMM: in_n, in_m*R, out multiples of 8
+            e["factored"] = (self.mode == "factored" and in_n % 8 == 0 and in_n <= 128 and self.R <= 16 and out_dim % 8 == 0
+                             and out_k * self.R * 4 <= 65536)
             self.entries.append(e)
         if not self.entries:
             raise ValueError("no module matches lora_target_modules")
@@ -88,9 +105,30 @@ class LoKrAdapters:
         self.bucket_bounds = [(0, off)]
         self.param_events = None
         self.grad_ready = None              # HipDDP hook: called once, after project()
-        self.delta = torch.zeros_like(model.flat_param)
-        ws = max(ops._lib().yat_lokr_project_workspace_bytes(e["out_l"], e["out_k"], e["in_n"]) for e in self.entries)
+        R = self.R
+        fact = [e for e in self.entries if e["factored"]]
+        # dense-mode entries keep their delta_w in a shadow of the model's flat weights (allocated only when one exists)
+        self.delta = torch.zeros_like(model.flat_param) if len(fact) < len(self.entries) else None
+        if fact:
+            # P = kron(w1, w2_a) * scale and its gradient, [out, in_m*R] per factored target, each in one flat buffer
+            sizes = [e["out"] * e["in_m"] * R for e in fact]
+            flatP = torch.zeros(sum(sizes), dtype=BF16, device=dev)
+            flatdP = torch.zeros(sum(sizes), dtype=BF16, device=dev)
+            o = 0
+            for e, n in zip(fact, sizes):
+                e["P"], e["dP"] = flatP[o:o + n].view(e["out"], e["in_m"] * R), flatdP[o:o + n].view(e["out"], e["in_m"] * R)
+                o += n
+                if R != self.r:                             # zero-padded copies of w2_a / w2_b and their gradients
+                    e["wa_pad"] = torch.zeros(e["out_k"], R, dtype=BF16, device=dev)
+                    e["wb_pad"] = torch.zeros(R, e["in_n"], dtype=BF16, device=dev)
+                    e["ga_pad"] = torch.zeros(e["out_k"], R, dtype=BF16, device=dev)
+            self._eye = torch.eye(R, dtype=BF16, device=dev)
+            self._gb_dummy = torch.empty(R, R, dtype=BF16, device=dev)
+            self._sw_ws = torch.empty(int(ops._lib().yat_lokr_small_wgrad_workspace_bytes(R, 128)), dtype=torch.uint8, device=dev)
+        ws = max(ops._lib().yat_lokr_project_workspace_bytes(e["out_l"], e["out_k"], R if e["factored"] else e["in_n"])
+                 for e in self.entries)
         self._ws = torch.empty(int(ws), dtype=torch.uint8, device=dev)
+        self._lookup = {}
         self.reset_parameters()
         model.adapters = self
 
@@ -104,6 +142,96 @@ class LoKrAdapters:
         """The view of the delta buffer that mirrors weight view ``w`` (same offset, shape and strides)."""
         off = (w.data_ptr() - self.model.flat_param.data_ptr()) // 2
         return torch.as_strided(self.delta, w.size(), w.stride(), off)
+
+    def lookup(self, t, base):
+        """Adapter entries whose target weight lies inside ``t`` (a view of the model's flat parameter or gradient buffer
+        ``base``; a fused q|k|v view holds three) -> [(entry, first row of the target inside the view)]."""
+        off, n = (t.data_ptr() - base.data_ptr()) // 2, t.numel()
+        hit = self._lookup.get((off, n))
+        if hit is None:
+            hit = [(e, (e["w_off"] - off) // e["inn"]) for e in self.entries if off <= e["w_off"] < off + n]
+            self._lookup[(off, n)] = hit
+        return hit
+
+    def _w2(self, e):
+        """(w2_a [out_k, R], w2_b [R, in_n]) with the rank padded to R."""
+        _, wa, wb = self._views(e, self.flat_param)
+        return (wa, wb) if self.R == self.r else (e["wa_pad"], e["wb_pad"])
+
+    # ---- application through the model's hooks (yat_amd/sana.py: lin / dgrad / weight-gradient emission)
+    def forward_term(self, x, w):
+        """x delta_w^T for the (possibly fused) target view ``w`` -> bf16 [M, rows(w)] for the GEMM's pre_add, or None."""
+        ents = self.lookup(w, self.model.flat_param)
+        if not ents:
+            return None
+        M, rows, R = x.shape[0], w.shape[0], self.R
+        tmp = torch.empty(M, rows, dtype=BF16, device=x.device)
+        if all(not e["factored"] for e, _ in ents):
+            ops.linear_fwd(x, self.delta_like(w), None, out=tmp)
+            return tmp
+        if sum(e["out"] for e, _ in ents) != rows:
+            tmp.zero_()
+        for e, row0 in ents:
+            blk = tmp[:, row0:row0 + e["out"]]
+            if not e["active"]:
+                blk.zero_()
+            elif not e["factored"]:
+                d = self.delta[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
+                ops.gemm(x, d, blk, M=M, N=e["out"], K=e["inn"], ldc=rows)
+            else:
+                im, n_ = e["in_m"], e["in_n"]
+                t1 = torch.empty(M * im, R, dtype=BF16, device=x.device)
+                ops.gemm(x.view(M * im, n_), self._w2(e)[1], t1, M=M * im, N=R, K=n_)
+                ops.gemm(t1.view(M, im * R), e["P"], blk, M=M, N=e["out"], K=im * R, ldc=rows)
+        return tmp
+
+    def dgrad_term(self, dy, w, dx):
+        """dx += dy delta_w for the target view ``w`` (dy [M, rows(w)], dx [M, in] contiguous)."""
+        ents = self.lookup(w, self.model.flat_param)
+        if not ents:
+            return
+        if all(not e["factored"] for e, _ in ents):
+            ops.linear_dgrad(dy, self.delta_like(w), out=dx, residual=dx)
+            return
+        M, R, ld = dy.shape[0], self.R, dy.stride(0)
+        for e, row0 in ents:
+            if not e["active"]:
+                continue
+            dyb = dy[:, row0:row0 + e["out"]]
+            if not e["factored"]:
+                d = self.delta[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
+                ops.gemm(dyb, d, dx, b_t=True, M=M, N=e["inn"], K=e["out"], lda=ld, ldb=e["inn"], ldc=e["inn"], residual=dx)
+                continue
+            im, n_ = e["in_m"], e["in_n"]
+            h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
+            ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
+            dx2 = dx.view(M * im, n_)
+            ops.gemm(h.view(M * im, R), self._w2(e)[1], dx2, b_t=True, M=M * im, N=n_, K=R, lda=R, ldb=n_, ldc=n_, residual=dx2)
+
+    def wgrad(self, dy, x, gw, accumulate=False):
+        """Adapter-side weight gradient of the target(s) behind the gradient view ``gw``: dense entries get d_delta_w in
+        their flat-gradient slot (as before), factored ones d_P and d_w2_b; a non-target weight (frozen, no adapter) gets
+        nothing.  dy [M, rows(gw)] (row stride allowed), x [M, in] contiguous."""
+        M, R, ld = dy.shape[0], self.R, dy.stride(0)
+        for e, row0 in self.lookup(gw, self.model.flat_grad):
+            if not e["active"]:
+                continue
+            dyb = dy[:, row0:row0 + e["out"]]
+            if not e["factored"]:
+                g = self.model.flat_grad[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
+                ops.gemm(dyb, x, g, a_t=True, b_t=True, M=e["out"], N=e["inn"], K=M, lda=ld, ldb=e["inn"], ldc=e["inn"],
+                         residual=g if accumulate else None)
+                continue
+            im, n_ = e["in_m"], e["in_n"]
+            x2 = x.view(M * im, n_)
+            t1 = torch.empty(M * im, R, dtype=BF16, device=x.device)
+            ops.gemm(x2, self._w2(e)[1], t1, M=M * im, N=R, K=n_)
+            ops.gemm(dyb, t1.view(M, im * R), e["dP"], a_t=True, b_t=True, M=e["out"], N=im * R, K=M, lda=ld, ldb=im * R,
+                     ldc=im * R, residual=e["dP"] if accumulate else None)
+            h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
+            ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
+            _, _, gb = self._views(e, self.flat_grad)
+            ops.lokr_small_wgrad(h.view(M * im, R), x2, gb, self._sw_ws, accumulate=accumulate)
 
     def reset_parameters(self):
         """peft init_weights=True: w1 zeros, w2_a / w2_b kaiming_uniform(a=sqrt(5)) drawn on the CPU, then cast."""
@@ -128,9 +256,16 @@ class LoKrAdapters:
         self.join_pending_update()
         for e in self.entries:
             e["active"] = (not training) or self.module_dropout <= 0.0 or bool(torch.rand(1) > self.module_dropout)
+            w1, wa, wb = self._views(e, self.flat_param)
+            if e["factored"]:
+                if e["active"]:
+                    if self.R != self.r:
+                        e["wa_pad"][:, :self.r].copy_(wa)
+                        e["wb_pad"][:self.r].copy_(wb)
+                    ops.lokr_delta(w1, self._w2(e)[0], self._eye, self.scale, e["P"])      # kron(w1, w2_a) * scale
+                continue
             d2 = self.delta[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
             if e["active"]:
-                w1, wa, wb = self._views(e, self.flat_param)
                 ops.lokr_delta(w1, wa, wb, self.scale, d2)
             else:
                 d2.zero_()
@@ -144,6 +279,13 @@ class LoKrAdapters:
                 g1.zero_(); ga.zero_(); gb.zero_()
                 continue
             w1, wa, wb = self._views(e, self.flat_param)
+            if e["factored"]:
+                # d_P -> (d_w1, d_w2_a) by the autograd of kron(w1, w2_a) * scale; d_w2_b was written by wgrad()
+                ga_r = ga if self.R == self.r else e["ga_pad"]
+                ops.lokr_project(w1, self._w2(e)[0], self._eye, self.scale, e["dP"], g1, ga_r, self._gb_dummy, self._ws)
+                if ga_r is not ga:
+                    ga.copy_(ga_r[:, :self.r])
+                continue
             dd = G[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
             ops.lokr_project(w1, wa, wb, self.scale, dd, g1, ga, gb, self._ws)
         if self.grad_ready is not None:

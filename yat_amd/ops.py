@@ -178,6 +178,18 @@ def lokr_project(w1, w2a, w2b, scale, d_delta2d, dw1, dw2a, dw2b, workspace):
     _l.check(rc, "yat_lokr_project")
 
 
+def lokr_small_wgrad(a2d, x2d, out2d, workspace, accumulate=False):
+    """out[q, n] (+)= sum_row a[row, q] * x[row, n], q < out.shape[0] (include/yat_hip.h: yat_lokr_small_wgrad)."""
+    _chk_bf16(a2d, x2d, out2d)
+    rows, R = a2d.shape
+    N = x2d.shape[1]
+    if x2d.shape[0] != rows or out2d.shape[1] != N or not (a2d.is_contiguous() and x2d.is_contiguous() and out2d.is_contiguous()):
+        raise ValueError("lokr_small_wgrad: shape mismatch")
+    _l.check(_lib().yat_lokr_small_wgrad(rows, R, N, out2d.shape[0], _p(a2d), _p(x2d), _p(out2d), int(accumulate),
+                                         _p(workspace), _stream()), "yat_lokr_small_wgrad")
+    return out2d
+
+
 def colsum(x2d, out, workspace, accumulate=False):
     """yat_colsum_bf16: out[c] (+)= sum_r x[r,c]."""
     rows, cols = x2d.shape

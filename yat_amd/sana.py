@@ -214,10 +214,9 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         def lin(x_, w_, bias_=None, out=None, **ep):
             """Linear of a (possibly adapted) target: with adapters, x delta_w^T is computed first and folded into the
             base GEMM right after its bias rounding (peft: base_layer(x) + F.linear(x, delta_w))."""
-            if ad is None:
+            tmp = ad.forward_term(x_, w_) if ad is not None else None       # None: no adapter on this weight
+            if tmp is None:
                 return ops.linear_fwd(x_, w_, bias_, out=out, **ep)
-            tmp = torch.empty(x_.shape[0], w_.shape[0], dtype=BF16, device=x_.device)
-            ops.linear_fwd(x_, ad.delta_like(w_), None, out=tmp)
             return ops.linear_fwd(x_, w_, bias_, out=out, pre_add=tmp, **ep)
 
         def params_ready(bucket, stream=main):
@@ -403,7 +402,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             """Input gradient through a (possibly adapted) target: dy W, plus dy delta_w accumulated in place."""
             r_ = ops.linear_dgrad(dy_, w_, out=out, residual=residual)
             if ad is not None:
-                ops.linear_dgrad(dy_, ad.delta_like(w_), out=r_, residual=r_)
+                ad.dgrad_term(dy_, w_, r_)
             return r_
 
         # Weight/bias gradients are off the critical path (nothing in backward reads them): they go to a second
@@ -415,6 +414,9 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
         def wgrad(dy, x, key, shape2d, bias_key=None):
             def run():
+                if ad is not None:        # frozen base: only the adapters' share (nothing at all for a non-target)
+                    ad.wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
+                    return
                 ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
                 if bias_key is not None:
                     ops.colsum(dy, G[bias_key], ws_col, accumulate=acc)
@@ -469,6 +471,9 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             big = []                                          # experiment: conv_inverted + conv_point + kv in one launch
 
             def emit(dy_, x_, gw_, bias=None, group=False):
+                if ad is not None:        # frozen base: adapter gradients only, never grouped / deferred
+                    off_chain(lambda: ad.wgrad(dy_, x_, gw_, accumulate=acc))
+                    return
                 if self.defer_wgrad or side is None:
                     deferred.append((dy_, x_, gw_))
                     return
