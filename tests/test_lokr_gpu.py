@@ -84,6 +84,21 @@ def test_lokr_small_wgrad(rows, R, N, r_out, acc):
     assert torch.equal(out, out2)                          # fixed summation order: bit-reproducible
 
 
+@pytest.mark.parametrize("rows,R,N", [(1000, 8, 56), (70000, 8, 80), (513, 16, 128), (4097, 8, 8)])
+def test_lokr_rows_products(rows, R, N):
+    """T1 = x' w2_b^T and dx' += H' w2_b of the factored path against fp64 (one bf16 rounding each, residual added after)."""
+    from yat_amd import ops
+    g = torch.Generator().manual_seed(rows + R + N)
+    x, wb = torch.randn(rows, N, generator=g).to(BF).to(DEV), (torch.randn(R, N, generator=g) * 0.3).to(BF).to(DEV)
+    t1 = ops.lokr_rows_fwd(x, wb, torch.empty(rows, R, dtype=BF, device=DEV))
+    want = (x.double() @ wb.double().T)
+    assert ((t1.double() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).all()
+    h, dx0 = (torch.randn(rows, R, generator=g) * 0.2).to(BF).to(DEV), torch.randn(rows, N, generator=g).to(BF).to(DEV)
+    dx = ops.lokr_rows_bwd(h, wb, dx0.clone())
+    want = ((h.double() @ wb.double()).float().to(BF).double() + dx0.double())
+    assert ((dx.double() - want).abs() <= 2.0 ** -7 * want.abs() + 2.0 ** -8 * (h.double().abs() @ wb.double().abs()) + 1e-6).all()
+
+
 @pytest.mark.parametrize("mode", ["factored", "dense"])
 def test_lokr_training_step_matches_oracle(mode):
     """One adapted training step (tiny SANA, non-zero w1 so the adapters matter): loss / prediction / adapter gradients

@@ -99,52 +99,132 @@ __global__ __launch_bounds__(256) void lokr_dw2_final_kernel(LokrP p, const floa
 
 // Small-output weight gradient of the factored adapter path: out[q, n] (+)= sum_row A[row, q] * X[row, n] with a few
 // (R <= 16) x (N <= 128) outputs and a million-row reduction (rows = B*N_tokens*in_m) -- far outside what a tiled GEMM is
-// for.  HBM-bound streaming pass: a wave walks rows, a lane owns two adjacent columns of X and all R accumulators for them;
-// the four waves of a workgroup meet in LDS, every workgroup leaves one fp32 partial, a second launch sums the partials in a
-// fixed order (no atomics).
+// for.  HBM-bound streaming pass; every workgroup leaves one fp32 partial, a second launch sums the partials in a fixed
+// order (no atomics).  (v1 -- a wave per row, a lane per column pair -- was latency-bound: 226-477 us per call.)
+// v2: LDS-tiled.  A workgroup stages CH rows of a [CH][R] and x [CH][N] with 16-byte loads, then every thread owns
+// (q, column pair) outputs and walks the staged rows: two LDS reads (a: 8 distinct addresses per row -> broadcast, x:
+// consecutive 4-byte words) and two FMAs per row.  Accumulators live across the workgroup's chunks; one partial per workgroup.
 template <int R>
 __global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int N, const bf16_t* A, const bf16_t* X,
                                                                float* partial) {
-    __shared__ float red[4][R][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-    const int c = 2 * lane;
-    const bool live = c < N;
-    float a0[R], a1[R];
+    constexpr int CH = 256;                                  // rows per staged chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);            // [CH][N]
+    bf16_t* as = xs + CH * N;                                // [CH][R]
+    const int NP = N >> 1;                                   // column pairs
+    constexpr int MAXO = (R * 64 + 255) / 256;               // outputs (q, pair) per thread: R * NP <= R * 64
+    float acc0[MAXO], acc1[MAXO];
+    int oq[MAXO], op[MAXO];
 #pragma unroll
-    for (int q = 0; q < R; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
-    for (int64_t r = r0 + wave; r < r1; r += 4) {
-        float av[R];
+    for (int u = 0; u < MAXO; ++u) {
+        const int o = threadIdx.x + 256 * u;
+        oq[u] = o / NP; op[u] = o - oq[u] * NP;
+        if (oq[u] >= R) { oq[u] = 0; op[u] = -1; }            // idle slot
+        acc0[u] = 0.f; acc1[u] = 0.f;
+    }
+    const int64_t nchunk = (rows + CH - 1) / CH;
+    for (int64_t ck = blockIdx.x; ck < nchunk; ck += gridDim.x) {
+        const int64_t r0 = ck * CH;
+        const int nr = (int)(rows - r0 < CH ? rows - r0 : CH);
+        __syncthreads();                                     // previous chunk fully consumed
+        const int xv = nr * N / 8, av = nr * R / 8;          // 16-byte vectors to stage
+        for (int v = threadIdx.x; v < xv; v += 256)
+            *reinterpret_cast<u32x4*>(xs + v * 8) = *reinterpret_cast<const u32x4*>(X + r0 * N + (int64_t)v * 8);
+        for (int v = threadIdx.x; v < av; v += 256)
+            *reinterpret_cast<u32x4*>(as + v * 8) = *reinterpret_cast<const u32x4*>(A + r0 * R + (int64_t)v * 8);
+        __syncthreads();
 #pragma unroll
-        for (int v = 0; v < R / 8; ++v) unpack8(*reinterpret_cast<const u32x4*>(A + r * R + v * 8), av + v * 8);
-        const uint32_t xx = live ? *reinterpret_cast<const uint32_t*>(X + r * N + c) : 0u;
-        const float x0 = __uint_as_float(xx << 16), x1 = __uint_as_float(xx & 0xffff0000u);
-#pragma unroll
-        for (int q = 0; q < R; ++q) { a0[q] += av[q] * x0; a1[q] += av[q] * x1; }
+        for (int u = 0; u < MAXO; ++u) {
+            if (op[u] < 0) continue;
+            const bf16_t* ap = as + oq[u];
+            const uint32_t* xp = reinterpret_cast<const uint32_t*>(xs) + op[u];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < nr; ++r) {
+                const float av_ = bf2f(ap[r * R]);
+                const uint32_t xx = xp[r * NP];
+                s0 += av_ * __uint_as_float(xx << 16);
+                s1 += av_ * __uint_as_float(xx & 0xffff0000u);
+            }
+            acc0[u] += s0; acc1[u] += s1;
+        }
     }
 #pragma unroll
-    for (int q = 0; q < R; ++q) { red[wave][q][c] = a0[q]; red[wave][q][c + 1] = a1[q]; }
-    __syncthreads();
-    for (int e = threadIdx.x; e < R * N; e += 256) {
-        const int q = e / N, n = e - q * N;
-        partial[(int64_t)blockIdx.x * R * N + e] = red[0][q][n] + red[1][q][n] + red[2][q][n] + red[3][q][n];
-    }
+    for (int u = 0; u < MAXO; ++u)
+        if (op[u] >= 0) {
+            float* dst = partial + (int64_t)blockIdx.x * R * N + oq[u] * N + 2 * op[u];
+            dst[0] = acc0[u]; dst[1] = acc1[u];
+        }
 }
-// out[q, n] = (accumulate ? out : 0) + sum_g partial[g][q*N + n], q < r_out.  One wave per 16 outputs: lane = (g-slice, e):
-// 4 slices of the partial list x 16 consecutive outputs (64-B runs), fixed order, then two shuffles.
+// out[q, n] = (accumulate ? out : 0) + sum_g partial[g][q*N + n], q < r_out.  One workgroup per 16 outputs: 16 slices of the
+// partial list (4 waves x 4 lane groups) x 16 consecutive outputs, fixed order, two shuffles + one LDS step.
 __global__ __launch_bounds__(256) void lokr_small_wgrad_final_kernel(int G, int RN, int n_out, const float* partial,
                                                                      bf16_t* out, int accumulate) {
+    __shared__ float red[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = (blockIdx.x * 4 + wave) * 16 + (lane & 15), slice = lane >> 4;
+    const int e = blockIdx.x * 16 + (lane & 15), slice = wave * 4 + (lane >> 4);
     float s = 0.f;
     if (e < n_out)
-        for (int g = slice; g < G; g += 4) s += partial[(int64_t)g * RN + e];
+        for (int g = slice; g < G; g += 16) s += partial[(int64_t)g * RN + e];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (e >= n_out || slice != 0) return;
+    if (lane < 16) red[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x >= 16 || e >= n_out) return;
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
     if (accumulate) s = rbf(s) + bf2f(out[e]);
     out[e] = f2bf(s);
+}
+
+// The two row-streaming products of the factored path, rows = M*in_m (a million at B = 32), N = in_n <= 128, R <= 16:
+//   FWD: t1[row, q]  = bf16( sum_n x[row, n] * wb[q, n] )                       (T1 = x' w2_b^T)
+//   BWD: dx[row, n]  = bf16( bf16( sum_q h[row, q] * wb[q, n] ) + dx[row, n] )  (dx' += H' w2_b, the GEMM's residual rounding)
+// A tiled GEMM spends a 128-wide tile on the 8 useful columns (measured 124 / 202 us per call); here w2_b sits in LDS as
+// fp32, read by broadcast, and the pass is HBM-bound (168 / 315 MB at D = 2240, B = 32).
+// LPR lanes share a row, each owning one 16-byte chunk of it (chunks past N idle): a wave's accesses are contiguous
+// 64/LPR-row runs.  FWD: 8 x R partial products per lane, butterfly over the row's lanes, lane c keeps q = c.  BWD: a lane
+// updates its own chunk, no exchange.  (v1 gave a lane a whole row: every 16-byte load of a wave touched 64 different rows;
+// 109 / 245 us per call against ~40 / ~65 us of traffic.)
+template <int R, int LPR, bool BWD>
+__global__ __launch_bounds__(256) void lokr_rows_kernel(int64_t rows, int N, const bf16_t* wb, const bf16_t* a, bf16_t* io) {
+    __shared__ float w[R][128];
+    for (int e = threadIdx.x; e < R * 128; e += 256) w[e >> 7][e & 127] = (e & 127) < N ? bf2f(wb[(e >> 7) * N + (e & 127)]) : 0.f;
+    __syncthreads();
+    constexpr int RPB = 256 / LPR;                             // rows per workgroup pass
+    const int c = threadIdx.x % LPR, n = c * 8;
+    const bool live = n < N;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; row < rows; row += (int64_t)gridDim.x * RPB) {
+        if (!BWD) {
+            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc[R];
+            if (live) unpack8(*reinterpret_cast<const u32x4*>(a + row * N + n), x);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&w[q][n]), hi = *reinterpret_cast<const f32x4*>(&w[q][n + 4]);
+                float s = x[0] * lo[0] + x[1] * lo[1] + x[2] * lo[2] + x[3] * lo[3] + x[4] * hi[0] + x[5] * hi[1] + x[6] * hi[2] +
+                          x[7] * hi[3];
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+                acc[q] = s;
+            }
+            // every lane of the row now holds all R sums; lane c < R/8 stores 8 of them as one 16-byte vector
+            if (c < R / 8) *reinterpret_cast<u32x4*>(io + row * R + c * 8) = pack8(acc + c * 8);
+        } else if (live) {
+            float h[R], o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8];
+#pragma unroll
+            for (int v = 0; v < R / 8; ++v) unpack8(*reinterpret_cast<const u32x4*>(a + row * R + v * 8), h + v * 8);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&w[q][n]), hi = *reinterpret_cast<const f32x4*>(&w[q][n + 4]);
+                o[0] += h[q] * lo[0]; o[1] += h[q] * lo[1]; o[2] += h[q] * lo[2]; o[3] += h[q] * lo[3];
+                o[4] += h[q] * hi[0]; o[5] += h[q] * hi[1]; o[6] += h[q] * hi[2]; o[7] += h[q] * hi[3];
+            }
+            bf16_t* dp = io + row * N + n;
+            unpack8(*reinterpret_cast<const u32x4*>(dp), d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) + d[e];
+            *reinterpret_cast<u32x4*>(dp) = pack8(o);
+        }
+    }
 }
 
 int fill(LokrP& p, int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2a, const void* w2b,
@@ -194,24 +274,53 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
     return YAT_OK;
 }
 
-uint64_t yat_lokr_small_wgrad_workspace_bytes(int R, int N) { return (uint64_t)1024 * R * N * sizeof(float); }
+int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, yat_stream_t stream) {
+    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 7) || !w2_b || !a || !io) return YAT_EINVAL;
+    const int lpr = N <= 64 ? 8 : 16;
+    int64_t g64 = (rows + 256 / lpr - 1) / (256 / lpr);
+    const dim3 grid((unsigned)(g64 > 4096 ? 4096 : g64)), block(256);
+    const bf16_t* wb = (const bf16_t*)w2_b;
+    const bf16_t* ap = (const bf16_t*)a;
+    bf16_t* iop = (bf16_t*)io;
+    hipStream_t st = (hipStream_t)stream;
+#define YAT_ROWS(RR, LL, BB) hipLaunchKernelGGL((lokr_rows_kernel<RR, LL, BB>), grid, block, 0, st, rows, N, wb, ap, iop)
+    if (R == 8 && lpr == 8) { if (backward) YAT_ROWS(8, 8, true); else YAT_ROWS(8, 8, false); }
+    else if (R == 8) { if (backward) YAT_ROWS(8, 16, true); else YAT_ROWS(8, 16, false); }
+    else if (lpr == 8) { if (backward) YAT_ROWS(16, 8, true); else YAT_ROWS(16, 8, false); }
+    else { if (backward) YAT_ROWS(16, 16, true); else YAT_ROWS(16, 16, false); }
+#undef YAT_ROWS
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+uint64_t yat_lokr_small_wgrad_workspace_bytes(int R, int N) { return (uint64_t)512 * R * N * sizeof(float); }
 
 int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, void* out, int accumulate,
                          void* workspace, yat_stream_t stream) {
-    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 1) || r_out <= 0 || r_out > R || !a || !x || !out ||
+    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 7) || r_out <= 0 || r_out > R || !a || !x || !out ||
         !workspace)
         return YAT_EINVAL;
-    int64_t g64 = (rows + 255) / 256;
-    const int G = (int)(g64 > 512 ? 512 : g64);          // two workgroups per CU; every extra partial lengthens the final pass
+    const int64_t nchunk = (rows + 255) / 256;
+    const int G = (int)(nchunk > 512 ? 512 : nchunk);
+    const int lds = 256 * (N + R) * 2;                       // <= 72 KiB (N = 128, R = 16)
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)lokr_small_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void*)lokr_small_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) !=
+                hipSuccess)
+            return YAT_EINVAL;
+        attr_set = true;
+    }
     if (R == 8)
-        hipLaunchKernelGGL((lokr_small_wgrad_kernel<8>), dim3(G), dim3(256), 0, (hipStream_t)stream, rows, N, (const bf16_t*)a,
+        hipLaunchKernelGGL((lokr_small_wgrad_kernel<8>), dim3(G), dim3(256), lds, (hipStream_t)stream, rows, N, (const bf16_t*)a,
                            (const bf16_t*)x, (float*)workspace);
     else
-        hipLaunchKernelGGL((lokr_small_wgrad_kernel<16>), dim3(G), dim3(256), 0, (hipStream_t)stream, rows, N, (const bf16_t*)a,
+        hipLaunchKernelGGL((lokr_small_wgrad_kernel<16>), dim3(G), dim3(256), lds, (hipStream_t)stream, rows, N, (const bf16_t*)a,
                            (const bf16_t*)x, (float*)workspace);
     YAT_CHECK_LAUNCH();
     const int n_out = r_out * N;
-    hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, R * N,
+    hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 15) / 16), dim3(256), 0, (hipStream_t)stream, G, R * N,
                        n_out, (const float*)workspace, (bf16_t*)out, accumulate);
     YAT_CHECK_LAUNCH();
     return YAT_OK;

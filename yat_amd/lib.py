@@ -64,6 +64,7 @@ SIGNATURES = {
     "yat_pad_mask": (I, [I, I, I, P, P, P, P, P, P, P]),
     "yat_flow_mix": (I, [I, I64, P, P, P, P, P, P]),
     "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
+    "yat_lokr_rows": (I, [I64, I, I, I, P, P, P, P]),
     "yat_lokr_small_wgrad_workspace_bytes": (U64, [I, I]),
     "yat_lokr_small_wgrad": (I, [I64, I, I, I, P, P, P, I, P, P]),
     "yat_patch_rearrange": (I, [I, I, I, I, I, I, I, P, P, P]),

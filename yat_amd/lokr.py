@@ -180,8 +180,7 @@ class LoKrAdapters:
                 ops.gemm(x, d, blk, M=M, N=e["out"], K=e["inn"], ldc=rows)
             else:
                 im, n_ = e["in_m"], e["in_n"]
-                t1 = torch.empty(M * im, R, dtype=BF16, device=x.device)
-                ops.gemm(x.view(M * im, n_), self._w2(e)[1], t1, M=M * im, N=R, K=n_)
+                t1 = ops.lokr_rows_fwd(x.view(M * im, n_), self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
                 ops.gemm(t1.view(M, im * R), e["P"], blk, M=M, N=e["out"], K=im * R, ldc=rows)
         return tmp
 
@@ -205,8 +204,7 @@ class LoKrAdapters:
             im, n_ = e["in_m"], e["in_n"]
             h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
             ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
-            dx2 = dx.view(M * im, n_)
-            ops.gemm(h.view(M * im, R), self._w2(e)[1], dx2, b_t=True, M=M * im, N=n_, K=R, lda=R, ldb=n_, ldc=n_, residual=dx2)
+            ops.lokr_rows_bwd(h.view(M * im, R), self._w2(e)[1], dx.view(M * im, n_))
 
     def wgrad(self, dy, x, gw, accumulate=False):
         """Adapter-side weight gradient of the target(s) behind the gradient view ``gw``: dense entries get d_delta_w in
@@ -224,8 +222,7 @@ class LoKrAdapters:
                 continue
             im, n_ = e["in_m"], e["in_n"]
             x2 = x.view(M * im, n_)
-            t1 = torch.empty(M * im, R, dtype=BF16, device=x.device)
-            ops.gemm(x2, self._w2(e)[1], t1, M=M * im, N=R, K=n_)
+            t1 = ops.lokr_rows_fwd(x2, self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
             ops.gemm(dyb, t1.view(M, im * R), e["dP"], a_t=True, b_t=True, M=e["out"], N=im * R, K=M, lda=ld, ldb=im * R,
                      ldc=im * R, residual=e["dP"] if accumulate else None)
             h = torch.empty(M, im * R, dtype=BF16, device=dy.device)

@@ -178,6 +178,28 @@ def lokr_project(w1, w2a, w2b, scale, d_delta2d, dw1, dw2a, dw2b, workspace):
     _l.check(rc, "yat_lokr_project")
 
 
+def lokr_rows_fwd(x2d, wb, t1):
+    """t1[rows, R] = x2d[rows, N] wb^T (wb [R, N]) -- the T1 product of the factored LoKr path."""
+    _chk_bf16(x2d, wb, t1)
+    rows, N = x2d.shape
+    R = wb.shape[0]
+    if wb.shape[1] != N or t1.shape != (rows, R) or not (x2d.is_contiguous() and wb.is_contiguous() and t1.is_contiguous()):
+        raise ValueError("lokr_rows_fwd: shape mismatch")
+    _l.check(_lib().yat_lokr_rows(rows, N, R, 0, _p(wb), _p(x2d), _p(t1), _stream()), "yat_lokr_rows")
+    return t1
+
+
+def lokr_rows_bwd(h2d, wb, dx2d):
+    """dx2d[rows, N] += h2d[rows, R] wb (product rounded to bf16 first, like a GEMM's residual epilogue)."""
+    _chk_bf16(h2d, wb, dx2d)
+    rows, R = h2d.shape
+    N = wb.shape[1]
+    if wb.shape[0] != R or dx2d.shape != (rows, N) or not (h2d.is_contiguous() and wb.is_contiguous() and dx2d.is_contiguous()):
+        raise ValueError("lokr_rows_bwd: shape mismatch")
+    _l.check(_lib().yat_lokr_rows(rows, N, R, 1, _p(wb), _p(h2d), _p(dx2d), _stream()), "yat_lokr_rows")
+    return dx2d
+
+
 def lokr_small_wgrad(a2d, x2d, out2d, workspace, accumulate=False):
     """out[q, n] (+)= sum_row a[row, q] * x[row, n], q < out.shape[0] (include/yat_hip.h: yat_lokr_small_wgrad)."""
     _chk_bf16(a2d, x2d, out2d)
