@@ -182,16 +182,21 @@ class LoKrAdapters:
                 im, n_ = e["in_m"], e["in_n"]
                 t1 = ops.lokr_rows_fwd(x.view(M * im, n_), self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
                 ops.gemm(t1.view(M, im * R), e["P"], blk, M=M, N=e["out"], K=im * R, ldc=rows)
+                # kept for the weight gradient (same x): the reference lives until the next forward replaces it, i.e.
+                # past every stream that reads it in the backward (which the main stream joins before the optimizer)
+                e["t1"] = (x.data_ptr(), t1)
         return tmp
 
     def dgrad_term(self, dy, w, dx):
-        """dx += dy delta_w for the target view ``w`` (dy [M, rows(w)], dx [M, in] contiguous)."""
+        """dx += dy delta_w for the target view ``w`` (dy [M, rows(w)], dx [M, in] contiguous).  Returns {id(entry): H}
+        with H = dy_block P of every factored entry -- the weight gradient of the same dy needs it too."""
+        hs = {}
         ents = self.lookup(w, self.model.flat_param)
         if not ents:
-            return
+            return hs
         if all(not e["factored"] for e, _ in ents):
             ops.linear_dgrad(dy, self.delta_like(w), out=dx, residual=dx)
-            return
+            return hs
         M, R, ld = dy.shape[0], self.R, dy.stride(0)
         for e, row0 in ents:
             if not e["active"]:
@@ -205,11 +210,14 @@ class LoKrAdapters:
             h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
             ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
             ops.lokr_rows_bwd(h.view(M * im, R), self._w2(e)[1], dx.view(M * im, n_))
+            hs[id(e)] = h
+        return hs
 
-    def wgrad(self, dy, x, gw, accumulate=False):
+    def wgrad(self, dy, x, gw, accumulate=False, hs=None):
         """Adapter-side weight gradient of the target(s) behind the gradient view ``gw``: dense entries get d_delta_w in
         their flat-gradient slot (as before), factored ones d_P and d_w2_b; a non-target weight (frozen, no adapter) gets
-        nothing.  dy [M, rows(gw)] (row stride allowed), x [M, in] contiguous."""
+        nothing.  dy [M, rows(gw)] (row stride allowed), x [M, in] contiguous; ``hs``: the H products ``dgrad_term`` already
+        made for this dy."""
         M, R, ld = dy.shape[0], self.R, dy.stride(0)
         for e, row0 in self.lookup(gw, self.model.flat_grad):
             if not e["active"]:
@@ -222,11 +230,19 @@ class LoKrAdapters:
                 continue
             im, n_ = e["in_m"], e["in_n"]
             x2 = x.view(M * im, n_)
-            t1 = ops.lokr_rows_fwd(x2, self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
+            kept = e.get("t1")
+            if kept is not None and kept[0] == x.data_ptr() and kept[1].shape[0] == M * im:
+                t1 = kept[1]                                 # T1 of this very x, computed by the forward
+            else:
+                t1 = ops.lokr_rows_fwd(x2, self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
             ops.gemm(dyb, t1.view(M, im * R), e["dP"], a_t=True, b_t=True, M=e["out"], N=im * R, K=M, lda=ld, ldb=im * R,
                      ldc=im * R, residual=e["dP"] if accumulate else None)
-            h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
-            ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
+            h = hs.get(id(e)) if hs else None
+            if h is None:
+                h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
+                ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
+            else:
+                h.record_stream(torch.cuda.current_stream())     # produced on the chain's stream, read on this one
             _, _, gb = self._views(e, self.flat_grad)
             ops.lokr_small_wgrad(h.view(M * im, R), x2, gb, self._sw_ws, accumulate=accumulate)
 

@@ -355,7 +355,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             ops.linear_fwd(S.hf[rs], P["proj_out.weight"], P["proj_out.bias"], out=out_tok[rs])
             ops.transpose(out_tok[rs].view(nb, N, Cout), pred[bs])
 
-        nchain = max(1, min(self.fwd_chains, B))
+        # (with adapters: one chain, so that the T1 product of every target covers the whole batch and the backward reuses it)
+        nchain = 1 if ad is not None else max(1, min(self.fwd_chains, B))
         if nchain == 1:
             run_chain(0, B, main)
         else:
@@ -402,8 +403,22 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             """Input gradient through a (possibly adapted) target: dy W, plus dy delta_w accumulated in place."""
             r_ = ops.linear_dgrad(dy_, w_, out=out, residual=residual)
             if ad is not None:
-                ad.dgrad_term(dy_, w_, r_)
+                flush_adapter_wgrads(dy_, ad.dgrad_term(dy_, w_, r_))
             return r_
+
+        # With adapters the weight gradient of a target needs H = dy P, which the input gradient of the same dy computes
+        # anyway: emit() only queues (dy, x, dW); the dgrad() that follows launches the queued item with its H.
+        pending_ad = []
+
+        def flush_adapter_wgrads(dy_=None, hs=None):
+            keep = []
+            for item in pending_ad:
+                if dy_ is None or item[0].data_ptr() == dy_.data_ptr():
+                    run_off_chain(lambda item=item, hs=(hs if dy_ is not None else None):
+                                  ad.wgrad(*item, accumulate=acc, hs=hs))
+                else:
+                    keep.append(item)
+            pending_ad[:] = keep
 
         # Weight/bias gradients are off the critical path (nothing in backward reads them): they go to a second
         # stream so their blocks fill the CUs the single-round dgrad launches leave idle, and their prologue/epilogue
@@ -411,6 +426,14 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         # embedders) or alternate between two sets by block parity (transformer blocks, below).
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
+
+        def run_off_chain(fn):
+            if side is None:
+                fn()
+                return
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
 
         def wgrad(dy, x, key, shape2d, bias_key=None):
             def run():
@@ -471,8 +494,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             big = []                                          # experiment: conv_inverted + conv_point + kv in one launch
 
             def emit(dy_, x_, gw_, bias=None, group=False):
-                if ad is not None:        # frozen base: adapter gradients only, never grouped / deferred
-                    off_chain(lambda: ad.wgrad(dy_, x_, gw_, accumulate=acc))
+                if ad is not None:        # frozen base: adapter gradients only, launched by the dgrad() of the same dy
+                    pending_ad.append((dy_, x_, gw_))
                     return
                 if self.defer_wgrad or side is None:
                     deferred.append((dy_, x_, gw_))
@@ -592,6 +615,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
                 dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
 
+            if ad is not None:
+                flush_adapter_wgrads()        # anything queued whose dy had no dgrad() (none today; keeps the queue per block)
             if side is None:
                 block_grads()
                 if self.grad_ready is not None:
