@@ -252,7 +252,8 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         variant = 1;
         // (N >= 256: one 256/320-wide column tile is fine when K is long enough to split -- the [out, in_m*r] weight
         //  gradients of the factored LoKr path are 2240 x 320 x 32768: 9 tiles, split 28 ways)
-        if (M >= 1024 && (N >= 512 || (N >= 256 && K >= 8192)) && K >= 256) {
+        static const int min_n256 = getenv("YAT_GEMM_MIN_N256") ? atoi(getenv("YAT_GEMM_MIN_N256")) : 256;
+        if (M >= 1024 && (N >= 512 || (N >= min_n256 && K >= 2048) || (N >= 256 && K >= 8192)) && K >= 256) {
             double best = est_time_128(M, N, K);
             for (int v = 4; v <= 5; ++v)
                 for (int s = 1; s <= max_ksplit; s = pow2_only ? s * 2 : s + 1) {
