@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--lokr", type=int, default=0, metavar="RANK",
                     help="BASELINE config 5 instead of config 2: LoKr adapters of this rank on the README target modules "
                          "(alpha = rank, module dropout 0.05), frozen base; not the headline line")
+    ap.add_argument("--lora", type=int, default=0, metavar="RANK",
+                    help="plain LoRA adapters (lora_algo: lora) of this rank on the README target modules, alpha = rank; "
+                         "not the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
@@ -174,6 +177,11 @@ def main():
         trained = LoKrAdapters(model, ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2",
                                        "proj"], r=args.lokr, alpha=float(args.lokr), module_dropout=0.05)
         log(f"LoKr rank {args.lokr}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
+    elif args.lora:
+        from yat_amd.lora import LoRAAdapters
+        trained = LoRAAdapters(model, ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2",
+                                       "proj"], r=args.lora, alpha=float(args.lora))
+        log(f"LoRA rank {args.lora}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
     opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
                     overlap_update=os.environ.get("YAT_OVERLAP_ADAMW", "1") != "0")
     ddp = HipDDP(trained, force=force_ddp) if (world > 1 or force_ddp) else None
@@ -292,6 +300,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("train_sana.py: SANA-1.6B (D=2240, 20 blocks) 1024px, bf16, "
                                     + (f"LoKr rank {args.lokr} adapters on a frozen base (BASELINE config 5), " if args.lokr
+                                       else f"LoRA rank {args.lora} adapters on a frozen base, " if args.lora
                                        else "full fine-tune, ") +
                                     f"cached latents/text embeds, aspect buckets {BUCKETS} round-robin, T=512, AdamW+clip"),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",

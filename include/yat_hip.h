@@ -204,14 +204,15 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
  *   T1 = x' w2_b^T            (yat_gemm_bf16, N = r)        P = kron(w1, w2_a) * scale  [out, in_m*r]  (yat_lokr_delta with
  *   adapter(x) = T1_flat P^T  (yat_gemm_bf16, K = in_m*r)       w2_b := identity)
  *   dx += (dy P)' w2_b,  d_P = dy^T T1_flat (then yat_lokr_project -> d_w1, d_w2_a),  d_w2_b = (dy P)'^T x'
- * -- the last one has r x in_n outputs and a rows-long reduction: out[q, n] (+)= sum_row a[row, q] * x[row, n], q < r_out.
- * a: bf16 [rows, R] (R = 8 or 16), x: bf16 [rows, N] (N <= 128, N % 8 == 0), out: bf16 [r_out, N]. */
+ * -- the last one has r x in_n outputs and a rows-long reduction: out[q, n] (+)= bf16(scale * sum_row a[row, q] * x[row, n]),
+ * q < r_out.  a: bf16 [rows, R] (R = 8 or 16), x: bf16 [rows, N] with row stride ldx (N % 8 == 0; column blocks of 128 are
+ * separate workgroups, so N may be a whole layer width: the d_A / d_B of a plain LoRA adapter), out: bf16 [r_out, ldo]. */
 /* the two row-streaming products of that path: backward=0: io[rows, R] = a[rows, N] w2_b^T;
  * backward=1: io[rows, N] = bf16(bf16(a[rows, R] w2_b) + io)   (w2_b: bf16 [R, N], R = 8 or 16, N <= 128, N % 8 == 0) */
 int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, yat_stream_t stream);
-uint64_t yat_lokr_small_wgrad_workspace_bytes(int R, int N);
-int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, void* out, int accumulate,
-                         void* workspace, yat_stream_t stream);
+uint64_t yat_lokr_small_wgrad_workspace_bytes(int64_t rows, int R, int N);
+int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, int ldx, void* out, int ldo,
+                         float scale, int accumulate, void* workspace, yat_stream_t stream);
 
 /* elementwise helpers: y = act(x) and dx = dy * act'(x) on bf16 (time-embed / caption MLPs);
  * act: 1 SiLU, 2 GELU(tanh).  add: out = bf16(a + b).  f32->bf16 convert. */

@@ -63,7 +63,7 @@ def test_lokr_kernels_bit_exact(out_dim, in_dim, scale):
 
 
 @pytest.mark.parametrize("rows,R,N,r_out,acc", [(1000, 8, 56, 8, False), (4096 * 40, 8, 56, 8, True), (777, 16, 128, 12, False),
-                                                (5000, 8, 8, 2, True)])
+                                                (5000, 8, 8, 2, True), (3000, 8, 2240, 4, False), (2049, 16, 328, 16, True)])
 def test_lokr_small_wgrad(rows, R, N, r_out, acc):
     """out[q, n] (+)= sum_row a[row, q] x[row, n]: the r x in_n weight gradient of the factored path (d_w2_b)."""
     from yat_amd import ops
@@ -71,7 +71,7 @@ def test_lokr_small_wgrad(rows, R, N, r_out, acc):
     a, x = (torch.randn(rows, R, generator=g) * 0.1).to(BF).to(DEV), torch.randn(rows, N, generator=g).to(BF).to(DEV)
     out0 = (torch.randn(r_out, N, generator=g) * 0.5).to(BF).to(DEV)
     out = out0.clone()
-    ws = torch.empty(int(ops._lib().yat_lokr_small_wgrad_workspace_bytes(R, N)), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(int(ops._lib().yat_lokr_small_wgrad_workspace_bytes(rows, R, N)), dtype=torch.uint8, device=DEV)
     ops.lokr_small_wgrad(a, x, out, ws, accumulate=acc)
     want = (a.double().T @ x.double())[:r_out]
     if acc:

@@ -1,0 +1,100 @@
+"""Plain LoRA adapters (``lora_algo: lora``) on the HIP path against the oracle's restatement of the peft wrap -- GPU.
+peft is absent from the container: the adapter arithmetic is [RECALL] on both sides (parity unpinned, oracle/lora_ref.py)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda"
+TARGETS = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("r,alpha", [(4, 4.0), (8, 16.0)])
+def test_lora_training_step_matches_oracle(r, alpha, tmp_path):
+    """One adapted training step (tiny SANA, non-zero lora_B so the adapters matter): loss / prediction / adapter gradients vs
+    the oracle's bf16 and fp32 runs of the peft-wrapped model; the optimizer moves only the adapters; peft-layout round trip."""
+    from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
+    from oracle.lora_ref import apply_lora, LoRAWrapped
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.lora import LoRAAdapters
+    from yat_amd.optim import FlatAdamW
+    rcfg = RefCfg.tiny(num_layers=2)
+    ref = SanaTransformerRef(rcfg)
+    init_like_pretrained(ref, 0)
+    ref_bf = copy.deepcopy(ref).to(BF)
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV)
+    hip.load_state_dict(ref_bf.state_dict())
+    ad = LoRAAdapters(hip, TARGETS, r=r, alpha=alpha)
+    g = torch.Generator().manual_seed(11)
+    for e in ad.entries:                                    # meaningful adapters: lora_B away from its zero init
+        _, bt = ad._views(e, ad.flat_param)
+        bt[:r].copy_((torch.randn(r, e["out"], generator=g) * 0.05).to(BF))
+    wrapped = apply_lora(ref_bf, TARGETS, r=r, alpha=alpha)
+    assert sorted(wrapped) == sorted(e["module"] for e in ad.entries)
+    sd = ad.state_dict()
+    for name, w in wrapped.items():
+        pre = f"base_model.model.{name}."
+        with torch.no_grad():
+            w.lora_A.copy_(sd[pre + "lora_A.weight"].cpu())
+            w.lora_B.copy_(sd[pre + "lora_B.weight"].cpu())
+    ref_32 = copy.deepcopy(ref_bf).float()
+    B, h, w_ = 2, 6, 10
+    latents = (torch.randn(B, rcfg.in_channels, h, w_, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (9, 30)]
+    outs = {}
+    for tag, model, dt in (("bf16", ref_bf, BF), ("fp32", ref_32, torch.float32)):
+        model.train()
+        loss, pred, _ = optimize_ref(model, RefSched(), latents, embs, torch.Generator().manual_seed(3), pad_to=32, dtype=dt)
+        loss.backward()
+        outs[tag] = (loss.detach(), pred.detach(), {n: (m.lora_A.grad, m.lora_B.grad) for n, m in model.named_modules()
+                                                   if isinstance(m, LoRAWrapped)})
+    recipe = SanaRecipe(hip, pad_to=32, device=DEV)
+    hip.train()
+    loss, pred, _ = recipe.optimize(latents, embs, torch.Generator().manual_seed(3), return_pred=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    l32, lbf, lh = float(outs["fp32"][0]), float(outs["bf16"][0]), float(loss.detach())
+    print(f"[parity] lora r={r} loss hip={lh:.6f} oracle_bf16={lbf:.6f} fp32={l32:.6f}")
+    assert abs(lh - l32) <= 1.3 * abs(lbf - l32) + 2e-3 * abs(l32)
+    e_h, e_r = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
+    print(f"[parity] lora pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
+    assert e_h <= 1.3 * e_r + 1e-3
+    hip_g, bf_g, f_g = [], [], []
+    for e in ad.entries:
+        ga, gbt = ad._views(e, ad.flat_grad)
+        assert ga[r:].abs().sum().item() == 0 and gbt[r:].abs().sum().item() == 0          # rank padding stays untouched
+        hip_g += [ga[:r].float().flatten().cpu(), gbt[:r].t().float().flatten().cpu()]
+        bf_g += [t.float().flatten() for t in outs["bf16"][2][e["module"]]]
+        f_g += [t.float().flatten() for t in outs["fp32"][2][e["module"]]]
+    hg, bg, fg = torch.cat(hip_g), torch.cat(bf_g), torch.cat(f_g)
+    e_h, e_r = rel(hg, fg), rel(bg, fg)
+    print(f"[parity] lora adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
+    assert torch.isfinite(hg).all() and fg.abs().max() > 0
+    assert e_h <= 1.3 * e_r + 2e-3
+    before = hip.flat_param.clone()
+    opt = FlatAdamW(ad, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    p0 = ad.flat_param.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(before, hip.flat_param) and not torch.equal(p0, ad.flat_param)
+    for e in ad.entries:                                    # the padded rank rows never move
+        a, bt = ad._views(e, ad.flat_param)
+        assert a[r:].abs().sum().item() == 0 and bt[r:].abs().sum().item() == 0
+    ad.save_pretrained(str(tmp_path / "a"))
+    from safetensors.torch import load_file
+    saved = load_file(str(tmp_path / "a" / "adapter_model.safetensors"))
+    again = LoRAAdapters(hip, TARGETS, r=r, alpha=alpha)
+    again.load_state_dict(saved)
+    assert torch.equal(again.flat_param, ad.flat_param)
+    k0 = f"base_model.model.{ad.entries[0]['module']}."
+    assert saved[k0 + "lora_A.weight"].shape == (r, ad.entries[0]["inn"]) and saved[k0 + "lora_B.weight"].shape == (ad.entries[0]["out"], r)

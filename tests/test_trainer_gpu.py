@@ -109,9 +109,10 @@ def test_overfits_a_fixed_batch():
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
 
 
-def test_trainer_lokr_config(tmp_path, monkeypatch):
-    """BASELINE config 5 plumbing end to end on a tiny model: lora_* YAML keys -> LoKr adapters on the README target modules,
-    frozen base, AdamW over the adapter set only, peft-layout adapter checkpoint."""
+@pytest.mark.parametrize("algo", ["lokr", "lora"])
+def test_trainer_lokr_config(tmp_path, monkeypatch, algo):
+    """BASELINE config 5 plumbing end to end on a tiny model: lora_* YAML keys -> LoKr (or plain LoRA) adapters on the README
+    target modules, frozen base, AdamW over the adapter set only, peft-layout adapter checkpoint."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from safetensors.torch import load_file
     from train_sana import SanaModel
@@ -126,7 +127,7 @@ def test_trainer_lokr_config(tmp_path, monkeypatch):
     yaml_path.write_text("\n".join([
         "urls:", "  - unused", "local_shard_paths:", *[f"  - {p}" for p in paths], "num_shards: 2", "dataset_seed: 7",
         "batch_size: 4", "learning_rate: 1e-3", "steps: 4", "num_steps_per_validation: 2", "validation_prompts:", "  - x",
-        "bfloat16: true", "lora_rank: 2", "lora_alpha: 2", "lora_algo: lokr", "lora_dropout: 0.05",
+        "bfloat16: true", "lora_rank: 2", "lora_alpha: 2", f"lora_algo: {algo}", *(["lora_dropout: 0.05"] if algo == "lokr" else []),
         "lora_target_modules:", *[f"  - {t}" for t in targets], "aspect_ratio: 1024", ""]))
     monkeypatch.chdir(tmp_path)
     params = TrainingParameters()
@@ -142,7 +143,13 @@ def test_trainer_lokr_config(tmp_path, monkeypatch):
     ck = tmp_path / "models" / saved[-1]
     sd = load_file(str(ck / "adapter_model.safetensors"))
     conf = json.loads((ck / "adapter_config.json").read_text())
-    assert conf["peft_type"] == "LOKR" and conf["r"] == 2 and conf["target_modules"] == targets
+    assert conf["r"] == 2 and conf["target_modules"] == targets
+    if algo == "lora":
+        assert conf["peft_type"] == "LORA" and len(sd) == 2 * len(trainer.adapters.entries)
+        assert sd["base_model.model.transformer_blocks.1.attn2.to_out.0.lora_B.weight"].shape == (128, 2)
+        assert any(v.abs().max() > 0 for k, v in sd.items() if k.endswith("lora_B.weight")), "lora_B never left its zero init"
+        return
+    assert conf["peft_type"] == "LOKR"
     assert "base_model.model.transformer_blocks.1.attn2.to_out.0.lokr_w1" in sd
     assert "base_model.model.patch_embed.proj.lokr_w2_a" in sd and len(sd) == 3 * len(trainer.adapters.entries)
     assert any(v.abs().max() > 0 for k, v in sd.items() if k.endswith("lokr_w1")), "w1 never left its zero init"

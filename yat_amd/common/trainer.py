@@ -206,13 +206,21 @@ class Model:
             self.sampler = self.make_sampler()
         self.adapters = None
         if getattr(p, "lora_rank", None) is not None:                 # :212-241 (get_peft_model)
-            if getattr(p, "lora_algo", "lora") != "lokr":
-                raise NotImplementedError("only lora_algo: lokr (BASELINE config 5) is built; lora / loha / fourierft are not")
+            algo = getattr(p, "lora_algo", "lora")
+            if algo not in ("lokr", "lora"):
+                raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 -- and lora are)")
             if getattr(p, "lora_pretrained", None):
                 raise NotImplementedError("resuming from a saved adapter (lora_pretrained) is not built")
-            from ..lokr import LoKrAdapters
-            self.adapters = LoKrAdapters(self.model, p.lora_target_modules, p.lora_rank, p.lora_alpha,
-                                         module_dropout=getattr(p, "lora_dropout", 0.0) or 0.0)
+            if algo == "lora":                                        # :214-219
+                if getattr(p, "lora_use_dora", False) or getattr(p, "lora_use_rslora", False):
+                    raise NotImplementedError("DoRA / rsLoRA are not built")
+                from ..lora import LoRAAdapters
+                self.adapters = LoRAAdapters(self.model, p.lora_target_modules, p.lora_rank, p.lora_alpha,
+                                             dropout=getattr(p, "lora_dropout", 0.0) or 0.0)
+            else:                                                     # :226-230
+                from ..lokr import LoKrAdapters
+                self.adapters = LoKrAdapters(self.model, p.lora_target_modules, p.lora_rank, p.lora_alpha,
+                                             module_dropout=getattr(p, "lora_dropout", 0.0) or 0.0)
             n_ad = self.adapters.num_parameters()
             print(f"trainable params: {n_ad:,} || all params: {self.model.numel_flat + n_ad:,} || "
                   f"trainable%: {100.0 * n_ad / (self.model.numel_flat + n_ad):.4f}")       # print_trainable_parameters (:239)

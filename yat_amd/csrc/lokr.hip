@@ -105,13 +105,15 @@ __global__ __launch_bounds__(256) void lokr_dw2_final_kernel(LokrP p, const floa
 // (q, column pair) outputs and walks the staged rows: two LDS reads (a: 8 distinct addresses per row -> broadcast, x:
 // consecutive 4-byte words) and two FMAs per row.  Accumulators live across the workgroup's chunks; one partial per workgroup.
 template <int R>
-__global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int N, const bf16_t* A, const bf16_t* X,
-                                                               float* partial) {
+__global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int N, int ldx, int npad, const bf16_t* A,
+                                                               const bf16_t* X, float* partial) {
     constexpr int CH = 256;                                  // rows per staged chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);            // [CH][N]
-    bf16_t* as = xs + CH * N;                                // [CH][R]
-    const int NP = N >> 1;                                   // column pairs
+    const int n0 = blockIdx.y * 128;                         // column block of x (LoRA: N = out / in, up to 11200)
+    const int Nb = N - n0 < 128 ? N - n0 : 128;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);            // [CH][Nb]
+    bf16_t* as = xs + CH * 128;                              // [CH][R]
+    const int NP = Nb >> 1, VPR = Nb >> 3;                   // column pairs / 16-byte vectors per row
     constexpr int MAXO = (R * 64 + 255) / 256;               // outputs (q, pair) per thread: R * NP <= R * 64
     float acc0[MAXO], acc1[MAXO];
     int oq[MAXO], op[MAXO];
@@ -127,10 +129,11 @@ __global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int
         const int64_t r0 = ck * CH;
         const int nr = (int)(rows - r0 < CH ? rows - r0 : CH);
         __syncthreads();                                     // previous chunk fully consumed
-        const int xv = nr * N / 8, av = nr * R / 8;          // 16-byte vectors to stage
-        for (int v = threadIdx.x; v < xv; v += 256)
-            *reinterpret_cast<u32x4*>(xs + v * 8) = *reinterpret_cast<const u32x4*>(X + r0 * N + (int64_t)v * 8);
-        for (int v = threadIdx.x; v < av; v += 256)
+        for (int v = threadIdx.x; v < nr * VPR; v += 256) {
+            const int r = v / VPR, c = v - r * VPR;
+            *reinterpret_cast<u32x4*>(xs + r * Nb + c * 8) = *reinterpret_cast<const u32x4*>(X + (r0 + r) * ldx + n0 + c * 8);
+        }
+        for (int v = threadIdx.x; v < nr * R / 8; v += 256)
             *reinterpret_cast<u32x4*>(as + v * 8) = *reinterpret_cast<const u32x4*>(A + r0 * R + (int64_t)v * 8);
         __syncthreads();
 #pragma unroll
@@ -152,28 +155,31 @@ __global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int
 #pragma unroll
     for (int u = 0; u < MAXO; ++u)
         if (op[u] >= 0) {
-            float* dst = partial + (int64_t)blockIdx.x * R * N + oq[u] * N + 2 * op[u];
+            float* dst = partial + ((int64_t)blockIdx.x * R + oq[u]) * npad + n0 + 2 * op[u];
             dst[0] = acc0[u]; dst[1] = acc1[u];
         }
 }
-// out[q, n] = (accumulate ? out : 0) + sum_g partial[g][q*N + n], q < r_out.  One workgroup per 16 outputs: 16 slices of the
-// partial list (4 waves x 4 lane groups) x 16 consecutive outputs, fixed order, two shuffles + one LDS step.
-__global__ __launch_bounds__(256) void lokr_small_wgrad_final_kernel(int G, int RN, int n_out, const float* partial,
-                                                                     bf16_t* out, int accumulate) {
+// out[q, n] = (accumulate ? out : 0) + bf16(scale * sum_g partial[g][q][n]), q < r_out.  One workgroup per 16 outputs: 16
+// slices of the partial list (4 waves x 4 lane groups) x 16 consecutive outputs, fixed order, two shuffles + one LDS step.
+__global__ __launch_bounds__(256) void lokr_small_wgrad_final_kernel(int G, int R, int N, int npad, int r_out, float scale,
+                                                                     const float* partial, bf16_t* out, int ldo,
+                                                                     int accumulate) {
     __shared__ float red[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 16 + (lane & 15), slice = wave * 4 + (lane >> 4);
+    const int q = e / N, n = e - q * N;
     float s = 0.f;
-    if (e < n_out)
-        for (int g = slice; g < G; g += 16) s += partial[(int64_t)g * RN + e];
+    if (q < r_out)
+        for (int g = slice; g < G; g += 16) s += partial[((int64_t)g * R + q) * npad + n];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     if (lane < 16) red[wave][lane] = s;
     __syncthreads();
-    if (threadIdx.x >= 16 || e >= n_out) return;
-    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    if (accumulate) s = rbf(s) + bf2f(out[e]);
-    out[e] = f2bf(s);
+    if (threadIdx.x >= 16 || q >= r_out) return;
+    s = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale;
+    bf16_t* o = out + (int64_t)q * ldo + n;
+    if (accumulate) s = rbf(s) + bf2f(*o);
+    *o = f2bf(s);
 }
 
 // The two row-streaming products of the factored path, rows = M*in_m (a million at B = 32), N = in_n <= 128, R <= 16:
@@ -293,16 +299,26 @@ int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, co
     return YAT_OK;
 }
 
-uint64_t yat_lokr_small_wgrad_workspace_bytes(int R, int N) { return (uint64_t)512 * R * N * sizeof(float); }
-
-int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, void* out, int accumulate,
-                         void* workspace, yat_stream_t stream) {
-    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 7) || r_out <= 0 || r_out > R || !a || !x || !out ||
-        !workspace)
-        return YAT_EINVAL;
+static int small_wgrad_groups(int64_t rows, int nblk) {
     const int64_t nchunk = (rows + 255) / 256;
-    const int G = (int)(nchunk > 512 ? 512 : nchunk);
-    const int lds = 256 * (N + R) * 2;                       // <= 72 KiB (N = 128, R = 16)
+    int64_t g = 512 / nblk;                                  // ~two workgroups per CU over all column blocks
+    if (g < 32) g = 32;
+    return (int)(nchunk < g ? nchunk : g);
+}
+
+uint64_t yat_lokr_small_wgrad_workspace_bytes(int64_t rows, int R, int N) {
+    const int nblk = (N + 127) / 128;
+    return (uint64_t)small_wgrad_groups(rows, nblk) * R * nblk * 128 * sizeof(float);
+}
+
+int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, int ldx, void* out, int ldo,
+                         float scale, int accumulate, void* workspace, yat_stream_t stream) {
+    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || (N & 7) || (ldx & 7) || ldx < N || ldo < N || r_out <= 0 || r_out > R ||
+        !a || !x || !out || !workspace)
+        return YAT_EINVAL;
+    const int nblk = (N + 127) / 128, npad = nblk * 128;
+    const int G = small_wgrad_groups(rows, nblk);
+    const int lds = 256 * (128 + R) * 2;                     // 72 KiB at R = 16
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)lokr_small_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) !=
@@ -313,15 +329,15 @@ int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, c
         attr_set = true;
     }
     if (R == 8)
-        hipLaunchKernelGGL((lokr_small_wgrad_kernel<8>), dim3(G), dim3(256), lds, (hipStream_t)stream, rows, N, (const bf16_t*)a,
-                           (const bf16_t*)x, (float*)workspace);
+        hipLaunchKernelGGL((lokr_small_wgrad_kernel<8>), dim3(G, nblk), dim3(256), lds, (hipStream_t)stream, rows, N, ldx, npad,
+                           (const bf16_t*)a, (const bf16_t*)x, (float*)workspace);
     else
-        hipLaunchKernelGGL((lokr_small_wgrad_kernel<16>), dim3(G), dim3(256), lds, (hipStream_t)stream, rows, N, (const bf16_t*)a,
-                           (const bf16_t*)x, (float*)workspace);
+        hipLaunchKernelGGL((lokr_small_wgrad_kernel<16>), dim3(G, nblk), dim3(256), lds, (hipStream_t)stream, rows, N, ldx, npad,
+                           (const bf16_t*)a, (const bf16_t*)x, (float*)workspace);
     YAT_CHECK_LAUNCH();
     const int n_out = r_out * N;
-    hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 15) / 16), dim3(256), 0, (hipStream_t)stream, G, R * N,
-                       n_out, (const float*)workspace, (bf16_t*)out, accumulate);
+    hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 15) / 16), dim3(256), 0, (hipStream_t)stream, G, R, N, npad,
+                       r_out, scale, (const float*)workspace, (bf16_t*)out, ldo, accumulate);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

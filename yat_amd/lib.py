@@ -65,8 +65,8 @@ SIGNATURES = {
     "yat_flow_mix": (I, [I, I64, P, P, P, P, P, P]),
     "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
     "yat_lokr_rows": (I, [I64, I, I, I, P, P, P, P]),
-    "yat_lokr_small_wgrad_workspace_bytes": (U64, [I, I]),
-    "yat_lokr_small_wgrad": (I, [I64, I, I, I, P, P, P, I, P, P]),
+    "yat_lokr_small_wgrad_workspace_bytes": (U64, [I64, I, I]),
+    "yat_lokr_small_wgrad": (I, [I64, I, I, I, P, P, I, P, I, F, I, P, P]),
     "yat_patch_rearrange": (I, [I, I, I, I, I, I, I, P, P, P]),
     "yat_add_pos_embed": (I, [I64, I, I, P, P, P, P]),
     "yat_ddpm_add_noise": (I, [I, I64, P, P, P, P, P, P]),

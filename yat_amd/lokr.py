@@ -124,7 +124,6 @@ class LoKrAdapters:
                     e["ga_pad"] = torch.zeros(e["out_k"], R, dtype=BF16, device=dev)
             self._eye = torch.eye(R, dtype=BF16, device=dev)
             self._gb_dummy = torch.empty(R, R, dtype=BF16, device=dev)
-            self._sw_ws = torch.empty(int(ops._lib().yat_lokr_small_wgrad_workspace_bytes(R, 128)), dtype=torch.uint8, device=dev)
         ws = max(ops._lib().yat_lokr_project_workspace_bytes(e["out_l"], e["out_k"], R if e["factored"] else e["in_n"])
                  for e in self.entries)
         self._ws = torch.empty(int(ws), dtype=torch.uint8, device=dev)
@@ -244,7 +243,7 @@ class LoKrAdapters:
             else:
                 h.record_stream(torch.cuda.current_stream())     # produced on the chain's stream, read on this one
             _, _, gb = self._views(e, self.flat_grad)
-            ops.lokr_small_wgrad(h.view(M * im, R), x2, gb, self._sw_ws, accumulate=accumulate)
+            ops.lokr_small_wgrad(h.view(M * im, R), x2, gb, accumulate=accumulate)
 
     def reset_parameters(self):
         """peft init_weights=True: w1 zeros, w2_a / w2_b kaiming_uniform(a=sqrt(5)) drawn on the CPU, then cast."""

@@ -1,0 +1,188 @@
+"""Plain LoRA adapters on the HIP path (``lora_algo: lora`` -- the reference wraps the transformer with peft's
+``LoraConfig(r, lora_alpha, lora_dropout, target_modules, use_dora)`` at common/trainer.py:213-219 and hands every parameter
+to AdamW :243-248).
+
+Arithmetic [RECALL peft/tuners/lora/layer.py -- parity unpinned, see oracle/lora_ref.py for the restatement]: for a target
+Linear / 1x1 Conv with weight W [out, in]:
+    result = base_layer(x) + lora_B(lora_A(dropout(x))) * scaling,   scaling = lora_alpha / r
+with lora_A [r, in] kaiming-uniform(a=sqrt(5)), lora_B [out, r] zeros, every op in the module dtype (bf16).
+
+MI355X mapping (same interface as yat_amd/lokr.py, so yat_amd/sana.py's hooks do not change): the adapter set owns one flat
+bf16 buffer (per target: A [R, in] then B^T [R, out], R = the rank padded to 8 so every skinny GEMM keeps 16-byte rows; the
+padding rows stay exactly zero: their gradients are zero) with a flat gradient twin -- clip + AdamW and the data-parallel
+all-reduce are the usual single launches.  Per target and step:
+    forward   T = x A^T (GEMM, N = R);  adapter = scaling * (T B^T)  (GEMM, K = R, the scalar as a constant gate row) -> pre_add
+    dgrad     dT = scaling * (dy B)     (GEMM, N = R);  dx += dT A   (GEMM, K = R, residual epilogue)
+    wgrad     d_B^T = scaling * T^T dy,  d_A = dT^T x  -- R x width outputs over a B*N-row reduction: yat_lokr_small_wgrad
+The dense weight gradients of the frozen base are never computed.  ``scaling`` is applied to the small side of each product
+(the reference rounds ``u * scaling`` and ``dy * scaling`` element-wise: identical when scaling is a power of two, one bf16
+rounding apart otherwise).  ``lora_dropout`` > 0, DoRA and rsLoRA are not built.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import torch
+
+from . import ops
+from .lokr import is_target
+
+BF16 = torch.bfloat16
+
+
+class LoRAAdapters:
+    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0):
+        if dropout and dropout > 0.0:
+            raise NotImplementedError("lora_dropout > 0 (element-wise dropout of the adapter input) is not built")
+        self.model, self.r, self.alpha, self.scale = model, int(r), float(alpha), float(alpha) / int(r)
+        self.targets = list(targets)
+        self.R = R = (self.r + 7) // 8 * 8
+        if R > 16:
+            raise NotImplementedError("LoRA rank > 16")
+        dev = model.flat_param.device
+        self.entries, off, segs = [], 0, [0]
+        base_ptr = model.flat_param.data_ptr()
+        for key, w in model.P.items():
+            if not key.endswith(".weight") or w.dim() < 2 or not is_target(key[:-7], self.targets):
+                continue
+            out_dim, in_dim = w.shape[0], w.numel() // w.shape[0]
+            if out_dim % 8 or in_dim % 8:
+                raise NotImplementedError(f"{key}: LoRA needs layer widths that are multiples of 8")
+            e = dict(module=key[:-7], key=key, out=out_dim, inn=in_dim, w_off=(w.data_ptr() - base_ptr) // 2,
+                     oa=off, ob=off + R * in_dim, active=True)
+            off += R * (in_dim + out_dim)
+            segs += [e["ob"], off]
+            self.entries.append(e)
+        if not self.entries:
+            raise ValueError("no module matches lora_target_modules")
+        self.numel_flat = off
+        self.flat_param = torch.zeros(off, dtype=BF16, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=BF16, device=dev)
+        self.seg_start = torch.tensor(sorted(set(segs)), dtype=torch.int64)
+        self.bucket_bounds = [(0, off)]
+        self.param_events = None
+        self.grad_ready = None
+        self._gate = torch.full((max(max(e["out"] for e in self.entries), R),), self.scale, dtype=BF16, device=dev)
+        self._lookup = {}
+        self.reset_parameters()
+        model.adapters = self
+
+    # ---- views: A [R, in] (rows >= r zero), B^T [R, out] (rows >= r zero)
+    def _views(self, e, flat):
+        return (flat[e["oa"]:e["oa"] + self.R * e["inn"]].view(self.R, e["inn"]),
+                flat[e["ob"]:e["ob"] + self.R * e["out"]].view(self.R, e["out"]))
+
+    def reset_parameters(self):
+        """peft init_lora_weights=True: lora_A kaiming_uniform(a=sqrt(5)) drawn on the CPU then cast, lora_B zeros."""
+        self.flat_param.zero_()
+        for e in self.entries:
+            a, _ = self._views(e, self.flat_param)
+            init = torch.empty(self.r, e["inn"], dtype=torch.float32)
+            torch.nn.init.kaiming_uniform_(init, a=math.sqrt(5))
+            a[:self.r].copy_(init.to(BF16))
+
+    def join_pending_update(self):
+        pev, self.param_events = self.param_events, None
+        if pev is not None:
+            cur = torch.cuda.current_stream()
+            for ev in pev:
+                cur.wait_event(ev)
+
+    def lookup(self, t, base):
+        off, n = (t.data_ptr() - base.data_ptr()) // 2, t.numel()
+        hit = self._lookup.get((off, n))
+        if hit is None:
+            hit = [(e, (e["w_off"] - off) // e["inn"]) for e in self.entries if off <= e["w_off"] < off + n]
+            self._lookup[(off, n)] = hit
+        return hit
+
+    # ---- per step (interface of yat_amd/lokr.py)
+    def materialize(self, training=True):
+        self.join_pending_update()                 # nothing to build: the factors are used as they are
+
+    def forward_term(self, x, w):
+        ents = self.lookup(w, self.model.flat_param)
+        if not ents:
+            return None
+        M, rows, R = x.shape[0], w.shape[0], self.R
+        tmp = torch.empty(M, rows, dtype=BF16, device=x.device)
+        if sum(e["out"] for e, _ in ents) != rows:
+            tmp.zero_()
+        for e, row0 in ents:
+            a, bt = self._views(e, self.flat_param)
+            t = torch.empty(M, R, dtype=BF16, device=x.device)
+            ops.gemm(x, a, t, M=M, N=R, K=e["inn"])                                        # T = x A^T
+            ops.gemm(t, bt, tmp[:, row0:row0 + e["out"]], b_t=True, M=M, N=e["out"], K=R, lda=R, ldb=e["out"], ldc=rows,
+                     gate=self._gate, ld_gate=0, rows_per_batch=M)                          # scaling * (T B^T)
+            e["t"] = (x.data_ptr(), t)             # kept for d_B (see lokr.py on the lifetime)
+        return tmp
+
+    def dgrad_term(self, dy, w, dx):
+        hs = {}
+        M, R, ld = dy.shape[0], self.R, dy.stride(0)
+        for e, row0 in self.lookup(w, self.model.flat_param):
+            a, bt = self._views(e, self.flat_param)
+            dt = torch.empty(M, R, dtype=BF16, device=dy.device)
+            ops.gemm(dy[:, row0:row0 + e["out"]], bt, dt, M=M, N=R, K=e["out"], lda=ld, ldb=e["out"], ldc=R,
+                     gate=self._gate, ld_gate=0, rows_per_batch=M)                          # dT = scaling * (dy B)
+            ops.gemm(dt, a, dx, b_t=True, M=M, N=e["inn"], K=R, lda=R, ldb=e["inn"], ldc=e["inn"], residual=dx)   # dx += dT A
+            hs[id(e)] = dt
+        return hs
+
+    def wgrad(self, dy, x, gw, accumulate=False, hs=None):
+        M, R, ld = dy.shape[0], self.R, dy.stride(0)
+        for e, row0 in self.lookup(gw, self.model.flat_grad):
+            a, bt = self._views(e, self.flat_param)
+            ga, gbt = self._views(e, self.flat_grad)
+            dyb = dy[:, row0:row0 + e["out"]]
+            kept = e.get("t")
+            if kept is not None and kept[0] == x.data_ptr() and kept[1].shape[0] == M:
+                t = kept[1]
+            else:
+                t = torch.empty(M, R, dtype=BF16, device=x.device)
+                ops.gemm(x, a, t, M=M, N=R, K=e["inn"])
+            dt = hs.get(id(e)) if hs else None
+            if dt is None:
+                dt = torch.empty(M, R, dtype=BF16, device=dy.device)
+                ops.gemm(dyb, bt, dt, M=M, N=R, K=e["out"], lda=ld, ldb=e["out"], ldc=R, gate=self._gate, ld_gate=0,
+                         rows_per_batch=M)
+            else:
+                dt.record_stream(torch.cuda.current_stream())
+            ops.lokr_small_wgrad(t, dyb, gbt[:self.r], accumulate=accumulate, scale=self.scale)   # d_B^T = scaling T^T dy
+            ops.lokr_small_wgrad(dt, x, ga[:self.r], accumulate=accumulate)                       # d_A = dT^T x
+
+    def project(self):
+        if self.grad_ready is not None:            # gradients are complete as written; only the DDP hook remains
+            self.grad_ready(0)
+
+    # ---- checkpoint (peft layout)
+    def state_dict(self):
+        self.join_pending_update()
+        sd = {}
+        for e in self.entries:
+            a, bt = self._views(e, self.flat_param)
+            pre = f"base_model.model.{e['module']}."
+            sd[pre + "lora_A.weight"], sd[pre + "lora_B.weight"] = a[:self.r], bt[:self.r].t()
+        return sd
+
+    def load_state_dict(self, sd):
+        for e in self.entries:
+            a, bt = self._views(e, self.flat_param)
+            pre = f"base_model.model.{e['module']}."
+            a[:self.r].copy_(sd[pre + "lora_A.weight"].to(device=a.device, dtype=BF16).view(self.r, e["inn"]))
+            bt[:self.r].copy_(sd[pre + "lora_B.weight"].to(device=a.device, dtype=BF16).view(e["out"], self.r).t())
+
+    def save_pretrained(self, path):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(path, "adapter_model.safetensors"))
+        with open(os.path.join(path, "adapter_config.json"), "w") as f:
+            json.dump({"peft_type": "LORA", "r": self.r, "lora_alpha": self.alpha, "lora_dropout": 0.0,
+                       "target_modules": self.targets, "use_dora": False, "use_rslora": False, "bias": "none",
+                       "init_lora_weights": True}, f, indent=2)
+
+    def num_parameters(self):
+        return sum(self.r * (e["inn"] + e["out"]) for e in self.entries)

@@ -200,15 +200,29 @@ def lokr_rows_bwd(h2d, wb, dx2d):
     return dx2d
 
 
-def lokr_small_wgrad(a2d, x2d, out2d, workspace, accumulate=False):
-    """out[q, n] (+)= sum_row a[row, q] * x[row, n], q < out.shape[0] (include/yat_hip.h: yat_lokr_small_wgrad)."""
+_SW_WS = {}
+
+
+def lokr_small_wgrad(a2d, x2d, out2d, workspace=None, accumulate=False, scale=1.0):
+    """out[q, n] (+)= bf16(scale * sum_row a[row, q] * x[row, n]), q < out.shape[0]; x2d / out2d may be column blocks of wider
+    matrices (row strides) -- include/yat_hip.h: yat_lokr_small_wgrad.  workspace None: a cached one per (device, stream)."""
     _chk_bf16(a2d, x2d, out2d)
     rows, R = a2d.shape
     N = x2d.shape[1]
-    if x2d.shape[0] != rows or out2d.shape[1] != N or not (a2d.is_contiguous() and x2d.is_contiguous() and out2d.is_contiguous()):
+    if x2d.shape[0] != rows or out2d.shape[1] != N or not a2d.is_contiguous() or x2d.stride(1) != 1 or out2d.stride(1) != 1:
         raise ValueError("lokr_small_wgrad: shape mismatch")
-    _l.check(_lib().yat_lokr_small_wgrad(rows, R, N, out2d.shape[0], _p(a2d), _p(x2d), _p(out2d), int(accumulate),
-                                         _p(workspace), _stream()), "yat_lokr_small_wgrad")
+    need = int(_lib().yat_lokr_small_wgrad_workspace_bytes(rows, R, N))
+    if workspace is None:
+        key = (a2d.device, torch.cuda.current_stream().cuda_stream)
+        workspace = _SW_WS.get(key)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=a2d.device)
+            _SW_WS[key] = workspace
+    elif workspace.numel() < need:
+        raise ValueError("lokr_small_wgrad: workspace too small")
+    _l.check(_lib().yat_lokr_small_wgrad(rows, R, N, out2d.shape[0], _p(a2d), _p(x2d), x2d.stride(0), _p(out2d),
+                                         out2d.stride(0), float(scale), int(accumulate), _p(workspace), _stream()),
+             "yat_lokr_small_wgrad")
     return out2d
 
 
