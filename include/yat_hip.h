@@ -140,6 +140,11 @@ int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off,
  *   (0 keep / -10000 drop); kv_len[b] = 1 + last kept key (tiles past it are skipped -- exact,
  *   their probabilities underflow to 0 -- unless kv_len[b]==0, then all T keys are used).
  *   out: bf16 [B*N, ldo]; lse: float [B, H, N] (natural log).  dh <= 128, dh % 8 == 0.
+ * The same entry points serve every softmax attention of the path: SANA attn2 (dh 112, T = 512), the softmax variant of
+ * attn1 in SANA's modified_blocks (dh 32; patch_sana_attention_layers.py:125-131) and both attentions of a PixArt-Sigma
+ * block (dh 72; self-attention over N = T = 4096 with q, k, v = the column blocks of the fused [3D] projection and a
+ * zero key_bias; utils/patch_pixart_sigma_transformer.py:150-158).  The kernels pick a head-dim instantiation and the
+ * workgroup shape (64 or 128 queries) from dh, N, H, B.
  * ------------------------------------------------------------------------------------------ */
 int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream);
