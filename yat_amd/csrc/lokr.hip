@@ -101,63 +101,76 @@ __global__ __launch_bounds__(256) void lokr_dw2_final_kernel(LokrP p, const floa
 // (R <= 16) x (N <= 128) outputs and a million-row reduction (rows = B*N_tokens*in_m) -- far outside what a tiled GEMM is
 // for.  HBM-bound streaming pass; every workgroup leaves one fp32 partial, a second launch sums the partials in a fixed
 // order (no atomics).  (v1 -- a wave per row, a lane per column pair -- was latency-bound: 226-477 us per call.)
-// v2: LDS-tiled.  A workgroup stages CH rows of a [CH][R] and x [CH][N] with 16-byte loads, then every thread owns
-// (q, column pair) outputs and walks the staged rows: two LDS reads (a: 8 distinct addresses per row -> broadcast, x:
-// consecutive 4-byte words) and two FMAs per row.  Accumulators live across the workgroup's chunks; one partial per workgroup.
-template <int R>
-__global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int N, int ldx, int npad, const bf16_t* A,
+// v3: the reduction runs on the matrix cores.  out^T tile = a^T x is a 16 x 128 MFMA accumulator block (q padded to 16, eight
+// 16-column tiles), k = 32 rows per v_mfma_f32_16x16x32_bf16; both operands are "k-strided" (k = the row index is the slow
+// dimension of a and x), so a workgroup stages CH rows of each as row-major LDS images with 16-byte loads and the waves
+// fetch fragments with the hardware-transposing ds_read_b64_tr_b16 (the x image XOR-swizzled like gemm256's k-strided
+// operand, the 32-byte rows of the a image need no swizzle).  The pass is a stream through LDS: 16 MFMAs per wave per 256 rows.
+// (v1, a wave per row: 226-477 us per call; v2, scalar FMAs from LDS: ~200 us in the step; traffic alone is ~35 us.)
+__device__ __forceinline__ uint32_t sw_swz(uint32_t krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int R, int N, int ldx, int npad, const bf16_t* A,
                                                                const bf16_t* X, float* partial) {
-    constexpr int CH = 256;                                  // rows per staged chunk
+    constexpr int CH = 256;                                  // rows per staged chunk = 8 k-steps of 32
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n0 = blockIdx.y * 128;                         // column block of x (LoRA: N = out / in, up to 11200)
+    char* ximg = smem;                                       // [CH][128] bf16, 256-byte rows, chunk ^= sw_swz(row)
+    char* aimg = smem + CH * 256;                            // [CH][16] bf16, 32-byte rows (columns >= R stay zero)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.y * 128;
     const int Nb = N - n0 < 128 ? N - n0 : 128;
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);            // [CH][Nb]
-    bf16_t* as = xs + CH * 128;                              // [CH][R]
-    const int NP = Nb >> 1, VPR = Nb >> 3;                   // column pairs / 16-byte vectors per row
-    constexpr int MAXO = (R * 64 + 255) / 256;               // outputs (q, pair) per thread: R * NP <= R * 64
-    float acc0[MAXO], acc1[MAXO];
-    int oq[MAXO], op[MAXO];
+    const int VPR = Nb >> 3, ntile = (Nb + 15) >> 4;
+    for (int v = threadIdx.x; v < CH * 2; v += 256) *reinterpret_cast<u32x4*>(aimg + v * 16) = u32x4{0u, 0u, 0u, 0u};
+    f32x4 acc[8];
 #pragma unroll
-    for (int u = 0; u < MAXO; ++u) {
-        const int o = threadIdx.x + 256 * u;
-        oq[u] = o / NP; op[u] = o - oq[u] * NP;
-        if (oq[u] >= R) { oq[u] = 0; op[u] = -1; }            // idle slot
-        acc0[u] = 0.f; acc1[u] = 0.f;
-    }
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int64_t nchunk = (rows + CH - 1) / CH;
     for (int64_t ck = blockIdx.x; ck < nchunk; ck += gridDim.x) {
         const int64_t r0 = ck * CH;
         const int nr = (int)(rows - r0 < CH ? rows - r0 : CH);
-        __syncthreads();                                     // previous chunk fully consumed
-        for (int v = threadIdx.x; v < nr * VPR; v += 256) {
+        __syncthreads();                                     // previous chunk fully consumed (and the zero fill done)
+        for (int v = threadIdx.x; v < CH * VPR; v += 256) {
             const int r = v / VPR, c = v - r * VPR;
-            *reinterpret_cast<u32x4*>(xs + r * Nb + c * 8) = *reinterpret_cast<const u32x4*>(X + (r0 + r) * ldx + n0 + c * 8);
+            u32x4 val = u32x4{0u, 0u, 0u, 0u};               // rows past the end contribute zeros (never stale LDS bits)
+            if (r < nr) val = *reinterpret_cast<const u32x4*>(X + (r0 + r) * ldx + n0 + c * 8);
+            *reinterpret_cast<u32x4*>(ximg + r * 256 + ((c ^ sw_swz(r)) << 4)) = val;
         }
-        for (int v = threadIdx.x; v < nr * R / 8; v += 256)
-            *reinterpret_cast<u32x4*>(as + v * 8) = *reinterpret_cast<const u32x4*>(A + r0 * R + (int64_t)v * 8);
+        for (int v = threadIdx.x; v < CH * (R >> 3); v += 256) {
+            const int r = v / (R >> 3), c = v - r * (R >> 3);
+            u32x4 val = u32x4{0u, 0u, 0u, 0u};
+            if (r < nr) val = *reinterpret_cast<const u32x4*>(A + (r0 + r) * R + c * 8);
+            *reinterpret_cast<u32x4*>(aimg + r * 32 + c * 16) = val;
+        }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < MAXO; ++u) {
-            if (op[u] < 0) continue;
-            const bf16_t* ap = as + oq[u];
-            const uint32_t* xp = reinterpret_cast<const uint32_t*>(xs) + op[u];
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < nr; ++r) {
-                const float av_ = bf2f(ap[r * R]);
-                const uint32_t xx = xp[r * NP];
-                s0 += av_ * __uint_as_float(xx << 16);
-                s1 += av_ * __uint_as_float(xx & 0xffff0000u);
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t kk = wave + 4 * ks;               // this wave's 32-row k-steps of the chunk
+            const uint32_t ra = kk * 32 + 8 * g + q, rb = ra + 4;
+            const bf16x8 af = cat4(lds_read_tr4(aimg, ra * 32 + p * 8), lds_read_tr4(aimg, rb * 32 + p * 8));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < ntile) {
+                    const uint32_t col = t * 16 + 4 * p;
+                    const uint32_t ca = (col >> 3) ^ sw_swz(ra), cb = (col >> 3) ^ sw_swz(rb);
+                    const bf16x8 xf = cat4(lds_read_tr4(ximg, ra * 256 + ca * 16 + (p & 1) * 8),
+                                           lds_read_tr4(ximg, rb * 256 + cb * 16 + (p & 1) * 8));
+                    acc[t] = mfma16(af, xf, acc[t]);         // acc[t][r] @ lane (g, li): out[q = 4g + r][n = 16t + li]
+                }
             }
-            acc0[u] += s0; acc1[u] += s1;
         }
     }
+    __syncthreads();                                         // every wave is done reading the images
+    float* red = reinterpret_cast<float*>(smem);             // [4 waves][16 q][128 n] fp32 = 32 KiB
 #pragma unroll
-    for (int u = 0; u < MAXO; ++u)
-        if (op[u] >= 0) {
-            float* dst = partial + ((int64_t)blockIdx.x * R + oq[u]) * npad + n0 + 2 * op[u];
-            dst[0] = acc0[u]; dst[1] = acc1[u];
-        }
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * g + r) * 128 + t * 16 + (lane & 15)] = acc[t][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < R * Nb; e += 256) {
+        const int qq = e / Nb, n = e - qq * Nb;
+        partial[((int64_t)blockIdx.x * R + qq) * npad + n0 + n] =
+            red[(0 * 16 + qq) * 128 + n] + red[(1 * 16 + qq) * 128 + n] + red[(2 * 16 + qq) * 128 + n] + red[(3 * 16 + qq) * 128 + n];
+    }
 }
 // out[q, n] = (accumulate ? out : 0) + bf16(scale * sum_g partial[g][q][n]), q < r_out.  One workgroup per 16 outputs: 16
 // slices of the partial list (4 waves x 4 lane groups) x 16 consecutive outputs, fixed order, two shuffles + one LDS step.
@@ -318,22 +331,16 @@ int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, c
         return YAT_EINVAL;
     const int nblk = (N + 127) / 128, npad = nblk * 128;
     const int G = small_wgrad_groups(rows, nblk);
-    const int lds = 256 * (128 + R) * 2;                     // 72 KiB at R = 16
+    const int lds = 256 * (128 + 16) * 2;                    // x image 64 KiB + a image 8 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)lokr_small_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void*)lokr_small_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) !=
-                hipSuccess)
+        if (hipFuncSetAttribute((const void*)lokr_small_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) !=
+            hipSuccess)
             return YAT_EINVAL;
         attr_set = true;
     }
-    if (R == 8)
-        hipLaunchKernelGGL((lokr_small_wgrad_kernel<8>), dim3(G, nblk), dim3(256), lds, (hipStream_t)stream, rows, N, ldx, npad,
-                           (const bf16_t*)a, (const bf16_t*)x, (float*)workspace);
-    else
-        hipLaunchKernelGGL((lokr_small_wgrad_kernel<16>), dim3(G, nblk), dim3(256), lds, (hipStream_t)stream, rows, N, ldx, npad,
-                           (const bf16_t*)a, (const bf16_t*)x, (float*)workspace);
+    hipLaunchKernelGGL(lokr_small_wgrad_kernel, dim3(G, nblk), dim3(256), lds, (hipStream_t)stream, rows, R, N, ldx, npad,
+                       (const bf16_t*)a, (const bf16_t*)x, (float*)workspace);
     YAT_CHECK_LAUNCH();
     const int n_out = r_out * N;
     hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 15) / 16), dim3(256), 0, (hipStream_t)stream, G, R, N, npad,
