@@ -215,6 +215,11 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
 /* the two row-streaming products of that path: backward=0: io[rows, R] = a[rows, N] w2_b^T;
  * backward=1: io[rows, N] = bf16(bf16(a[rows, R] w2_b) + io)   (w2_b: bf16 [R, N], R = 8 or 16, N <= 128, N % 8 == 0) */
 int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, yat_stream_t stream);
+/* rank-R expansion over a whole layer width (plain LoRA, peft lora/layer.py [RECALL]; the reference's LoraConfig branch at
+ * common/trainer.py:214-219): io[row, n] = f(sum_q h[row, q] * w[q, n]), h: bf16 [rows, R], w: bf16 [R, N], io: bf16 [rows, ldio];
+ * residual=0: io = bf16(bf16(sum) * scale)  (lora_B(lora_A(x)) * scaling);  residual=1: io = bf16(bf16(sum) + io)  (dx += dT A) */
+int yat_rank_expand(int64_t rows, int N, int R, const void* w, const void* h, void* io, int ldio, float scale, int residual,
+                    yat_stream_t stream);
 uint64_t yat_lokr_small_wgrad_workspace_bytes(int64_t rows, int R, int N);
 int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, const void* x, int ldx, void* out, int ldo,
                          float scale, int accumulate, void* workspace, yat_stream_t stream);

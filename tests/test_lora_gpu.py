@@ -98,3 +98,24 @@ def test_lora_training_step_matches_oracle(r, alpha, tmp_path):
     assert torch.equal(again.flat_param, ad.flat_param)
     k0 = f"base_model.model.{ad.entries[0]['module']}."
     assert saved[k0 + "lora_A.weight"].shape == (r, ad.entries[0]["inn"]) and saved[k0 + "lora_B.weight"].shape == (ad.entries[0]["out"], r)
+
+
+@pytest.mark.parametrize("rows,R,N,ld", [(1000, 8, 2240, 2240), (333, 16, 11200, 11200), (4096, 8, 64, 192), (77, 8, 520, 520)])
+def test_rank_expand(rows, R, N, ld):
+    """io = bf16(bf16(h w) * scale) and io = bf16(bf16(h w) + io): the K = R products of the LoRA path, bit-exact against the
+    fp64 product rounded the same way (a K <= 16 sum of bf16 products is exact in fp32 up to the last rounding)."""
+    from yat_amd import ops
+    g = torch.Generator().manual_seed(rows + N)
+    h, w = (torch.randn(rows, R, generator=g) * 0.3).to(BF).to(DEV), (torch.randn(R, N, generator=g) * 0.2).to(BF).to(DEV)
+    buf = torch.randn(rows, ld, generator=g).to(BF).to(DEV)
+    prod = (h.double() @ w.double())
+    out = buf.clone()
+    ops.rank_expand(h, w, out[:, :N], scale=0.75)
+    want = (prod.float().to(BF).float() * 0.75).to(BF)
+    ok = (out[:, :N].float() - want.float()).abs() <= 2.0 ** -7 * want.float().abs() + 1e-30
+    assert ok.all() and torch.equal(out[:, N:], buf[:, N:])             # one-ulp slack: fp32 vs fp64 accumulation of the sum
+    out = buf.clone()
+    ops.rank_expand(h, w, out[:, :N], residual=True)
+    want = (prod.float().to(BF).float() + buf[:, :N].float()).to(BF)
+    ok = (out[:, :N].float() - want.float()).abs() <= 2.0 ** -7 * want.float().abs() + 2.0 ** -7 * prod.abs().float() + 1e-30
+    assert ok.all() and torch.equal(out[:, N:], buf[:, N:])

@@ -246,6 +246,48 @@ __global__ __launch_bounds__(256) void lokr_rows_kernel(int64_t rows, int N, con
     }
 }
 
+// Rank-R expansion over a whole layer width (plain LoRA: u = T B^T with K = R, dx += dT A): a GEMM with an 8-deep reduction
+// is all epilogue, so it runs as a stream instead -- io[row, n] = f(sum_q h[row, q] * w[q, n]) with w's column block
+// (CB = 512 columns, fp32) in LDS, a lane per 16-byte chunk of the output row, a wave per 512 contiguous columns.
+//   residual = 0: io = bf16(bf16(sum) * scale)      (peft: lora_B(..) * scaling, each op rounded)
+//   residual = 1: io = bf16(bf16(sum) + io)         (accumulation into an input gradient, the GEMM's residual rounding)
+template <int R>
+__global__ __launch_bounds__(256) void lokr_wide_rows_kernel(int64_t rows, int N, int ldio, const bf16_t* wsrc, const bf16_t* h,
+                                                             bf16_t* io, float scale, int residual) {
+    constexpr int CB = 512;
+    __shared__ float w[R][CB];
+    const int n0 = blockIdx.y * CB;
+    for (int e = threadIdx.x; e < R * CB; e += 256) {
+        const int q = e / CB, n = n0 + (e - q * CB);
+        w[q][e - q * CB] = n < N ? bf2f(wsrc[(int64_t)q * N + n]) : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, n = n0 + c * 8;          // this lane's 8 columns
+    if (n >= N) return;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        float hv[R], o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < R / 8; ++v) unpack8(*reinterpret_cast<const u32x4*>(h + row * R + v * 8), hv + v * 8);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&w[q][c * 8]), hi = *reinterpret_cast<const f32x4*>(&w[q][c * 8 + 4]);
+            o[0] += hv[q] * lo[0]; o[1] += hv[q] * lo[1]; o[2] += hv[q] * lo[2]; o[3] += hv[q] * lo[3];
+            o[4] += hv[q] * hi[0]; o[5] += hv[q] * hi[1]; o[6] += hv[q] * hi[2]; o[7] += hv[q] * hi[3];
+        }
+        bf16_t* dp = io + row * ldio + n;
+        if (residual) {
+            float d[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dp), d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) + d[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) * scale;
+        }
+        *reinterpret_cast<u32x4*>(dp) = pack8(o);
+    }
+}
+
 int fill(LokrP& p, int out_l, int out_k, int in_m, int in_n, int r, const void* w1, const void* w2a, const void* w2b,
          float scale, int ld) {
     if (out_l <= 0 || out_k <= 0 || in_m <= 0 || in_n <= 0 || r <= 0 || r > 64 || !w1 || !w2a || !w2b ||
@@ -308,6 +350,22 @@ int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, co
     else if (lpr == 8) { if (backward) YAT_ROWS(16, 8, true); else YAT_ROWS(16, 8, false); }
     else { if (backward) YAT_ROWS(16, 16, true); else YAT_ROWS(16, 16, false); }
 #undef YAT_ROWS
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_rank_expand(int64_t rows, int N, int R, const void* w, const void* h, void* io, int ldio, float scale, int residual,
+                    yat_stream_t stream) {
+    if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || (N & 7) || (ldio & 7) || ldio < N || !w || !h || !io) return YAT_EINVAL;
+    const int nblk = (N + 511) / 512;
+    int64_t g64 = (rows + 3) / 4;
+    const int gx = (int)(g64 > 2048 / nblk + 1 ? 2048 / nblk + 1 : g64);
+    if (R == 8)
+        hipLaunchKernelGGL((lokr_wide_rows_kernel<8>), dim3(gx, nblk), dim3(256), 0, (hipStream_t)stream, rows, N, ldio,
+                           (const bf16_t*)w, (const bf16_t*)h, (bf16_t*)io, scale, residual);
+    else
+        hipLaunchKernelGGL((lokr_wide_rows_kernel<16>), dim3(gx, nblk), dim3(256), 0, (hipStream_t)stream, rows, N, ldio,
+                           (const bf16_t*)w, (const bf16_t*)h, (bf16_t*)io, scale, residual);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

@@ -11,8 +11,9 @@ MI355X mapping (same interface as yat_amd/lokr.py, so yat_amd/sana.py's hooks do
 bf16 buffer (per target: A [R, in] then B^T [R, out], R = the rank padded to 8 so every skinny GEMM keeps 16-byte rows; the
 padding rows stay exactly zero: their gradients are zero) with a flat gradient twin -- clip + AdamW and the data-parallel
 all-reduce are the usual single launches.  Per target and step:
-    forward   T = x A^T (GEMM, N = R);  adapter = scaling * (T B^T)  (GEMM, K = R, the scalar as a constant gate row) -> pre_add
-    dgrad     dT = scaling * (dy B)     (GEMM, N = R);  dx += dT A   (GEMM, K = R, residual epilogue)
+    forward   T = x A^T (GEMM, N = R);  adapter = bf16(bf16(T B^T) * scaling)  (yat_rank_expand: a K = R product is all epilogue,
+              so it is a stream, not a GEMM) -> pre_add
+    dgrad     dT = scaling * (dy B)     (GEMM, N = R, the scalar as a constant gate row);  dx += dT A   (yat_rank_expand)
     wgrad     d_B^T = scaling * T^T dy,  d_A = dT^T x  -- R x width outputs over a B*N-row reduction: yat_lokr_small_wgrad
 The dense weight gradients of the frozen base are never computed.  ``scaling`` is applied to the small side of each product
 (the reference rounds ``u * scaling`` and ``dy * scaling`` element-wise: identical when scaling is a power of two, one bf16
@@ -114,8 +115,7 @@ class LoRAAdapters:
             a, bt = self._views(e, self.flat_param)
             t = torch.empty(M, R, dtype=BF16, device=x.device)
             ops.gemm(x, a, t, M=M, N=R, K=e["inn"])                                        # T = x A^T
-            ops.gemm(t, bt, tmp[:, row0:row0 + e["out"]], b_t=True, M=M, N=e["out"], K=R, lda=R, ldb=e["out"], ldc=rows,
-                     gate=self._gate, ld_gate=0, rows_per_batch=M)                          # scaling * (T B^T)
+            ops.rank_expand(t, bt, tmp[:, row0:row0 + e["out"]], scale=self.scale)         # bf16(bf16(T B^T) * scaling)
             e["t"] = (x.data_ptr(), t)             # kept for d_B (see lokr.py on the lifetime)
         return tmp
 
@@ -127,7 +127,7 @@ class LoRAAdapters:
             dt = torch.empty(M, R, dtype=BF16, device=dy.device)
             ops.gemm(dy[:, row0:row0 + e["out"]], bt, dt, M=M, N=R, K=e["out"], lda=ld, ldb=e["out"], ldc=R,
                      gate=self._gate, ld_gate=0, rows_per_batch=M)                          # dT = scaling * (dy B)
-            ops.gemm(dt, a, dx, b_t=True, M=M, N=e["inn"], K=R, lda=R, ldb=e["inn"], ldc=e["inn"], residual=dx)   # dx += dT A
+            ops.rank_expand(dt, a, dx, residual=True)                                       # dx += dT A
             hs[id(e)] = dt
         return hs
 

@@ -200,6 +200,19 @@ def lokr_rows_bwd(h2d, wb, dx2d):
     return dx2d
 
 
+def rank_expand(h2d, w, io2d, scale=1.0, residual=False):
+    """io[rows, N] = bf16(bf16(h w) * scale), or bf16(bf16(h w) + io) with residual -- h2d [rows, R], w [R, N]; io2d may be a
+    column block of a wider matrix (include/yat_hip.h: yat_rank_expand)."""
+    _chk_bf16(h2d, w, io2d)
+    rows, R = h2d.shape
+    N = w.shape[1]
+    if w.shape[0] != R or io2d.shape != (rows, N) or not (h2d.is_contiguous() and w.is_contiguous()) or io2d.stride(1) != 1:
+        raise ValueError("rank_expand: shape mismatch")
+    _l.check(_lib().yat_rank_expand(rows, N, R, _p(w), _p(h2d), _p(io2d), io2d.stride(0), float(scale), int(residual), _stream()),
+             "yat_rank_expand")
+    return io2d
+
+
 _SW_WS = {}
 
 
