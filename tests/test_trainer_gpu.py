@@ -144,6 +144,15 @@ def test_trainer_lokr_config(tmp_path, monkeypatch, algo):
     sd = load_file(str(ck / "adapter_model.safetensors"))
     conf = json.loads((ck / "adapter_config.json").read_text())
     assert conf["r"] == 2 and conf["target_modules"] == targets
+    # lora_pretrained: a second trainer resumes from the saved adapter (PeftModel.from_pretrained, common/trainer.py:236)
+    yaml_path.write_text(yaml_path.read_text() + f"lora_pretrained: {ck}\n")
+    params2 = TrainingParameters()
+    params2.read_yaml(str(yaml_path))
+    resumed = SanaModel(params2, config=cfg)
+    resumed.initialize()
+    assert type(resumed.adapters) is type(trainer.adapters)
+    for k, v in resumed.adapters.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
     if algo == "lora":
         assert conf["peft_type"] == "LORA" and len(sd) == 2 * len(trainer.adapters.entries)
         assert sd["base_model.model.transformer_blocks.1.attn2.to_out.0.lora_B.weight"].shape == (128, 2)

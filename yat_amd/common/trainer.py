@@ -207,20 +207,34 @@ class Model:
         self.adapters = None
         if getattr(p, "lora_rank", None) is not None:                 # :212-241 (get_peft_model)
             algo = getattr(p, "lora_algo", "lora")
+            targets, rank, alpha = p.lora_target_modules, p.lora_rank, p.lora_alpha
+            drop, rslora, saved = getattr(p, "lora_dropout", 0.0) or 0.0, bool(getattr(p, "lora_use_rslora", False)), None
+            if getattr(p, "lora_pretrained", None):
+                # :236 PeftModel.from_pretrained(model, path, is_trainable=True): the saved adapter's own config decides
+                import json
+                from safetensors.torch import load_file
+                with open(os.path.join(p.lora_pretrained, "adapter_config.json")) as f:
+                    conf = json.load(f)
+                algo = {"LORA": "lora", "LOKR": "lokr"}.get(conf.get("peft_type"))
+                if algo is None:
+                    raise NotImplementedError(f"lora_pretrained: peft_type {conf.get('peft_type')!r} is not built")
+                targets, rank = conf["target_modules"], int(conf["r"])
+                alpha = conf["lora_alpha"] if algo == "lora" else conf["alpha"]
+                drop = conf.get("lora_dropout" if algo == "lora" else "module_dropout", 0.0) or 0.0
+                rslora = bool(conf.get("use_rslora", False))
+                saved = load_file(os.path.join(p.lora_pretrained, "adapter_model.safetensors"))
             if algo not in ("lokr", "lora"):
                 raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 -- and lora are)")
-            if getattr(p, "lora_pretrained", None):
-                raise NotImplementedError("resuming from a saved adapter (lora_pretrained) is not built")
             if algo == "lora":                                        # :214-219
-                if getattr(p, "lora_use_dora", False) or getattr(p, "lora_use_rslora", False):
-                    raise NotImplementedError("DoRA / rsLoRA are not built")
+                if getattr(p, "lora_use_dora", False):
+                    raise NotImplementedError("DoRA is not built")
                 from ..lora import LoRAAdapters
-                self.adapters = LoRAAdapters(self.model, p.lora_target_modules, p.lora_rank, p.lora_alpha,
-                                             dropout=getattr(p, "lora_dropout", 0.0) or 0.0)
+                self.adapters = LoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora)
             else:                                                     # :226-230
                 from ..lokr import LoKrAdapters
-                self.adapters = LoKrAdapters(self.model, p.lora_target_modules, p.lora_rank, p.lora_alpha,
-                                             module_dropout=getattr(p, "lora_dropout", 0.0) or 0.0)
+                self.adapters = LoKrAdapters(self.model, targets, rank, alpha, module_dropout=drop)
+            if saved is not None:
+                self.adapters.load_state_dict(saved)
             n_ad = self.adapters.num_parameters()
             print(f"trainable params: {n_ad:,} || all params: {self.model.numel_flat + n_ad:,} || "
                   f"trainable%: {100.0 * n_ad / (self.model.numel_flat + n_ad):.4f}")       # print_trainable_parameters (:239)

@@ -17,7 +17,7 @@ all-reduce are the usual single launches.  Per target and step:
     wgrad     d_B^T = scaling * T^T dy,  d_A = dT^T x  -- R x width outputs over a B*N-row reduction: yat_lokr_small_wgrad
 The dense weight gradients of the frozen base are never computed.  ``scaling`` is applied to the small side of each product
 (the reference rounds ``u * scaling`` and ``dy * scaling`` element-wise: identical when scaling is a power of two, one bf16
-rounding apart otherwise).  ``lora_dropout`` > 0, DoRA and rsLoRA are not built.
+rounding apart otherwise).  ``lora_dropout`` > 0 and DoRA are not built.
 """
 from __future__ import annotations
 
@@ -34,10 +34,12 @@ BF16 = torch.bfloat16
 
 
 class LoRAAdapters:
-    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0):
+    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0, use_rslora: bool = False):
         if dropout and dropout > 0.0:
             raise NotImplementedError("lora_dropout > 0 (element-wise dropout of the adapter input) is not built")
-        self.model, self.r, self.alpha, self.scale = model, int(r), float(alpha), float(alpha) / int(r)
+        self.model, self.r, self.alpha, self.use_rslora = model, int(r), float(alpha), bool(use_rslora)
+        # [RECALL peft] scaling = lora_alpha / r, or lora_alpha / sqrt(r) with use_rslora
+        self.scale = float(alpha) / (math.sqrt(int(r)) if use_rslora else int(r))
         self.targets = list(targets)
         self.R = R = (self.r + 7) // 8 * 8
         if R > 16:
@@ -181,7 +183,7 @@ class LoRAAdapters:
                   os.path.join(path, "adapter_model.safetensors"))
         with open(os.path.join(path, "adapter_config.json"), "w") as f:
             json.dump({"peft_type": "LORA", "r": self.r, "lora_alpha": self.alpha, "lora_dropout": 0.0,
-                       "target_modules": self.targets, "use_dora": False, "use_rslora": False, "bias": "none",
+                       "target_modules": self.targets, "use_dora": False, "use_rslora": self.use_rslora, "bias": "none",
                        "init_lora_weights": True}, f, indent=2)
 
     def num_parameters(self):
