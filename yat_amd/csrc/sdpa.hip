@@ -282,7 +282,10 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     stage(0, smem);
 
     bf16x8 qf[QS][KS], dof[QS][KS];
-    float dl[QS], nlse2[QS];                     // nlse2 = -lse * log2e (queries past N: -1e30 -> P = 0)
+    // Row constants ride in the MFMA accumulators: S' = q.k - lse/scale and dP' = dO.v - delta start from these tuples, so
+    // p = exp2(S' * scale*log2e + bias*log2e) needs no subtraction and dS = p * dP' no second one (queries past N: -1e30 -> P = 0)
+    f32x4 sinit[QS], dpinit[QS];
+    const float inv_scale = 1.0f / p.scale, c2 = p.scale * LOG2E;
     f32x4 acc[QS][DT];
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
@@ -297,9 +300,11 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) d_ += (float)dof[qs][ks][e] * (float)of[e];
         }
-        dl[qs] = group_sum(d_);
-        nlse2[qs] = qi < p.N ? -p.lse[((int64_t)b * p.H + h) * p.N + qi] * LOG2E : -1e30f;
-        if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = dl[qs];
+        const float nd = -group_sum(d_);
+        const float sl = qi < p.N ? -p.lse[((int64_t)b * p.H + h) * p.N + qi] * inv_scale : -1e30f;
+        sinit[qs] = f32x4{sl, sl, sl, sl};
+        dpinit[qs] = f32x4{nd, nd, nd, nd};
+        if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = nd;      // the dK/dV kernel wants -delta too
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -320,8 +325,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
         for (int nj = 0; nj < 4; ++nj) {
 #pragma unroll
             for (int qs = 0; qs < QS; ++qs) {
-                s[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s[qs][nj] = sinit[qs];
+                dp[qs][nj] = dpinit[qs];
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -334,15 +339,20 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
             }
         }
         bf16x8 f0[QS], f1[QS];
+        f32x4 bv2[4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
+            bv2[nj] = f32x4{bv[0] * LOG2E, bv[1] * LOG2E, bv[2] * LOG2E, bv[3] * LOG2E};
+        }
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = exp_sub(__builtin_fmaf(s[qs][nj][r], p.scale, bv[r]), nlse2[qs]);
-                    s[qs][nj][r] = pr * (dp[qs][nj][r] - dl[qs]);   // dS (w.r.t. the scaled logits)
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qs][nj][r], c2, bv2[nj][r]));
+                    s[qs][nj][r] = pr * dp[qs][nj][r];              // dS (w.r.t. the scaled logits)
                 }
             }
             f0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     float kb_[KB];
     bool kvalid[KB];
     f32x4 adk[KB][DT], adv[KB][DT];
+    const float ninv_scale = -1.0f / p.scale, c2 = p.scale * LOG2E;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int key = k0 + kb * 16 + li;
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             vf[kb][ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
         }
         kvalid[kb] = key < p.T;
-        kb_[kb] = kvalid[kb] ? p.bias[(int64_t)b * p.T + key] : -1e30f;        // keys past T: P = exp2(-huge) = 0
+        kb_[kb] = (kvalid[kb] ? p.bias[(int64_t)b * p.T + key] : -1e30f) * LOG2E;     // keys past T: P = exp2(-huge) = 0
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { adk[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
@@ -472,9 +483,14 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
 #pragma unroll
         for (int nq = 0; nq < 4; ++nq) {
 #pragma unroll
+            // accumulators start from the row constants: S' = q.k - lse/scale, dP' = dO.v - delta (dQ's kernel stored -delta)
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + nq * 16 + 4 * g);
+            const f32x4 cs = f32x4{ls[0] * ninv_scale, ls[1] * ninv_scale, ls[2] * ninv_scale, ls[3] * ninv_scale};
+            const f32x4 cd = *reinterpret_cast<const f32x4*>(del_s + nq * 16 + 4 * g);
+#pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                s[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s[kb][nq] = cs;
+                dp[kb][nq] = cd;
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -487,21 +503,15 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             }
         }
         bf16x8 pf0[KB], pf1[KB], sf0[KB], sf1[KB];
-        float nl2[4][4];
-#pragma unroll
-        for (int nq = 0; nq < 4; ++nq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) nl2[nq][r] = -lse_s[nq * 16 + 4 * g + r] * LOG2E;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
             for (int nq = 0; nq < 4; ++nq)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ql = nq * 16 + 4 * g + r;
-                    const float pr = exp_sub(__builtin_fmaf(s[kb][nq][r], p.scale, kb_[kb]), nl2[nq][r]);
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][nq][r], c2, kb_[kb]));
                     s[kb][nq][r] = pr;                                      // P
-                    dp[kb][nq][r] = pr * (dp[kb][nq][r] - del_s[ql]);       // dS
+                    dp[kb][nq][r] = pr * dp[kb][nq][r];                     // dS
                 }
             pf0[kb] = acc_to_frag(s[kb][0], s[kb][1]); pf1[kb] = acc_to_frag(s[kb][2], s[kb][3]);
             sf0[kb] = acc_to_frag(dp[kb][0], dp[kb][1]); sf1[kb] = acc_to_frag(dp[kb][2], dp[kb][3]);
