@@ -217,6 +217,10 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
 /* the two row-streaming products of that path: backward=0: io[rows, R] = a[rows, N] w2_b^T;
  * backward=1: io[rows, N] = bf16(bf16(a[rows, R] w2_b) + io)   (w2_b: bf16 [R, N], R = 8 or 16, N <= 128, N % 8 == 0) */
 int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, yat_stream_t stream);
+/* nn.Dropout(p) on a LoRA adapter's input (peft lora/layer.py [RECALL]; LoraConfig(lora_dropout=...) at common/trainer.py:215):
+ * keep(i) = hash(seed, i) >= p (counter-based, so the backward regenerates the mask); backward_add=0: io = bf16(x * keep / (1-p));
+ * backward_add=1: io = bf16(io + bf16(x * keep / (1-p)))  (gradient through the same mask, accumulated into an input gradient) */
+int yat_dropout(int64_t n, float p, uint64_t seed, int backward_add, const void* x, void* io, yat_stream_t stream);
 /* rank-R expansion over a whole layer width (plain LoRA, peft lora/layer.py [RECALL]; the reference's LoraConfig branch at
  * common/trainer.py:214-219): io[row, n] = f(sum_q h[row, q] * w[q, n]), h: bf16 [rows, R], w: bf16 [R, N], io: bf16 [rows, ldio];
  * residual=0: io = bf16(bf16(sum) * scale)  (lora_B(lora_A(x)) * scaling);  residual=1: io = bf16(bf16(sum) + io)  (dx += dT A) */

@@ -135,9 +135,42 @@ __global__ void mse_final_kernel(int nb, const float* partial, float inv_n, floa
     if (threadIdx.x == 0) loss[0] = s * inv_n;
 }
 
+// Counter-based dropout (LoRA's nn.Dropout on the adapter input, peft lora/layer.py [RECALL]): the keep decision of element i
+// is a hash of (seed, i) -- splitmix64 -- so the backward regenerates the mask instead of storing it.  torch's arithmetic:
+// out = x * mask * (1 / (1 - p)) evaluated in fp32, rounded once.
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t i, uint32_t thresh24) {
+    uint64_t z = i + seed * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40) >= thresh24;                    // 24 uniform bits against p * 2^24
+}
+// MODE 0: y = dropout(x);  MODE 1: io = bf16(io + dropout_mask(g))  (the gradient through the same mask)
+template <int MODE>
+__global__ void dropout_kernel(int64_t n, uint64_t seed, uint32_t thresh24, float inv_keep, const bf16_t* x, bf16_t* io) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = dropout_keep(seed, (uint64_t)i, thresh24) ? rbf(bf2f(x[i]) * inv_keep) : 0.f;
+        io[i] = f2bf(MODE == 0 ? v : v + bf2f(io[i]));
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int yat_dropout(int64_t n, float p, uint64_t seed, int backward_add, const void* x, void* io, yat_stream_t stream) {
+    if (n <= 0 || !(p >= 0.f && p < 1.f) || !x || !io) return YAT_EINVAL;
+    const uint32_t thresh = (uint32_t)(p * 16777216.0f);
+    const float inv_keep = 1.0f / (1.0f - p);
+    if (backward_add)
+        hipLaunchKernelGGL((dropout_kernel<1>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, seed, thresh, inv_keep,
+                           (const bf16_t*)x, (bf16_t*)io);
+    else
+        hipLaunchKernelGGL((dropout_kernel<0>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, seed, thresh, inv_keep,
+                           (const bf16_t*)x, (bf16_t*)io);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
 
 int yat_act_fwd(int64_t n, int act, const void* x, void* y, yat_stream_t stream) {
     if (n <= 0 || (act != 1 && act != 2) || !x || !y) return YAT_EINVAL;

@@ -482,7 +482,6 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
         f32x4 s[KB][4], dp[KB][4];
 #pragma unroll
         for (int nq = 0; nq < 4; ++nq) {
-#pragma unroll
             // accumulators start from the row constants: S' = q.k - lse/scale, dP' = dO.v - delta (dQ's kernel stored -delta)
             const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + nq * 16 + 4 * g);
             const f32x4 cs = f32x4{ls[0] * ninv_scale, ls[1] * ninv_scale, ls[2] * ninv_scale, ls[3] * ninv_scale};

@@ -200,6 +200,25 @@ def lokr_rows_bwd(h2d, wb, dx2d):
     return dx2d
 
 
+def dropout(x, p, seed, out=None):
+    """out = bf16(x * keep / (1 - p)) with the counter-based mask of (seed, element index) -- yat_dropout."""
+    _chk_bf16(x)
+    out = torch.empty_like(x) if out is None else out
+    if not (x.is_contiguous() and out.is_contiguous()):
+        raise ValueError("dropout: contiguous tensors only")
+    _l.check(_lib().yat_dropout(x.numel(), float(p), int(seed), 0, _p(x), _p(out), _stream()), "yat_dropout")
+    return out
+
+
+def dropout_bwd_add(g, p, seed, io):
+    """io += dropout-mask(g) / (1 - p): the gradient through the mask of (seed, element index), accumulated."""
+    _chk_bf16(g, io)
+    if g.shape != io.shape or not (g.is_contiguous() and io.is_contiguous()):
+        raise ValueError("dropout_bwd_add: shape mismatch")
+    _l.check(_lib().yat_dropout(g.numel(), float(p), int(seed), 1, _p(g), _p(io), _stream()), "yat_dropout")
+    return io
+
+
 def rank_expand(h2d, w, io2d, scale=1.0, residual=False):
     """io[rows, N] = bf16(bf16(h w) * scale), or bf16(bf16(h w) + io) with residual -- h2d [rows, R], w [R, N]; io2d may be a
     column block of a wider matrix (include/yat_hip.h: yat_rank_expand)."""
