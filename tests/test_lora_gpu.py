@@ -121,3 +121,65 @@ def test_rank_expand(rows, R, N, ld):
     want = (prod.float().to(BF).float() + buf[:, :N].float()).to(BF)
     ok = (out[:, :N].float() - want.float()).abs() <= 2.0 ** -7 * want.float().abs() + 2.0 ** -7 * prod.abs().float() + 1e-5 * mag
     assert ok.all() and torch.equal(out[:, N:], buf[:, N:])
+
+
+def test_dropout_kernel():
+    """Counter-based dropout: exact arithmetic (bf16(x / (1 - p)) or 0), keep rate, determinism per seed, and the backward's
+    mask is the forward's."""
+    from yat_amd import ops
+    n, p = 1 << 20, 0.3
+    x = torch.randn(n, generator=torch.Generator().manual_seed(0)).to(BF).to(DEV)
+    y = ops.dropout(x, p, seed=12345)
+    keep = y != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 3e-3, frac
+    want = (x.float() * (1.0 / (1.0 - p))).to(BF)
+    assert torch.equal(y[keep], want[keep])
+    assert torch.equal(y, ops.dropout(x, p, seed=12345)) and not torch.equal(y, ops.dropout(x, p, seed=12346))
+    # neighbouring elements are uncorrelated enough for a mask: lag-1 agreement ~ (1-p)^2 + p^2
+    agree = (keep[1:] == keep[:-1]).float().mean().item()
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 5e-3, agree
+    g, io0 = torch.randn(n, generator=torch.Generator().manual_seed(1)).to(BF).to(DEV), torch.randn(n).to(BF).to(DEV)
+    io = ops.dropout_bwd_add(g, p, 12345, io0.clone())
+    wantb = (io0.float() + torch.where(keep, (g.float() * (1.0 / (1.0 - p))).to(BF).float(), torch.zeros_like(g, dtype=torch.float32))).to(BF)
+    assert torch.equal(io, wantb)
+
+
+def test_lora_dropout_forward_backward_consistent():
+    """lora_dropout > 0: adapter output, input gradient and both weight gradients of one target against the fp64 formulas
+    evaluated with the very mask the kernels use (extracted by running the dropout kernel on ones)."""
+    from yat_amd import ops
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.lora import LoRAAdapters
+    cfg = SanaConfig(num_layers=1, num_attention_heads=4, attention_head_dim=32, num_cross_attention_heads=2,
+                     cross_attention_head_dim=64, cross_attention_dim=128, caption_channels=96, in_channels=8, out_channels=8,
+                     sample_size=8)
+    hip = SanaTransformer2DModelHIP(cfg, device=DEV).init_synthetic(0)
+    r, p = 4, 0.25
+    ad = LoRAAdapters(hip, ["to_out.0"], r=r, alpha=8.0, dropout=p, seed=7)
+    e = next(en for en in ad.entries if en["module"] == "transformer_blocks.0.attn1.to_out.0")
+    g = torch.Generator().manual_seed(5)
+    a, bt = ad._views(e, ad.flat_param)
+    bt[:r].copy_((torch.randn(r, e["out"], generator=g) * 0.2).to(BF))
+    ad.materialize(training=True)
+    M = 200
+    x, dy = torch.randn(M, e["inn"], generator=g).to(BF).to(DEV), torch.randn(M, e["out"], generator=g).to(BF).to(DEV)
+    dx0 = torch.randn(M, e["inn"], generator=g).to(BF).to(DEV)
+    w, gw = hip.P[e["key"]], hip.G[e["key"]]
+    mask = ops.dropout(torch.ones_like(x), p, ad._mask_seed(e)) != 0
+    assert 0.6 < mask.float().mean().item() < 0.9
+    out = ad.forward_term(x, w)
+    xd = torch.where(mask, (x.float() / (1 - p)).to(BF).double(), torch.zeros_like(x, dtype=torch.float64))
+    A, B, s = a[:r].double(), bt[:r].double().T, ad.scale
+    T = (xd @ A.T)
+    assert rel(out, (T @ B.T) * s) < 1e-2
+    dx = dx0.clone()
+    hs = ad.dgrad_term(dy, w, dx)
+    dT = (dy.double() @ B) * s
+    assert rel(dx.double() - dx0.double(), torch.where(mask, (dT @ A) / (1 - p), torch.zeros_like(xd))) < 2e-2
+    ad.wgrad(dy, x, gw, accumulate=False, hs=hs)
+    ga, gbt = ad._views(e, ad.flat_grad)
+    assert rel(ga[:r], dT.T @ xd) < 1e-2 and rel(gbt[:r], (T.T @ dy.double()) * s) < 1e-2
+    # eval mode: no mask
+    ad.materialize(training=False)
+    assert rel(ad.forward_term(x, w), ((x.double() @ A.T) @ B.T) * s) < 1e-2

@@ -229,7 +229,8 @@ class Model:
                 if getattr(p, "lora_use_dora", False):
                     raise NotImplementedError("DoRA is not built")
                 from ..lora import LoRAAdapters
-                self.adapters = LoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora)
+                self.adapters = LoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora,
+                                             seed=int(getattr(p, "dataset_seed", 0) or 0))
             else:                                                     # :226-230
                 from ..lokr import LoKrAdapters
                 self.adapters = LoKrAdapters(self.model, targets, rank, alpha, module_dropout=drop)

@@ -17,7 +17,9 @@ all-reduce are the usual single launches.  Per target and step:
     wgrad     d_B^T = scaling * T^T dy,  d_A = dT^T x  -- R x width outputs over a B*N-row reduction: yat_lokr_small_wgrad
 The dense weight gradients of the frozen base are never computed.  ``scaling`` is applied to the small side of each product
 (the reference rounds ``u * scaling`` and ``dy * scaling`` element-wise: identical when scaling is a power of two, one bf16
-rounding apart otherwise).  ``lora_dropout`` > 0 and DoRA are not built.
+rounding apart otherwise).  ``lora_dropout`` > 0: ``yat_dropout`` with a counter-based mask (hash of a per-(step, layer) seed and
+the element index) that forward, input gradient and weight gradient regenerate -- the mask *stream* cannot equal torch's
+Philox stream, the arithmetic (x * mask / (1 - p), one rounding) does.  DoRA is not built.
 """
 from __future__ import annotations
 
@@ -34,10 +36,11 @@ BF16 = torch.bfloat16
 
 
 class LoRAAdapters:
-    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0, use_rslora: bool = False):
-        if dropout and dropout > 0.0:
-            raise NotImplementedError("lora_dropout > 0 (element-wise dropout of the adapter input) is not built")
+    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0, use_rslora: bool = False, seed: int = 0):
+        if not (0.0 <= float(dropout or 0.0) < 1.0):
+            raise ValueError("lora_dropout must be in [0, 1)")
         self.model, self.r, self.alpha, self.use_rslora = model, int(r), float(alpha), bool(use_rslora)
+        self.dropout, self._seed, self._step = float(dropout or 0.0), int(seed), 0
         # [RECALL peft] scaling = lora_alpha / r, or lora_alpha / sqrt(r) with use_rslora
         self.scale = float(alpha) / (math.sqrt(int(r)) if use_rslora else int(r))
         self.targets = list(targets)
@@ -54,7 +57,7 @@ class LoRAAdapters:
             if out_dim % 8 or in_dim % 8:
                 raise NotImplementedError(f"{key}: LoRA needs layer widths that are multiples of 8")
             e = dict(module=key[:-7], key=key, out=out_dim, inn=in_dim, w_off=(w.data_ptr() - base_ptr) // 2,
-                     oa=off, ob=off + R * in_dim, active=True)
+                     oa=off, ob=off + R * in_dim, active=True, index=len(self.entries))
             off += R * (in_dim + out_dim)
             segs += [e["ob"], off]
             self.entries.append(e)
@@ -104,6 +107,17 @@ class LoRAAdapters:
     # ---- per step (interface of yat_amd/lokr.py)
     def materialize(self, training=True):
         self.join_pending_update()                 # nothing to build: the factors are used as they are
+        # nn.Dropout on the adapter input: a fresh mask per layer and step in training, none in eval.  The mask is a hash of
+        # (seed, element): forward, input gradient and weight gradient regenerate it from the per-(step, layer) seed.
+        self._drop = self.dropout if (training and self.dropout > 0.0) else 0.0
+        self._step += 1
+
+    def _mask_seed(self, e):
+        return (self._seed * 1000003 + self._step) * 4096 + e["index"]
+
+    def _dropped(self, e, x):
+        """dropout(x) for layer e (x itself when dropout is off)."""
+        return ops.dropout(x, self._drop, self._mask_seed(e)) if self._drop > 0.0 else x
 
     def forward_term(self, x, w):
         ents = self.lookup(w, self.model.flat_param)
@@ -116,7 +130,7 @@ class LoRAAdapters:
         for e, row0 in ents:
             a, bt = self._views(e, self.flat_param)
             t = torch.empty(M, R, dtype=BF16, device=x.device)
-            ops.gemm(x, a, t, M=M, N=R, K=e["inn"])                                        # T = x A^T
+            ops.gemm(self._dropped(e, x), a, t, M=M, N=R, K=e["inn"])                      # T = dropout(x) A^T
             ops.rank_expand(t, bt, tmp[:, row0:row0 + e["out"]], scale=self.scale)         # bf16(bf16(T B^T) * scaling)
             e["t"] = (x.data_ptr(), t)             # kept for d_B (see lokr.py on the lifetime)
         return tmp
@@ -129,7 +143,11 @@ class LoRAAdapters:
             dt = torch.empty(M, R, dtype=BF16, device=dy.device)
             ops.gemm(dy[:, row0:row0 + e["out"]], bt, dt, M=M, N=R, K=e["out"], lda=ld, ldb=e["out"], ldc=R,
                      gate=self._gate, ld_gate=0, rows_per_batch=M)                          # dT = scaling * (dy B)
-            ops.rank_expand(dt, a, dx, residual=True)                                       # dx += dT A
+            if self._drop > 0.0:                                                            # dx += mask * (dT A) / (1 - p)
+                g_ = ops.rank_expand(dt, a, torch.empty(M, e["inn"], dtype=BF16, device=dy.device))
+                ops.dropout_bwd_add(g_, self._drop, self._mask_seed(e), dx)
+            else:
+                ops.rank_expand(dt, a, dx, residual=True)                                   # dx += dT A
             hs[id(e)] = dt
         return hs
 
@@ -144,7 +162,7 @@ class LoRAAdapters:
                 t = kept[1]
             else:
                 t = torch.empty(M, R, dtype=BF16, device=x.device)
-                ops.gemm(x, a, t, M=M, N=R, K=e["inn"])
+                ops.gemm(self._dropped(e, x), a, t, M=M, N=R, K=e["inn"])
             dt = hs.get(id(e)) if hs else None
             if dt is None:
                 dt = torch.empty(M, R, dtype=BF16, device=dy.device)
@@ -153,7 +171,7 @@ class LoRAAdapters:
             else:
                 dt.record_stream(torch.cuda.current_stream())
             ops.lokr_small_wgrad(t, dyb, gbt[:self.r], accumulate=accumulate, scale=self.scale)   # d_B^T = scaling T^T dy
-            ops.lokr_small_wgrad(dt, x, ga[:self.r], accumulate=accumulate)                       # d_A = dT^T x
+            ops.lokr_small_wgrad(dt, self._dropped(e, x), ga[:self.r], accumulate=accumulate)     # d_A = dT^T dropout(x)
 
     def project(self):
         if self.grad_ready is not None:            # gradients are complete as written; only the DDP hook remains
@@ -182,7 +200,7 @@ class LoRAAdapters:
         save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
                   os.path.join(path, "adapter_model.safetensors"))
         with open(os.path.join(path, "adapter_config.json"), "w") as f:
-            json.dump({"peft_type": "LORA", "r": self.r, "lora_alpha": self.alpha, "lora_dropout": 0.0,
+            json.dump({"peft_type": "LORA", "r": self.r, "lora_alpha": self.alpha, "lora_dropout": self.dropout,
                        "target_modules": self.targets, "use_dora": False, "use_rslora": self.use_rslora, "bias": "none",
                        "init_lora_weights": True}, f, indent=2)
 
