@@ -31,8 +31,11 @@ class LoRAWrapped(nn.Module):
             p.requires_grad_(False)
         self.conv = isinstance(base, nn.Conv2d)
         if self.conv:
-            assert base.kernel_size == (1, 1), "only 1x1 convolutions are targeted in SANA"
-            out_dim, in_dim = base.out_channels, base.in_channels
+            # [RECALL] lora_A = Conv2d(in, r, kernel_size, stride, padding) of the base conv, lora_B = Conv2d(r, out, 1):
+            # SANA's targets are 1x1; PixArt's PatchEmbed projection is k = s = 2 (lora_A held as [r, in*k*k], reshaped on use)
+            assert base.kernel_size == base.stride and base.padding == (0, 0)
+            self.k = base.kernel_size[0]
+            out_dim, in_dim = base.out_channels, base.in_channels * self.k * self.k
         else:
             out_dim, in_dim = base.out_features, base.in_features
         dt = base.weight.dtype
@@ -46,7 +49,8 @@ class LoRAWrapped(nn.Module):
         result = self.base_layer(x)
         xin = self.dropout(x.to(self.lora_A.dtype))
         if self.conv:
-            u = F.conv2d(F.conv2d(xin, self.lora_A[:, :, None, None]), self.lora_B[:, :, None, None])
+            a4 = self.lora_A.view(self.r, -1, self.k, self.k)
+            u = F.conv2d(F.conv2d(xin, a4, stride=self.k), self.lora_B[:, :, None, None])
         else:
             u = F.linear(F.linear(xin, self.lora_A), self.lora_B)
         return result + u * self.scaling

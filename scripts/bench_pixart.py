@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--gemm-detail", default=None)
     ap.add_argument("--roofline-steps", type=int, default=2)
+    ap.add_argument("--lora", type=int, default=0, metavar="RANK", help="plain LoRA adapters of this rank on a frozen base")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU (the HIP path has no CPU fallback)")
@@ -56,7 +57,13 @@ def main():
     cfg = PixArtConfig(num_layers=args.layers)
     model = PixArtTransformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
     log(f"PixArt-Sigma: {args.layers} blocks, {model.numel_flat / 1e6:.1f} M parameters")
-    opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0, overlap_update=True)
+    trained = model
+    if args.lora:
+        from yat_amd.lora import LoRAAdapters
+        trained = LoRAAdapters(model, ["to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"], r=args.lora,
+                               alpha=float(args.lora))
+        log(f"LoRA rank {args.lora}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
+    opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0, overlap_update=True)
     recipe = PixArtRecipe(model, device=dev)
     B, T, Cc = args.batch, 300, cfg.caption_channels
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -127,7 +134,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"train_pixart_sigma.py: PixArt-Sigma-XL-2 (D=1152, 16x72 heads, {cfg.num_layers} blocks) 1024px, "
-                               f"bf16, full fine-tune, cached latents/T5 embeds, aspect buckets {BUCKETS} round-robin, T=300, "
+                               f"bf16, {'LoRA rank %d on a frozen base' % args.lora if args.lora else 'full fine-tune'}, cached latents/T5 embeds, aspect buckets {BUCKETS} round-robin, T=300, "
                                "DDPM eps-prediction, AdamW+clip", "per_gpu_batch": B, "seq_len": 4096, "params": model.numel_flat},
         "loss": loss_val, "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),

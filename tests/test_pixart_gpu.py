@@ -230,3 +230,56 @@ def test_overfits_a_fixed_batch():
     print("[pixart] overfit losses:", [round(x, 4) for x in losses[::5]], round(losses[-1], 4))
     assert all(l == l and l < 1e4 for l in losses)
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def test_pixart_lora_step_matches_oracle():
+    """LoRA adapters (lora_algo: lora) on the PixArt-Sigma path: the adapter hooks of the model are the same as SANA's.
+    One adapted step on the tiny configuration vs the oracle's peft-wrapped model in bf16 and fp32."""
+    from oracle.pixart_ref import DDPMSchedule as RefSched, pixart_optimize_ref
+    from oracle.lora_ref import apply_lora, LoRAWrapped
+    from yat_amd.recipe import PixArtRecipe
+    from yat_amd.lora import LoRAAdapters
+    targets = ["to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
+    ref_bf, _, hip, latents, embs, noise = _setup(dict(num_layers=2), 2, 12, 20, [7, 40])
+    r = 4
+    ad = LoRAAdapters(hip, targets, r=r, alpha=4.0)
+    g = torch.Generator().manual_seed(21)
+    for e in ad.entries:
+        _, bt = ad._views(e, ad.flat_param)
+        bt[:r].copy_((torch.randn(r, e["out"], generator=g) * 0.05).to(BF))
+    wrapped = apply_lora(ref_bf, targets, r=r, alpha=4.0)
+    assert sorted(wrapped) == sorted(e["module"] for e in ad.entries) and "transformer_blocks.0.ff.net.0.proj" in wrapped
+    sd = ad.state_dict()
+    for name, w in wrapped.items():
+        with torch.no_grad():
+            w.lora_A.copy_(sd[f"base_model.model.{name}.lora_A.weight"].cpu())
+            w.lora_B.copy_(sd[f"base_model.model.{name}.lora_B.weight"].cpu())
+    ref_32 = copy.deepcopy(ref_bf).float()
+    outs = {}
+    for tag, model, cast in (("bf16", ref_bf, lambda t: t), ("fp32", ref_32, lambda t: t.float())):
+        model.train()
+        loss, out, _, _ = pixart_optimize_ref(model, RefSched(), cast(latents), [cast(e_) for e_ in embs], cast(noise),
+                                              torch.Generator(), 64, True)
+        loss.backward()
+        outs[tag] = (loss.detach(), out.detach(), {n: (m.lora_A.grad, m.lora_B.grad) for n, m in model.named_modules()
+                                                  if isinstance(m, LoRAWrapped)})
+    recipe = PixArtRecipe(hip, pad_to=64, device=DEV)
+    hip.train()
+    base = hip.flat_param.clone()
+    loss, out, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True, noise=noise.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    e_h, e_r = rel(out, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
+    print(f"[pixart] lora out hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
+    assert e_h <= 1.3 * e_r + 1e-3
+    hip_g, bf_g, f_g = [], [], []
+    for e in ad.entries:
+        ga, gbt = ad._views(e, ad.flat_grad)
+        hip_g += [ga[:r].float().flatten().cpu(), gbt[:r].t().float().flatten().cpu()]
+        bf_g += [t.float().flatten() for t in outs["bf16"][2][e["module"]]]
+        f_g += [t.float().flatten() for t in outs["fp32"][2][e["module"]]]
+    hg, bg, fg = torch.cat(hip_g), torch.cat(bf_g), torch.cat(f_g)
+    e_h, e_r = rel(hg, fg), rel(bg, fg)
+    print(f"[pixart] lora adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
+    assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.3 * e_r + 2e-3
+    assert torch.equal(base, hip.flat_param)

@@ -16,6 +16,7 @@ gradients and the text branch on a second stream).  What differs from SANA is on
 * attn2 reads the projected captions directly (no RMSNorm), T = 300 padded keys;
 * the FFN is Linear(D, 4D) -> GELU(tanh) -> Linear(4D, D): two GEMMs with fused bias+activation / bias+gate+residual epilogues;
 * the head emits 2C channels (learned sigma); unpatchify is ``yat_patch_rearrange`` in the "nhwpqc" order.
+PEFT adapters (yat_amd/lora.py, yat_amd/lokr.py) hook in exactly as in yat_amd/sana.py: ``lin`` / ``dgrad`` / ``wgrad``.
 """
 from __future__ import annotations
 
@@ -185,9 +186,10 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
 
     # ------------------------------------------------------------------ forward
     def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None, kv_work=None):
-        if self.adapters is not None:
-            raise NotImplementedError("PEFT adapters are built for the SANA path only")
         cfg, P = self.cfg, self.P
+        ad = self.adapters
+        if ad is not None:
+            ad.materialize(self.training)                     # yat_amd/lora.py / lokr.py: this step's adapter state
         D, H, dh, p = cfg.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim, cfg.patch_size
         B, Cin, Hl, Wl = latents.shape
         if Hl % p or Wl % p:
@@ -214,10 +216,16 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, Hl=Hl, Wl=Wl, key_bias=key_bias, kv_len=kv_len,
                             kv_work=kv_work, enc2d=enc2d, blocks=[])
         buf = self._buf
-        lin = ops.linear_fwd
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None
+
+        def lin(x_, w_, bias_=None, out=None, **ep):
+            """Linear of a (possibly adapted) target: the adapter term is folded in through the GEMM's pre_add epilogue."""
+            tmp = ad.forward_term(x_, w_) if ad is not None else None
+            if tmp is None:
+                return ops.linear_fwd(x_, w_, bias_, out=out, **ep)
+            return ops.linear_fwd(x_, w_, bias_, out=out, pre_add=tmp, **ep)
 
         def params_ready(bucket, stream=main):
             if pev is not None:
@@ -336,9 +344,23 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         ws_ln = buf("ws_ln", (ops.ln_bwd_workspace_bytes(M, D, N),), u8)
         ws_gate = buf("ws_gate", (int(lib.yat_gate_bwd_workspace_bytes(M, D, N)),), u8)
         scale = 1.0 / math.sqrt(dh)
-        dgrad = ops.linear_dgrad
+        ad = self.adapters
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
+        pending_ad = []                   # adapter weight gradients wait for the H product of the dgrad of the same dy
+
+        def dgrad(dy_, w_, out=None, residual=None):
+            r_ = ops.linear_dgrad(dy_, w_, out=out, residual=residual)
+            if ad is not None:
+                hs = ad.dgrad_term(dy_, w_, r_)
+                keep = []
+                for item in pending_ad:
+                    if item[0].data_ptr() == dy_.data_ptr():
+                        off_chain(lambda item=item, hs=hs: ad.wgrad(*item, accumulate=acc, hs=hs))
+                    else:
+                        keep.append(item)
+                pending_ad[:] = keep
+            return r_
 
         def off_chain(fn):
             """Weight / bias / table gradients: nothing on the dependent chain reads them -> second stream, right behind
@@ -350,7 +372,14 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             with torch.cuda.stream(side):
                 fn()
 
-        def wgrad(dy, x, gw, gbias=None):
+        def wgrad(dy, x, gw, gbias=None, dgrad_follows=True):
+            if ad is not None:            # frozen base: only the adapters' share, launched by the dgrad() of the same dy
+                if dgrad_follows:
+                    pending_ad.append((dy, x, gw))
+                else:
+                    off_chain(lambda: ad.wgrad(dy, x, gw, accumulate=acc))
+                return
+
             def run():
                 ops.linear_wgrad(dy, x, gw, accumulate=acc)
                 if gbias is not None:
@@ -389,7 +418,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate,
                          dbias=G[pre + "ff.net.2.bias"], accumulate_bias=acc)
             wgrad(dlin3, A.f1, G[pre + "ff.net.2.weight"])
-            if self.fuse_act_bwd:               # see __init__: measured slower in the step, kept as a switch
+            if self.fuse_act_bwd and ad is None:   # see __init__: measured slower in the step, kept as a switch
                 dz = ops.linear_dgrad_act(dlin3, P[pre + "ff.net.2.weight"], A.z, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
             else:
                 df1 = dgrad(dlin3, P[pre + "ff.net.2.weight"], out=buf("df1", (M, 4 * D)))
@@ -412,8 +441,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
 
             def text_grads(dkv2=dkv2, wkv=wkv, gkv=gkv, gbkv=gbkv, first=(i == cfg.num_layers - 1)):
-                ops.linear_wgrad(dkv2, S.encp, gkv, accumulate=acc)
-                ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
+                wgrad(dkv2, S.encp, gkv, gbkv)
                 dgrad(dkv2, wkv, out=denc, residual=None if first else denc)      # the text-side chain lives on this stream
             off_chain(text_grads)
             # x1 = x + gate_msa * lin1
@@ -449,12 +477,12 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         if side is not None:
             main.wait_stream(side)
             side = None
-        wgrad(dx, S.x_tok, G["pos_embed.proj.weight"].view(D, Kp), G["pos_embed.proj.bias"])     # + pos_embed: identity
+        wgrad(dx, S.x_tok, G["pos_embed.proj.weight"].view(D, Kp), G["pos_embed.proj.bias"], dgrad_follows=False)   # + pos_embed: identity
         # caption branch: encp = linear_2(gelu_tanh(linear_1(enc)))
         wgrad(denc, S.c1, G["caption_projection.linear_2.weight"], G["caption_projection.linear_2.bias"])
         dc1 = dgrad(denc, P["caption_projection.linear_2.weight"], out=buf("dc1", (Mt, D)))
         dzc1 = ops.act_bwd(S.zc1, dc1, "gelu_tanh", buf("dzc1", (Mt, D)))
-        wgrad(dzc1, S.enc2d, G["caption_projection.linear_1.weight"], G["caption_projection.linear_1.bias"])
+        wgrad(dzc1, S.enc2d, G["caption_projection.linear_1.weight"], G["caption_projection.linear_1.bias"], dgrad_follows=False)
         # timestep branch
         pre = "adaln_single."
         dtmod_b = ops.f32_to_bf16(dtmod, buf("dtmod_b", (B, 6 * D)))
@@ -466,9 +494,13 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         wgrad(d_emb, S.e1, G[pre + "emb.timestep_embedder.linear_2.weight"], G[pre + "emb.timestep_embedder.linear_2.bias"])
         de1 = dgrad(d_emb, P[pre + "emb.timestep_embedder.linear_2.weight"], out=buf("te_d2", (B, D)))
         dz1 = ops.act_bwd(S.z1, de1, "silu", buf("te_d3", (B, D)))
-        wgrad(dz1, S.tproj, G[pre + "emb.timestep_embedder.linear_1.weight"], G[pre + "emb.timestep_embedder.linear_1.bias"])
+        wgrad(dz1, S.tproj, G[pre + "emb.timestep_embedder.linear_1.weight"], G[pre + "emb.timestep_embedder.linear_1.bias"],
+              dgrad_follows=False)
         if self.grad_ready is not None:
             self.grad_ready(0)
+        if ad is not None:
+            assert not pending_ad, "an adapter weight gradient was queued without a following dgrad()"
+            ad.project()                  # adapter gradients complete (LoKr: d_P -> d_w1, d_w2_a; DDP hook)
 
     # ------------------------------------------------------------------ checkpoint I/O (diffusers layout)
     def save_pretrained(self, path):
