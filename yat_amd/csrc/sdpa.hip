@@ -567,6 +567,7 @@ int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
 }
 template <int KS, int DT>
 int launch_fwd(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    if (wide == 2) return launch_fwd_qs<KS, DT, 3>(p, B, stream);          // 192-query workgroups
     return wide ? launch_fwd_qs<KS, DT, 2>(p, B, stream) : launch_fwd_qs<KS, DT, 1>(p, B, stream);
 }
 template <int KS, int DT, int QS>
@@ -634,7 +635,11 @@ int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
     // 128-query workgroups once there are enough of them to fill the chip twice over (PixArt-Sigma: N = 4096)
     static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
-    const int wide = wide_env >= 0 ? wide_env : ((int64_t)((N + 127) / 128) * H * B >= 1024);
+    // ... and 192-query ones (three sub-tiles per wave: K / V fragments feed three MFMAs, 236 registers) while the head dim
+    // leaves room for them at two waves per SIMD (dh <= 80): 1.26 -> 1.17 ms at N = T = 4096, dh 72
+    int wide = (int64_t)((N + 127) / 128) * H * B >= 1024;
+    if (dh <= 80 && (int64_t)((N + 191) / 192) * H * B >= 1024) wide = 2;
+    if (wide_env >= 0) wide = wide_env;
     return YAT_SDPA_DISPATCH(launch_fwd, dh, p, B, wide, (hipStream_t)stream);
 }
 
