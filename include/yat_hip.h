@@ -153,8 +153,7 @@ int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q,
  * grid over all T/64 tiles with early exit (correct, but idle LDS-heavy workgroups cost ~0.24 us each).
  * parts: 1 = dQ and delta (what the dependent chain needs), 2 = dK/dV (reads delta; feeds only the text-side weight
  * gradients, so the caller may run it on another stream after part 1), 3 = both.
- * delta (float [B, H, N], caller-owned scratch): part 1 writes -rowsum(dO * O) there (the sign the accumulator-initialised
- * products of part 2 consume directly); its content is private to the two parts. */
+ * delta (float [B, H, N], caller-owned scratch): part 1 writes rowsum(dO * O) there for part 2. */
 int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
                  const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,

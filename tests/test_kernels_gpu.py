@@ -433,7 +433,9 @@ def _sdpa_ref(q, k, v, bias, B, N, T, H, dh, scale):
     (16, 256, 150, 32, 72, [150, 149, 64, 1] * 4), (8, 130, 130, 64, 112, [130, 64, 65, 2] * 2),
     (32, 130, 70, 16, 128, [70, 1, 64, 33] * 8),
     # ceil(N/192) * H * B >= 1024 and dh <= 80: the 192-query forward
-    (16, 400, 150, 32, 72, [150, 149, 64, 1] * 4), (8, 200, 100, 128, 32, [100, 3] * 4), (16, 385, 90, 32, 64, [90, 17] * 8)])
+    (16, 400, 150, 32, 72, [150, 149, 64, 1] * 4), (8, 200, 100, 128, 32, [100, 3] * 4), (16, 385, 90, 32, 64, [90, 17] * 8),
+    # ceil(T/128) * H * B >= 1024, dh <= 80, dense grid: dK/dV with 32 keys per wave (ragged T: partial last workgroup)
+    (8, 150, 300, 64, 72, [300, 299, 130, 0, 64, 1, 200, 257]), (16, 100, 200, 32, 32, [200, 5] * 8)])
 def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
     D = H * dh
     scale = 1.0 / math.sqrt(dh)

@@ -282,10 +282,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     stage(0, smem);
 
     bf16x8 qf[QS][KS], dof[QS][KS];
-    // Row constants ride in the MFMA accumulators: S' = q.k - lse/scale and dP' = dO.v - delta start from these tuples, so
-    // p = exp2(S' * scale*log2e + bias*log2e) needs no subtraction and dS = p * dP' no second one (queries past N: -1e30 -> P = 0)
-    f32x4 sinit[QS], dpinit[QS];
-    const float inv_scale = 1.0f / p.scale, c2 = p.scale * LOG2E;
+    float dl[QS], nlse2[QS];                     // nlse2 = -lse * log2e (queries past N: -1e30 -> P = 0)
     f32x4 acc[QS][DT];
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
@@ -300,11 +297,9 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) d_ += (float)dof[qs][ks][e] * (float)of[e];
         }
-        const float nd = -group_sum(d_);
-        const float sl = qi < p.N ? -p.lse[((int64_t)b * p.H + h) * p.N + qi] * inv_scale : -1e30f;
-        sinit[qs] = f32x4{sl, sl, sl, sl};
-        dpinit[qs] = f32x4{nd, nd, nd, nd};
-        if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = nd;      // the dK/dV kernel wants -delta too
+        dl[qs] = group_sum(d_);
+        nlse2[qs] = qi < p.N ? -p.lse[((int64_t)b * p.H + h) * p.N + qi] * LOG2E : -1e30f;
+        if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = dl[qs];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -325,8 +320,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
         for (int nj = 0; nj < 4; ++nj) {
 #pragma unroll
             for (int qs = 0; qs < QS; ++qs) {
-                s[qs][nj] = sinit[qs];
-                dp[qs][nj] = dpinit[qs];
+                s[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -339,20 +334,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
             }
         }
         bf16x8 f0[QS], f1[QS];
-        f32x4 bv2[4];
-#pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
-            bv2[nj] = f32x4{bv[0] * LOG2E, bv[1] * LOG2E, bv[2] * LOG2E, bv[3] * LOG2E};
-        }
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qs][nj][r], c2, bv2[nj][r]));
-                    s[qs][nj][r] = pr * dp[qs][nj][r];              // dS (w.r.t. the scaled logits)
+                    const float pr = exp_sub(__builtin_fmaf(s[qs][nj][r], p.scale, bv[r]), nlse2[qs]);
+                    s[qs][nj][r] = pr * (dp[qs][nj][r] - dl[qs]);   // dS (w.r.t. the scaled logits)
                 }
             }
             f0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
@@ -436,7 +426,6 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     float kb_[KB];
     bool kvalid[KB];
     f32x4 adk[KB][DT], adv[KB][DT];
-    const float ninv_scale = -1.0f / p.scale, c2 = p.scale * LOG2E;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int key = k0 + kb * 16 + li;
@@ -447,7 +436,7 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             vf[kb][ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
         }
         kvalid[kb] = key < p.T;
-        kb_[kb] = (kvalid[kb] ? p.bias[(int64_t)b * p.T + key] : -1e30f) * LOG2E;     // keys past T: P = exp2(-huge) = 0
+        kb_[kb] = kvalid[kb] ? p.bias[(int64_t)b * p.T + key] : -1e30f;        // keys past T: P = exp2(-huge) = 0
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { adk[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
@@ -479,53 +468,110 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
         const float* lse_s = reinterpret_cast<const float*>(cur + 2 * TILE);
         const float* del_s = lse_s + 64;
 
-        f32x4 s[KB][4], dp[KB][4];
+        if constexpr (KB == 1) {
+            f32x4 s[KB][4], dp[KB][4];
 #pragma unroll
-        for (int nq = 0; nq < 4; ++nq) {
-            // accumulators start from the row constants: S' = q.k - lse/scale, dP' = dO.v - delta (dQ's kernel stored -delta)
-            const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + nq * 16 + 4 * g);
-            const f32x4 cs = f32x4{ls[0] * ninv_scale, ls[1] * ninv_scale, ls[2] * ninv_scale, ls[3] * ninv_scale};
-            const f32x4 cd = *reinterpret_cast<const f32x4*>(del_s + nq * 16 + 4 * g);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                s[kb][nq] = cs;
-                dp[kb][nq] = cd;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qfr = frag_row_tr(Qt, nq * 16, ks, lane), ofr = frag_row_tr(Ot, nq * 16, ks, lane);
+            for (int nq = 0; nq < 4; ++nq) {
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
-                    s[kb][nq] = mfma16(qfr, kf[kb][ks], s[kb][nq]);     // [q = 16nq+4g+r][key = li]
-                    dp[kb][nq] = mfma16(ofr, vf[kb][ks], dp[kb][nq]);
+                    s[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dp[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qfr = frag_row_tr(Qt, nq * 16, ks, lane), ofr = frag_row_tr(Ot, nq * 16, ks, lane);
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        s[kb][nq] = mfma16(qfr, kf[kb][ks], s[kb][nq]);     // [q = 16nq+4g+r][key = li]
+                        dp[kb][nq] = mfma16(ofr, vf[kb][ks], dp[kb][nq]);
+                    }
                 }
             }
-        }
-        bf16x8 pf0[KB], pf1[KB], sf0[KB], sf1[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
+            bf16x8 pf0[KB], pf1[KB], sf0[KB], sf1[KB];
+            float nl2[4][4];
 #pragma unroll
             for (int nq = 0; nq < 4; ++nq)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][nq][r], c2, kb_[kb]));
-                    s[kb][nq][r] = pr;                                      // P
-                    dp[kb][nq][r] = pr * dp[kb][nq][r];                     // dS
-                }
-            pf0[kb] = acc_to_frag(s[kb][0], s[kb][1]); pf1[kb] = acc_to_frag(s[kb][2], s[kb][3]);
-            sf0[kb] = acc_to_frag(dp[kb][0], dp[kb][1]); sf1[kb] = acc_to_frag(dp[kb][2], dp[kb][3]);
-        }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 o0 = frag_tr_acc(Ot, 0, dt * 16, lane), o1 = frag_tr_acc(Ot, 32, dt * 16, lane);
-            const bf16x8 q0f = frag_tr_acc(Qt, 0, dt * 16, lane), q1f = frag_tr_acc(Qt, 32, dt * 16, lane);
+                for (int r = 0; r < 4; ++r) nl2[nq][r] = -lse_s[nq * 16 + 4 * g + r] * LOG2E;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                adv[kb][dt] = mfma16(o0, pf0[kb], adv[kb][dt]);
-                adv[kb][dt] = mfma16(o1, pf1[kb], adv[kb][dt]);
-                adk[kb][dt] = mfma16(q0f, sf0[kb], adk[kb][dt]);
-                adk[kb][dt] = mfma16(q1f, sf1[kb], adk[kb][dt]);
+#pragma unroll
+                for (int nq = 0; nq < 4; ++nq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = nq * 16 + 4 * g + r;
+                        const float pr = exp_sub(__builtin_fmaf(s[kb][nq][r], p.scale, kb_[kb]), nl2[nq][r]);
+                        s[kb][nq][r] = pr;                                      // P
+                        dp[kb][nq][r] = pr * (dp[kb][nq][r] - del_s[ql]);       // dS
+                    }
+                pf0[kb] = acc_to_frag(s[kb][0], s[kb][1]); pf1[kb] = acc_to_frag(s[kb][2], s[kb][3]);
+                sf0[kb] = acc_to_frag(dp[kb][0], dp[kb][1]); sf1[kb] = acc_to_frag(dp[kb][2], dp[kb][3]);
             }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 o0 = frag_tr_acc(Ot, 0, dt * 16, lane), o1 = frag_tr_acc(Ot, 32, dt * 16, lane);
+                const bf16x8 q0f = frag_tr_acc(Qt, 0, dt * 16, lane), q1f = frag_tr_acc(Qt, 32, dt * 16, lane);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    adv[kb][dt] = mfma16(o0, pf0[kb], adv[kb][dt]);
+                    adv[kb][dt] = mfma16(o1, pf1[kb], adv[kb][dt]);
+                    adk[kb][dt] = mfma16(q0f, sf0[kb], adk[kb][dt]);
+                    adk[kb][dt] = mfma16(q1f, sf1[kb], adk[kb][dt]);
+                }
+            }
+    
+        } else {
+            // two halves of 32 queries: S / dP, the softmax and the P / dS fragments of a half are dead before the next one starts
+            // (half the live score registers: 32 keys per wave then fit two waves per SIMD; at 16 keys per wave -- the
+            // branch above -- all four 16-query tiles stay in flight, which measured 3-15 % faster there)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 s[KB][2], dp[KB][2];
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    const int nq = 2 * half + hq;
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        s[kb][hq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        dp[kb][hq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const bf16x8 qfr = frag_row_tr(Qt, nq * 16, ks, lane), ofr = frag_row_tr(Ot, nq * 16, ks, lane);
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) {
+                            s[kb][hq] = mfma16(qfr, kf[kb][ks], s[kb][hq]);     // [q = 16nq+4g+r][key = li]
+                            dp[kb][hq] = mfma16(ofr, vf[kb][ks], dp[kb][hq]);
+                        }
+                    }
+                }
+                bf16x8 pf[KB], sf[KB];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // the same arithmetic as the 16-key branch: dense and work-list launches agree bit for bit
+                            const int ql = (2 * half + hq) * 16 + 4 * g + r;
+                            const float pr = exp_sub(__builtin_fmaf(s[kb][hq][r], p.scale, kb_[kb]), -lse_s[ql] * LOG2E);
+                            s[kb][hq][r] = pr;                                  // P
+                            dp[kb][hq][r] = pr * (dp[kb][hq][r] - del_s[ql]);   // dS
+                        }
+                    pf[kb] = acc_to_frag(s[kb][0], s[kb][1]);
+                    sf[kb] = acc_to_frag(dp[kb][0], dp[kb][1]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 of = frag_tr_acc(Ot, 32 * half, dt * 16, lane), qf_ = frag_tr_acc(Qt, 32 * half, dt * 16, lane);
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        adv[kb][dt] = mfma16(of, pf[kb], adv[kb][dt]);
+                        adk[kb][dt] = mfma16(qf_, sf[kb], adk[kb][dt]);
+                    }
+                }
+            }
+    
         }
     }
 #pragma unroll
@@ -670,12 +716,15 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     if (!(parts & 2)) return YAT_OK;
     if (work_list && n_work > 0) { p.work = work_list; p.n_work = n_work; }
     // 128-key workgroups: dense grid only (the host's compact work list counts 64-key tiles)
-    // dK/dV keeps 64-key workgroups.  Both 128-key variants measured slower at N = T = 4096, dh 72 (dense grid only; the
-    // host's compact work list counts 64-key tiles) and stay behind YAT_SDPA_WIDE_KV: 1 = 8 waves x 16 keys (1.97 ms vs
-    // 1.80 ms: one workgroup per CU, eight waves per barrier), 2 = 4 waves x 32 keys (3.19 ms vs 2.37 ms before the VALU
-    // trims: 330 registers leave one wave per SIMD).
-    static const int wide_kv_env = getenv("YAT_SDPA_WIDE_KV") ? atoi(getenv("YAT_SDPA_WIDE_KV")) : 0;
-    const int wide_kv = p.work ? 0 : wide_kv_env;
+    // dK/dV: 128-key workgroups of 4 waves x 32 keys (code 2) on the dense grid (the host's compact work list counts 64-key
+    // tiles) while the head dim leaves the registers for two waves per SIMD (dh <= 80: 222 VGPRs once the query tile is
+    // walked in two 32-row halves): every Q / dO fragment read from LDS feeds two MFMAs -- 1.83 -> 1.42 ms at N = T = 4096,
+    // dh 72.  (Same shape with all four 16-query tiles in flight: 330 registers, one wave per SIMD, 3.19 vs 2.37 ms; code 1 =
+    // 8 waves x 16 keys: 1.97 vs 1.80 ms.  Both stay reachable through YAT_SDPA_WIDE_KV.)
+    static const int wide_kv_env = getenv("YAT_SDPA_WIDE_KV") ? atoi(getenv("YAT_SDPA_WIDE_KV")) : -1;
+    int wide_kv = (dh <= 80 && (int64_t)((T + 127) / 128) * H * B >= 1024) ? 2 : 0;
+    if (wide_kv_env >= 0) wide_kv = wide_kv_env;
+    if (p.work) wide_kv = 0;
     return YAT_SDPA_DISPATCH(launch_dkv, dh, p, B, wide_kv, (hipStream_t)stream);
 }
 
