@@ -147,6 +147,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         # the separate HBM-bound pass overlaps the second stream's MFMA-bound weight gradients for free, a longer epilogue
         # in a one-workgroup-per-CU GEMM does not.  Off by default.
         self.fuse_act_bwd = os.environ.get("YAT_FUSE_ACT_BWD", "0") != "0"
+        self.split_parts = os.environ.get("YAT_PIXART_SPLIT", "1") != "0"    # LN statistics / cross dK,dV off the chain
         self.pos_bf16_base = True         # the base-grid table is a module buffer: ``.to(bfloat16)`` rounds it (:52)
         self._pos = {}
 
@@ -424,17 +425,28 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
                 df1 = dgrad(dlin3, P[pre + "ff.net.2.weight"], out=buf("df1", (M, 4 * D)))
                 dz = ops.act_bwd(A.z, df1, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
             wgrad(dz, A.h2, G[pre + "ff.net.0.proj.weight"], G[pre + "ff.net.0.proj.bias"])
-            dh2 = dgrad(dz, P[pre + "ff.net.0.proj.weight"], out=buf("dh", (M, D)))
+            # this step is bound by the dependent chain (serialized kernel time 264 ms vs 247 ms per step), so what only
+            # parameters or the text side need leaves it: LayerNorm column statistics and the cross-attention dK/dV go to the
+            # second stream (their inputs then live in the parity-alternating buffers)
+            split = side is not None and self.split_parts
+            dh2 = dgrad(dz, P[pre + "ff.net.0.proj.weight"], out=buf(f"dh2.{par}" if split else "dh", (M, D)))
             other = dxb if dx is dxa else dxa
-            dx2 = ops.ln_modulate_bwd(A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2, dx,
-                                      buf(f"dx2.{par}", (M, D)), dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln)
+            ln2 = (A.x2, A.mean2, A.rstd2, mod2d[:, 4 * D:5 * D], 6 * D, N, dh2)
+            dx2 = ops.ln_modulate_bwd(*ln2, dx, buf(f"dx2.{par}", (M, D)), dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D,
+                                      ws_ln, parts=1 if split else 3)
+            if split:
+                off_chain(lambda ln2=ln2, dmod2d=dmod2d: ops.ln_modulate_bwd(
+                    *ln2, None, None, dmod2d[:, 3 * D:4 * D], dmod2d[:, 4 * D:5 * D], 6 * D, ws_ln, parts=2))
             # x2 = x1 + to_out(o2)
             wgrad(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"])
-            do2 = dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf("do", (M, D)))
+            do2 = dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf(f"do2.{par}" if split else "do", (M, D)))
             dq2 = buf(f"dq2.{par}", (M, D))
             dkv2 = buf(f"dkv2.{par}", (Mt, 2 * D))
-            ops.sdpa_bwd(A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H, dh, scale, S.key_bias, S.kv_len, A.o2, do2, A.lse,
-                         buf("delta", (B, H, N), f32), dq2, dkv2[:, :D], dkv2[:, D:], work=S.kv_work)
+            sd = (A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H, dh, scale, S.key_bias, S.kv_len, A.o2, do2, A.lse,
+                  buf(f"delta2.{par}" if split else "delta", (B, H, N), f32), dq2, dkv2[:, :D], dkv2[:, D:])
+            ops.sdpa_bwd(*sd, work=S.kv_work, parts=1 if split else 3)
+            if split:
+                off_chain(lambda sd=sd: ops.sdpa_bwd(*sd, work=S.kv_work, parts=2))
             wgrad(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"])
             dx1 = dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)      # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
@@ -456,9 +468,12 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             wqkv, gqkv = self._fused(pre + "attn1.to_q.weight", 3 * D, D)
             _, gbqkv = self._fused(pre + "attn1.to_q.bias", 3 * D)
             wgrad(dqkv, A.h1, gqkv, gbqkv)
-            dh1 = dgrad(dqkv, wqkv, out=buf("dh", (M, D)))
-            dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1, dx1, dx, dmod2d[:, 0:D],
-                                     dmod2d[:, D:2 * D], 6 * D, ws_ln)
+            dh1 = dgrad(dqkv, wqkv, out=buf(f"dh1.{par}" if split else "dh", (M, D)))
+            ln1 = (A.x_in, A.mean1, A.rstd1, mod2d[:, D:2 * D], 6 * D, N, dh1)
+            dx = ops.ln_modulate_bwd(*ln1, dx1, dx, dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln, parts=1 if split else 3)
+            if split:
+                off_chain(lambda ln1=ln1, dmod2d=dmod2d: ops.ln_modulate_bwd(
+                    *ln1, None, None, dmod2d[:, 0:D], dmod2d[:, D:2 * D], 6 * D, ws_ln, parts=2))
 
             def block_done(dmod=dmod, pre=pre, i=i):
                 ops.modulation_bwd(dmod, G[pre + "scale_shift_table"], dtmod, D, accumulate_table=acc)
