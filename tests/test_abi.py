@@ -87,3 +87,21 @@ def test_no_kernel_uses_scratch(built_lib):
         assert r.get("VGPRs Spill", 0) == 0, (name, r)
     gemm = {k: v for k, v in res.items() if "gemm256_kernel" in k}
     assert len(gemm) >= 10 and all(v["VGPRs"] + v.get("AGPRs", 0) <= 256 for v in gemm.values())     # 2 waves per SIMD
+
+
+def test_bad_arguments_of_the_widened_rows_are_rejected(built_lib):
+    """PixArt glue and adapter entry points: validation precedes any launch (fake non-null pointers are never dereferenced)."""
+    lib = ylib.load()
+    assert lib.yat_patch_rearrange(1, 4, 7, 8, 2, 1, 1, 1, 2, None) == -1                       # H % p != 0
+    assert lib.yat_patch_rearrange(1, 4, 8, 8, 2, 1, 1, 1, 1, None) == -1                       # in place
+    assert lib.yat_add_pos_embed(16, 4, 12, 1, 1, 1, None) == -1                                # D % 8 != 0
+    assert lib.yat_ddpm_add_noise(2, 64, 1, 1, None, 1, 1, None) == -1                          # null coefficient
+    assert lib.yat_mse_bf16_chunk(2, 64, 32, 1, 1, 1.0, 1, None, 1, None) == -1                 # stride < used
+    assert lib.yat_dropout(64, 1.0, 7, 0, 1, 1, None) == -1                                     # p must be < 1
+    assert lib.yat_rank_expand(16, 60, 8, 1, 1, 1, 64, 1.0, 0, None) == -1                      # N % 8 != 0
+    assert lib.yat_rank_expand(16, 64, 12, 1, 1, 1, 64, 1.0, 0, None) == -1                     # R must be 8 or 16
+    assert lib.yat_lokr_rows(16, 136, 8, 0, 1, 1, 1, None) == -1                                # N > 128
+    assert lib.yat_lokr_small_wgrad(16, 8, 64, 9, 1, 1, 64, 1, 64, 1.0, 0, 1, None) == -1       # r_out > R
+    assert lib.yat_lokr_small_wgrad(16, 8, 64, 8, 1, 1, 32, 1, 64, 1.0, 0, 1, None) == -1       # ldx < N
+    assert lib.yat_lokr_small_wgrad_workspace_bytes(32768, 8, 2240) == 32 * 8 * 18 * 128 * 4
+    assert lib.yat_sdpa_fwd(1, 64, 64, 1, 136, 0.1, 1, 136, 1, 1, 136, 1, None, 1, 136, None, None) == -1   # dh > 128
