@@ -283,3 +283,47 @@ def test_pixart_lora_step_matches_oracle():
     print(f"[pixart] lora adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
     assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.3 * e_r + 2e-3
     assert torch.equal(base, hip.flat_param)
+
+
+def test_real_width_block_matches_oracle():
+    """One block at the real width (D = 1152, 16 heads x 72, T5 width 4096, T = 300 padded keys) on 64x64 latents (1024
+    tokens, a non-base grid): the head-dim-72 attention instantiations, the K = 1152 / 4608 GEMM shapes and the GELU epilogue
+    against the oracle in bf16 and fp32 -- same criterion as the tiny configurations."""
+    from oracle.pixart_ref import (PixArtConfig as RefCfg, PixArtTransformerRef, init_like_pretrained,
+                                   DDPMSchedule as RefSched, pixart_optimize_ref)
+    from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
+    from yat_amd.recipe import PixArtRecipe
+    rcfg = RefCfg(num_layers=1)
+    ref = PixArtTransformerRef(rcfg)
+    init_like_pretrained(ref, 3)
+    ref_bf = copy.deepcopy(ref).to(BF)
+    ref_32 = copy.deepcopy(ref_bf).float()
+    hip = PixArtTransformer2DModelHIP(PixArtConfig(num_layers=1), device=DEV)
+    hip.load_state_dict(ref_bf.state_dict())
+    g = torch.Generator().manual_seed(17)
+    latents = (torch.randn(2, 4, 64, 64, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (300, 77)]
+    noise = torch.randn(2, 4, 64, 64, generator=g).to(BF)
+    loss_bf, out_bf, _, _ = pixart_optimize_ref(ref_bf, RefSched(), latents, embs, noise, torch.Generator(), 300, True)
+    loss_32, out_32, _, _ = pixart_optimize_ref(ref_32, RefSched(), latents.float(), [e.float() for e in embs], noise.float(),
+                                                torch.Generator(), 300, True)
+    loss_bf.backward()
+    loss_32.backward()
+    recipe = PixArtRecipe(hip, pad_to=300, device=DEV)
+    loss, out, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True, noise=noise.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
+    e_h, e_b = rel(out, out_32), rel(out_bf, out_32)
+    print(f"[pixart] real width: loss hip={l_h:.5f} oracle_bf16={l_b:.5f} fp32={l_t:.5f}; out hip={e_h:.3e} oracle_bf16={e_b:.3e}")
+    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 2.0 ** -7 * abs(l_t)
+    assert e_h <= 1.3 * e_b + 1e-3
+    p32 = dict(ref_32.named_parameters())
+    num_h = num_b = den = 0.0
+    for name, pb in ref_bf.named_parameters():
+        gh, gb, gt = hip.G[name].float().cpu(), pb.grad.float(), p32[name].grad.float()
+        assert torch.isfinite(gh).all(), name
+        num_h += (gh - gt).pow(2).sum().item(); num_b += (gb - gt).pow(2).sum().item(); den += gt.pow(2).sum().item()
+    tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
+    print(f"[pixart] real width: grads hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
+    assert tot_h <= 1.3 * tot_b + 1e-3
