@@ -198,3 +198,45 @@ def test_validation_sampler_matches_oracle():
     print(f"[parity] sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
     assert torch.isfinite(out.float()).all() and out.shape == x0.shape
     assert e_hip <= 1.3 * e_ref + 2e-3
+
+
+def test_real_width_block_matches_oracle():
+    """One SANA-1.6B block at the real width (D = 2240, 70 x 32 linear-attention heads, 20 x 112 cross-attention heads,
+    FFN 5600, caption width 2304, T = 512 padded keys) on 16x32 latents: the full-size GEMM shapes, head-dim-112 attention,
+    linear attention and the depthwise GLU against the oracle in bf16 and fp32."""
+    from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    rcfg = RefCfg(num_layers=1)
+    ref = SanaTransformerRef(rcfg)
+    init_like_pretrained(ref, 5)
+    ref_bf = copy.deepcopy(ref).to(BF)
+    ref_32 = copy.deepcopy(ref_bf).float()
+    hip = SanaTransformer2DModelHIP(SanaConfig(num_layers=1), device=DEV)
+    hip.load_state_dict(ref_bf.state_dict())
+    g = torch.Generator().manual_seed(23)
+    latents = (torch.randn(2, 32, 16, 32, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (300, 41)]
+    loss_bf, pred_bf, _ = optimize_ref(ref_bf, RefSched(), latents, embs, torch.Generator(), 512, BF)
+    loss_32, pred_32, _ = optimize_ref(ref_32, RefSched(), latents, embs, torch.Generator(), 512, torch.float32)
+    loss_bf.backward()
+    loss_32.backward()
+    recipe = SanaRecipe(hip, pad_to=512, device=DEV)
+    loss, pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
+    e_h, e_b = rel(pred, pred_32), rel(pred_bf, pred_32)
+    print(f"[parity] real width: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} fp32={l_t:.6f}; pred hip={e_h:.3e} oracle_bf16={e_b:.3e}")
+    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 1e-3 * abs(l_t)
+    assert e_h <= 1.3 * e_b + 1e-3
+    p32 = dict(ref_32.named_parameters())
+    num_h = num_b = den = 0.0
+    for name, pb in ref_bf.named_parameters():
+        gh, gb, gt = hip.G[name].float().cpu(), pb.grad.float(), p32[name].grad.float()
+        assert torch.isfinite(gh).all(), name
+        num_h += (gh - gt).pow(2).sum().item(); num_b += (gb - gt).pow(2).sum().item(); den += gt.pow(2).sum().item()
+    tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
+    print(f"[parity] real width: grads hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
+    assert tot_h <= 1.3 * tot_b + 1e-3
