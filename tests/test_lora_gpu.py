@@ -183,3 +183,39 @@ def test_lora_dropout_forward_backward_consistent():
     # eval mode: no mask
     ad.materialize(training=False)
     assert rel(ad.forward_term(x, w), ((x.double() @ A.T) @ B.T) * s) < 1e-2
+
+
+@pytest.mark.parametrize("kind", ["lora", "lokr"])
+def test_adapter_grad_accumulation_adds(kind):
+    """Two micro-steps on the same batch with accumulate_grads=True on the second must give twice the adapter gradients
+    (accelerator.accumulate with adapters: d_P / d_A / d_B accumulate in place, the LoKr projection runs on the sum)."""
+    from oracle.sana_ref import SanaConfig as RefCfg
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.lora import LoRAAdapters
+    from yat_amd.lokr import LoKrAdapters
+    rcfg = RefCfg.tiny(num_layers=1)
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV).init_synthetic(1)
+    g = torch.Generator().manual_seed(2)
+    if kind == "lora":
+        ad = LoRAAdapters(hip, TARGETS, r=4, alpha=4.0)
+        for e in ad.entries:
+            ad._views(e, ad.flat_param)[1][:4].copy_((torch.randn(4, e["out"], generator=g) * 0.05).to(BF))
+    else:
+        ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0)
+        for e in ad.entries:
+            w1 = ad._views(e, ad.flat_param)[0]
+            w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+    latents = (torch.randn(2, rcfg.in_channels, 4, 6, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (5, 9)]
+    recipe = SanaRecipe(hip, pad_to=16, device=DEV)
+    hip.train()
+    recipe.optimize(latents, embs, torch.Generator()).backward()
+    g1 = ad.flat_grad.clone()
+    assert g1.abs().max() > 0
+    hip.accumulate_grads = True
+    recipe.optimize(latents, embs, torch.Generator()).backward()
+    hip.accumulate_grads = False
+    torch.cuda.synchronize()
+    assert rel(ad.flat_grad, g1.float() * 2) <= 6e-3
