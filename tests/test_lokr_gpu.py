@@ -186,3 +186,36 @@ def test_lokr_training_step_matches_oracle(mode):
 def apply_names(model):
     from oracle.lokr_ref import LoKrWrapped
     return {n: m for n, m in model.named_modules() if isinstance(m, LoKrWrapped)}
+
+
+@pytest.mark.parametrize("mode", ["factored", "dense"])
+def test_lokr_module_dropout_drops_the_adapter(mode):
+    """peft's module dropout: a dropped adapter contributes nothing in that step -- prediction equals the base model's, its
+    gradients are zero; in eval mode it is always applied."""
+    from oracle.sana_ref import SanaConfig as RefCfg
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.lokr import LoKrAdapters
+    rcfg = RefCfg.tiny(num_layers=1)
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV).init_synthetic(1)
+    g = torch.Generator().manual_seed(4)
+    latents = (torch.randn(2, rcfg.in_channels, 4, 6, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (5, 9)]
+    recipe = SanaRecipe(hip, pad_to=16, device=DEV)
+    hip.train()
+    _, base_pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
+    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=1.0 - 1e-9, mode=mode)      # rand(1) > p: never
+    for e in ad.entries:
+        w1 = ad._views(e, ad.flat_param)[0]
+        w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+    loss, pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert all(not e["active"] for e in ad.entries)
+    assert torch.equal(pred, base_pred) and ad.flat_grad.abs().max().item() == 0
+    hip.eval()
+    with torch.no_grad():
+        enc, mask, _, _ = recipe.pad_embeddings(embs)
+        out = hip(latents.to(DEV), encoder_hidden_states=enc, timestep=torch.tensor([500.0, 20.0]), encoder_attention_mask=mask).sample
+    assert all(e["active"] for e in ad.entries) and torch.isfinite(out.float()).all()
