@@ -49,6 +49,25 @@ def _ddp_worker(rank, world, port, tmp):
     t = ddp.all_reduce_scalar_mean(torch.tensor([float(rank)]))
     assert t.item() == 0.5
 
+    # PEFT adapters under data parallel: the adapter set is the "model" HipDDP sees; its single bucket is reduced when
+    # project() (the last thing the backward does) reports the gradients complete
+    from yat_amd.lora import LoRAAdapters
+    base = type("Base", (), {})()
+    base.flat_param = torch.zeros(16 * 8 + 24 * 8, dtype=torch.bfloat16)
+    base.flat_grad = torch.zeros_like(base.flat_param)
+    base.P = {"blocks.0.to_q.weight": base.flat_param[:128].view(16, 8), "blocks.0.other.weight": base.flat_param[128:].view(24, 8)}
+    ad = LoRAAdapters(base, ["to_q"], r=2, alpha=2.0)
+    assert [e["module"] for e in ad.entries] == ["blocks.0.to_q"] and ad.num_parameters() == 2 * (8 + 16)
+    ddp_ad = HipDDP(ad)
+    ddp_ad.broadcast_parameters()                             # rank 0's kaiming draw everywhere
+    gathered = [torch.zeros_like(ad.flat_param, dtype=torch.float32) for _ in range(world)]
+    dist.all_gather(gathered, ad.flat_param.float())
+    assert torch.equal(gathered[0], gathered[1])
+    ad.flat_grad[:] = float(rank + 1)
+    ad.project()
+    ddp_ad.wait()
+    assert torch.all(ad.flat_grad.float() == 1.5)
+
     # bucket sampler consensus: both ranks must yield the same ratio at every step
     from tests.test_host_logic import _make_shards
     from yat_amd.common.aspect_ratios import ASPECT_RATIO_1024_BIN
