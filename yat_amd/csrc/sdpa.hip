@@ -113,6 +113,7 @@ struct SdpaP {
     uint64_t stat_bytes;             // bytes of the lse / delta arrays (B*H*N*4)
     uint64_t bias_bytes;             // bytes of the key-bias array (B*T*4)
     const int* work; int n_work;     // dK/dV kernel: compact list of (batch, key tile) pairs, or null for the dense grid
+    int xcd_remap;                   // workgroup index -> (tile, head, image) so that an XCD owns contiguous (image, head) runs
 };
 
 // ------------------------------------------------------------------------------------------ forward
@@ -128,8 +129,11 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);
+    // the query blocks of one (image, head) read the same K / V: give them to one XCD (one L2) instead of all eight
+    int bx, h, b;
+    if (p.xcd_remap) xcd_contiguous3(bx, h, b);
+    else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
+    const int q0 = bx * (64 * QS) + wave * (16 * QS);
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
@@ -260,8 +264,10 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);       // QS 16-query sub-tiles per wave, as in the forward
+    int bx, h, b;
+    if (p.xcd_remap) xcd_contiguous3(bx, h, b);
+    else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
+    const int q0 = bx * (64 * QS) + wave * (16 * QS);               // QS 16-query sub-tiles per wave, as in the forward
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
@@ -389,9 +395,10 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     // Work decomposition: launching early-exit workgroups of this LDS-heavy kernel is NOT free (measured: ~0.24 us
     // per idle workgroup, 230 us for the 70 % idle tiles of a T=512 / kv_len~160 batch), so the host hands a compact
     // (batch, key tile) list built from the embedding lengths it already knows; the dense grid remains as a fallback.
-    const int h = blockIdx.y;
-    const int b = p.work ? p.work[2 * blockIdx.x] : blockIdx.z;
-    const int tile = p.work ? p.work[2 * blockIdx.x + 1] : blockIdx.x;
+    int bx = blockIdx.x, h = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap && !p.work) xcd_contiguous3(bx, h, bz);         // key tiles of one (image, head) share Q / dO in one L2
+    const int b = p.work ? p.work[2 * bx] : bz;
+    const int tile = p.work ? p.work[2 * bx + 1] : bx;
     const int k0 = tile * KT + wave * (16 * KB);
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
@@ -679,6 +686,10 @@ int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
     p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = lse;
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
+    // XCD-contiguous order only for long uniform key loops (self-attention): with ragged kv_len the images with long
+    // captions would pile up on one XCD (measured: T = 300 cross-attention 81 -> 104 us; N = T = 4096 1175 -> 1117 us)
+    static const int xcd_env = getenv("YAT_SDPA_XCD") ? atoi(getenv("YAT_SDPA_XCD")) : -1;
+    p.xcd_remap = xcd_env >= 0 ? xcd_env : (T >= 1024);
     // 128-query workgroups once there are enough of them to fill the chip twice over (PixArt-Sigma: N = 4096)
     static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
     // ... and 192-query ones (three sub-tiles per wave: K / V fragments feed three MFMAs, 236 registers) while the head dim
@@ -706,6 +717,8 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
     p.bias_bytes = (uint64_t)B * T * 4;
     p.stat_bytes = (uint64_t)B * H * N * 4;
+    static const int xcd_env = getenv("YAT_SDPA_XCD") ? atoi(getenv("YAT_SDPA_XCD")) : -1;
+    p.xcd_remap = xcd_env >= 0 ? xcd_env : (T >= 1024);
     if (parts < 1 || parts > 3) return YAT_EINVAL;
     static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
     if (parts & 1) {                               // dQ, and delta = rowsum(dO * O) which the dK/dV part reads
