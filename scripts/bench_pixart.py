@@ -113,8 +113,8 @@ def main():
     log(f"{elapsed:.3f}s for {args.steps} steps (host enqueue {1e3 * issue / args.steps:.1f} ms/step), loss={loss_val:.4f}")
 
     # serialized pass for the per-launch GEMM figure
-    saved = (model.side_wgrad, opt.overlap_update)
-    model.side_wgrad, opt.overlap_update = False, False
+    saved = (model.side_wgrad, opt.overlap_update, model.fwd_chains)
+    model.side_wgrad, opt.overlap_update, model.fwd_chains = False, False, 1
     step(0)
     torch.cuda.synchronize()
     timer = []
@@ -123,7 +123,7 @@ def main():
         step(1 + i)
     torch.cuda.synchronize()
     ops.GEMM_TIMER = None
-    model.side_wgrad, opt.overlap_update = saved
+    model.side_wgrad, opt.overlap_update, model.fwd_chains = saved
 
     gf = sum(t[0] for t in timer)
     gms = sum(t[1].elapsed_time(t[2]) for t in timer)
