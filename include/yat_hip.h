@@ -9,7 +9,8 @@
  * bf16 tensors are raw uint16 storage; row-major with explicit leading dimensions in ELEMENTS;
  * `stream` is a hipStream_t passed as void*; every call only enqueues work (no sync, no
  * allocation, graph-capturable) and returns 0 on success, a negative yat error for bad arguments
- * or a positive hipError_t from the launch.  The library keeps no global mutable state.
+ * or a positive hipError_t from the launch.  The library keeps no global mutable state except the
+ * RCCL communicator of the communication section at the end.
  */
 #ifndef YAT_HIP_H
 #define YAT_HIP_H
@@ -19,6 +20,13 @@ extern "C" {
 #endif
 
 typedef void* yat_stream_t; /* hipStream_t */
+
+/* status codes: 0 ok; negative = argument / state error of this library; 1..999 = a hipError_t from a launch or a HIP
+ * runtime call; YAT_ECOMM_BASE + ncclResult_t = an RCCL error (yat_comm_last_error() holds the text). */
+#define YAT_OK 0
+#define YAT_EINVAL (-1)
+#define YAT_ENOCOMM (-2)      /* communicator not initialised, or librccl could not be bound */
+#define YAT_ECOMM_BASE 1000
 
 int yat_version(void);
 
@@ -31,6 +39,11 @@ int yat_version(void);
  *   their autograd backward  common/trainer.py:344
  * ------------------------------------------------------------------------------------------ */
 typedef struct yat_gemm_epilogue {
+    uint32_t struct_size;  /* = sizeof(yat_gemm_epilogue) as the CALLER compiled it (yat_gemm_epilogue_size() for a binding  */
+                           /* that cannot take sizeof).  The library copies that many bytes and zero-fills the rest, so a     */
+                           /* caller built against an older, shorter layout keeps working when options are appended;        */
+                           /* anything below the first layout (64 bytes: through rows_per_batch), above the library's own   */
+                           /* size or not a multiple of 8 is rejected with YAT_EINVAL -- never read past the caller's object */
     const void* bias;      /* bf16 [N] or NULL: v += bias[n]                                       */
     void* aux_out;         /* bf16 [M, ld_aux] or NULL: stores the Linear output (pre-activation / */
                            /* pre-gate), rounded to bf16, for the backward pass                     */
@@ -49,6 +62,8 @@ typedef struct yat_gemm_epilogue {
                            /* selecting act (1 SiLU, 2 GELU-tanh) -- FeedForward's GELU in PixArt-Sigma (net.0 -> net.2);      */
                            /* excludes the other options                                                                       */
 } yat_gemm_epilogue;
+
+uint64_t yat_gemm_epilogue_size(void);   /* sizeof(yat_gemm_epilogue) in this build of the library */
 
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
  * b_t=0: B is [N,K] (k contiguous, nn.Linear weight layout); b_t=1: B is [K,N].
@@ -297,6 +312,37 @@ int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_
 int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_avg_sq, const float* clip_coef,
                    double lr, double beta1, double beta2, double eps, double weight_decay, int step, int zero_grad,
                    void* ema_shadow, double ema_decay, int background, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * communication: data-parallel gradient reduction over RCCL / xGMI, one process per GPU.
+ * replaces: Accelerate's DDP wrap -- Accelerator(...) + DistributedDataParallelKwargs common/trainer.py:31-37,
+ *   accelerator.prepare (rank0 -> all parameter broadcast) :253, the bucketed all-reduce(avg) fired inside
+ *   accelerator.backward(loss) :344.
+ * The library owns the communicator and one completion event per bucket (its only global state); the caller owns the
+ * buffers and decides WHEN a bucket is ready (the backward schedule, yat_amd/sana.py) -- bucket scheduling is host logic
+ * tied to the model's launch order, so it stays with the launch order; this is the transport.  RCCL is bound at run time
+ * (the copy the process already holds, else the system librccl.so.1), so the library loads without it.
+ *   yat_comm_unique_id : rank 0 draws the 128-byte rendezvous id; the caller ships it to the other ranks (env, store, file)
+ *   yat_comm_init      : collective over all `world` ranks; one communicator per process
+ *   yat_comm_broadcast : in-place broadcast of `nbytes` from `root` on `stream` (parameters at start-up)
+ *   yat_bucket_allreduce_async : records an event on producer_stream, makes comm_stream wait for it, enqueues the in-place
+ *       all-reduce(mean) of nbytes/2 bf16 gradients on comm_stream and records the bucket's completion event; returns at
+ *       once.  producer_stream == comm_stream skips the first event.  bucket_id in [0, 256).
+ *   yat_comm_wait      : compute_stream waits (on the device; the host does not block) for bucket_id, or for every
+ *       outstanding bucket when bucket_id < 0
+ *   yat_comm_destroy   : releases the communicator and the events
+ * ------------------------------------------------------------------------------------------ */
+#define YAT_COMM_ID_BYTES 128
+int yat_comm_unique_id(void* id_out_128);
+int yat_comm_init(int rank, int world, const void* unique_id_128);
+int yat_comm_world(void);                /* 0 before yat_comm_init */
+int yat_comm_rank(void);                 /* -1 before yat_comm_init */
+int yat_comm_broadcast(void* ptr, uint64_t nbytes, int root, yat_stream_t stream);
+int yat_bucket_allreduce_async(void* ptr, uint64_t nbytes, int bucket_id, yat_stream_t producer_stream,
+                               yat_stream_t comm_stream);
+int yat_comm_wait(int bucket_id, yat_stream_t compute_stream);
+int yat_comm_destroy(void);
+const char* yat_comm_last_error(void);
 
 #ifdef __cplusplus
 }

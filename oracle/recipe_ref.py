@@ -120,3 +120,34 @@ def sample_latents_ref(model, sched: FlowMatchSchedule, latents, prompt_embeds, 
         v = (v_u + guidance_scale * (v_c - v_u)).to(dtype)
         x = (x.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(dtype)
     return x
+
+
+class EMAModelRef:
+    """[RECALL] diffusers.training_utils.EMAModel(parameters, decay=0.999) as the reference constructs and steps it
+    (common/trainer.py:266-268,350-351): defaults min_decay=0, update_after_step=0, use_ema_warmup=False.  Shadows are
+    clones of the parameters (bf16 for a bf16 model), updated in place in that dtype."""
+
+    def __init__(self, parameters, decay: float = 0.999, min_decay: float = 0.0, update_after_step: int = 0):
+        self.shadow_params = [p.clone().detach() for p in parameters]
+        self.decay, self.min_decay, self.update_after_step = decay, min_decay, update_after_step
+        self.optimization_step = 0
+        self.cur_decay_value = None
+
+    def get_decay(self, optimization_step: int) -> float:
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = (1 + step) / (10 + step)                      # use_ema_warmup=False branch
+        return max(min(cur, self.decay), self.min_decay)
+
+    @torch.no_grad()
+    def step(self, parameters):
+        self.optimization_step += 1
+        decay = self.get_decay(self.optimization_step)
+        self.cur_decay_value = decay
+        one_minus_decay = 1 - decay
+        for s_param, param in zip(self.shadow_params, list(parameters)):
+            if param.requires_grad:
+                s_param.sub_(one_minus_decay * (s_param - param))
+            else:
+                s_param.copy_(param)

@@ -11,6 +11,7 @@ HEADER = os.path.join(ROOT, "include", "yat_hip.h")
 
 _CT = {
     "int": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float, "double": C.c_double,
+    "const char*": C.c_char_p,
 }
 
 
@@ -18,8 +19,8 @@ def _parse_header():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|uint64_t)\s+(yat_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
-        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+    for m in re.finditer(r"\b(int|uint64_t|const char\s*\*)\s*(yat_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, params = re.sub(r"\s+", "", m.group(1)).replace("constchar*", "const char*"), m.group(2), m.group(3).strip()
         plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
         types = []
         for p in plist:
@@ -105,3 +106,78 @@ def test_bad_arguments_of_the_widened_rows_are_rejected(built_lib):
     assert lib.yat_lokr_small_wgrad(16, 8, 64, 8, 1, 1, 32, 1, 64, 1.0, 0, 1, None) == -1       # ldx < N
     assert lib.yat_lokr_small_wgrad_workspace_bytes(32768, 8, 2240) == 32 * 8 * 18 * 128 * 4
     assert lib.yat_sdpa_fwd(1, 64, 64, 1, 136, 0.1, 1, 136, 1, 1, 136, 1, None, 1, 136, None, None) == -1   # dh > 128
+
+
+def test_gemm_epilogue_is_versioned_by_size(built_lib):
+    """yat_gemm_epilogue.struct_size: the library copies exactly what the caller owns.  The full layout and the first
+    published one (64 bytes) are accepted; zero, a truncated, an oversized or a misaligned size is YAT_EINVAL before anything
+    is read or launched -- a binding written against an older header can never make the library read past its object."""
+    lib = ylib.load()
+    full = C.sizeof(ylib.GemmEpilogue)
+    assert lib.yat_gemm_epilogue_size() == full == 112
+    assert ylib.GemmEpilogue().struct_size == full
+
+    def call(ep):
+        # M = 0 is rejected AFTER the epilogue is not looked at; use valid dims + fake non-null pointers and a bad activation
+        # so that a struct that passes the size check fails later with the same code but a different cause is excluded:
+        return lib.yat_gemm_bf16(0, 0, 8, 8, 8, 1, 8, 1, 8, 1, 8, C.byref(ep), None)
+
+    ok = ylib.GemmEpilogue(None, None, 7)                       # activation 7: invalid -> EINVAL from the field check
+    assert call(ok) == -1
+    # accepted sizes get past validation: without a GPU the call then fails in the HIP runtime (a positive hipError_t)
+    import torch
+    if not torch.cuda.is_available():
+        assert call(ylib.GemmEpilogue()) > 0
+        v1 = ylib.GemmEpilogue()
+        v1.struct_size = 64
+        assert call(v1) > 0
+    for bad in (0, 8, 56, 60, full + 8, 0x7fff0000):
+        ep = ylib.GemmEpilogue()
+        ep.struct_size = bad
+        assert call(ep) == -1, bad
+
+    class OldEpilogue(C.Structure):                             # the round-1 INTEGRATION.md stub: no size field, 9 members
+        _fields_ = [("bias", C.c_void_p), ("aux_out", C.c_void_p), ("activation", C.c_int), ("gate", C.c_void_p),
+                    ("residual", C.c_void_p), ("ld_aux", C.c_int), ("ld_gate", C.c_int), ("ld_residual", C.c_int),
+                    ("rows_per_batch", C.c_int)]
+    for bias in (None, 0x7f0000001000):
+        old = OldEpilogue(bias, None, 0, None, None, 0, 0, 0, 0)
+        rc = lib.yat_gemm_bf16(0, 0, 8, 8, 8, 1, 8, 1, 8, 1, 8, C.cast(C.byref(old), C.POINTER(ylib.GemmEpilogue)), None)
+        assert rc == -1
+
+
+def test_comm_entry_points_without_a_communicator(built_lib):
+    """The communication quartet (+ helpers) is exported and refuses work before yat_comm_init; nothing here touches a GPU
+    or loads RCCL."""
+    lib = ylib.load()
+    assert lib.yat_comm_world() == 0 and lib.yat_comm_rank() == -1
+    assert lib.yat_bucket_allreduce_async(1, 128, 0, None, None) == -2          # YAT_ENOCOMM
+    assert lib.yat_comm_wait(-1, None) == -2
+    assert lib.yat_comm_broadcast(1, 128, 0, None) == -2
+    assert lib.yat_comm_destroy() == 0                                           # idempotent
+    assert lib.yat_comm_init(0, 0, b"x" * 128) == -1 and lib.yat_comm_init(2, 2, b"x" * 128) == -1
+    assert lib.yat_comm_init(0, 1, None) == -1 and lib.yat_comm_unique_id(None) == -1
+    assert isinstance(lib.yat_comm_last_error(), bytes)
+
+
+def test_integration_stub_matches_the_header():
+    """INTEGRATION.md's Level-2 ctypes stub is documentation a maintainer will paste: its GemmEpilogue must be the header's
+    struct, member for member (round 1 shipped a 9-field stub for a 15-field struct)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class GemmEpilogue(C.Structure):"):doc.index("_lib.yat_gemm_epilogue_size.restype")]
+    doc_fields = re.findall(r'\("(\w+)",\s*C\.(\w+)\)', block)
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = hdr[hdr.index("typedef struct yat_gemm_epilogue {"):hdr.index("} yat_gemm_epilogue;")].split("{", 1)[1]
+    hdr_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ptr = "*" in decl
+        base = decl.replace("const", "").replace("*", " ").split()
+        ctype = "c_void_p" if ptr else {"int": "c_int", "uint32_t": "c_uint32"}[base[0]]
+        for name in " ".join(base[1:]).split(","):
+            hdr_fields.append((name.strip(), ctype))
+    assert doc_fields == hdr_fields
+    by_name = {"c_void_p": C.c_void_p, "c_int": C.c_int, "c_uint32": C.c_uint32}      # (c_uint32 is an alias of c_uint)
+    assert [(n, t) for n, t in ylib.GemmEpilogue._fields_] == [(n, by_name[t]) for n, t in hdr_fields]

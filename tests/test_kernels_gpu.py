@@ -666,6 +666,51 @@ def test_clip_and_adamw_match_torch_cpu(ops):
         assert flat["g"].abs().max().item() == 0.0     # zero_grad fused
 
 
+def test_ema_matches_emamodel_restatement():
+    """EMAModel.step (common/trainer.py:266-268,350-351) fused into the AdamW launch: 12 optimizer steps through
+    FlatAdamW(use_ema=True) against torch CPU AdamW + the oracle's EMAModel restatement on bf16 tensors, including the decay
+    warm-up (0 on the first step, (1+s)/(10+s) after, capped at 0.999).  The schedule is compared exactly; the shadows may
+    differ only where the parameters already do (the AdamW kernel is bit-exact but for rare 1-ulp ties)."""
+    from types import SimpleNamespace
+    from oracle.recipe_ref import EMAModelRef
+    from yat_amd.optim import FlatAdamW
+    shapes = [(96, 40), (40,), (3, 3, 16), (2000,), (8,)]
+    g = torch.Generator().manual_seed(11)
+    params = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(BF)) for s in shapes]
+    opt = torch.optim.AdamW(params, lr=2e-2, weight_decay=0.01)
+    ema = EMAModelRef(params, decay=0.999)
+    starts, off = [], 0
+    for p in params:
+        starts.append(off)
+        off += (p.numel() + 7) // 8 * 8
+    model = SimpleNamespace(flat_param=torch.zeros(off, dtype=BF, device=DEV), flat_grad=torch.zeros(off, dtype=BF, device=DEV),
+                            seg_start=torch.tensor(starts + [off], dtype=torch.int64), numel_flat=off,
+                            bucket_bounds=[(0, off)], param_events=None, join_pending_update=lambda: None)
+    for p, s in zip(params, starts):
+        model.flat_param[s:s + p.numel()] = p.data.flatten().to(DEV)
+    hip = FlatAdamW(model, lr=2e-2, weight_decay=0.01, max_grad_norm=1.0, use_ema=True, ema_decay=0.999)
+    for step in range(1, 13):
+        for p, s in zip(params, starts):
+            p.grad = (torch.randn(p.shape, generator=g) * (3.0 if step % 5 == 1 else 0.05)).to(BF)
+            model.flat_grad[s:s + p.numel()] = p.grad.flatten().to(DEV)
+        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        opt.step()
+        ema.step(params)
+        hip.step()
+        assert hip._ema_decay_now() == ema.cur_decay_value, (step, hip._ema_decay_now(), ema.cur_decay_value)
+        bad_p = bad_s = 0
+        for p, sh, s in zip(params, ema.shadow_params, starts):
+            mine_p = model.flat_param[s:s + p.numel()].cpu().view(p.shape)
+            mine_s = hip.ema_shadow[s:s + p.numel()].cpu().view(p.shape)
+            bad_p += (mine_p != p.data).sum().item()
+            bad_s += (mine_s != sh).sum().item()
+            close(mine_s, sh, f"ema_shadow step {step}", tol=1e-3, ulps=1)
+        print(f"[parity] ema step {step:2d}: decay={ema.cur_decay_value:.6f}; shadow elements differing bitwise "
+              f"{bad_s} / {off} (parameters {bad_p})")
+        assert bad_s <= max(2 * bad_p, 0.002 * off)
+    assert ema.cur_decay_value == (1 + 11) / (10 + 11)
+
+
 @pytest.mark.parametrize("act", ["gelu_tanh", "silu"])
 @pytest.mark.parametrize("M,N,K", [(300, 328, 96), (1024, 1152, 288), (520, 4608, 1152)])
 def test_dgrad_with_activation_backward_epilogue(ops, act, M, N, K):

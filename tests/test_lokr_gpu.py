@@ -219,3 +219,105 @@ def test_lokr_module_dropout_drops_the_adapter(mode):
         enc, mask, _, _ = recipe.pad_embeddings(embs)
         out = hip(latents.to(DEV), encoder_hidden_states=enc, timestep=torch.tensor([500.0, 20.0]), encoder_attention_mask=mask).sample
     assert all(e["active"] for e in ad.entries) and torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("mode", ["factored", "dense"])
+def test_lokr_module_dropout_with_gradient_accumulation(mode):
+    """Module dropout x gradient accumulation (gas = 2) with every per-micro-step pattern -- on/on, on/off, off/on, off/off --
+    against the oracle's peft-wrapped model accumulating ``.grad`` over two backward calls.  An entry dropped on the second
+    micro-step keeps the first one's sums; one dropped on the first starts from zero on the second (not from the previous
+    optimizer step's sums); one dropped on both has no gradient at all and the optimizer leaves it alone -- parameters, moments
+    and step count -- exactly like torch.optim.AdamW skips a ``grad is None`` parameter (common/trainer.py:317,344-348)."""
+    from oracle.sana_ref import SanaConfig as RefCfg, SanaTransformerRef, init_like_pretrained
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
+    from oracle.lokr_ref import apply_lokr
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.lokr import LoKrAdapters
+    from yat_amd.optim import FlatAdamW
+    rcfg = RefCfg.tiny(num_layers=2)
+    ref = SanaTransformerRef(rcfg)
+    init_like_pretrained(ref, 0)
+    ref_32 = copy.deepcopy(ref).to(BF).float()
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV)
+    hip.load_state_dict(copy.deepcopy(ref).to(BF).state_dict())
+    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=0.5, mode=mode)
+    g = torch.Generator().manual_seed(7)
+    for e in ad.entries:
+        w1, _, _ = ad._views(e, ad.flat_param)
+        w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+    wrapped = apply_lokr(ref_32, TARGETS, r=2, alpha=4.0)
+    sd = ad.state_dict()
+    for name, w in wrapped.items():
+        pre = f"base_model.model.{name}."
+        with torch.no_grad():
+            w.lokr_w1.copy_(sd[pre + "lokr_w1"].cpu().float())
+            w.lokr_w2_a.copy_(sd[pre + "lokr_w2_a"].cpu().float())
+            w.lokr_w2_b.copy_(sd[pre + "lokr_w2_b"].cpu().float())
+    names = [e["module"] for e in ad.entries]
+    pattern = {n: ((True, True), (True, False), (False, True), (False, False))[i % 4] for i, n in enumerate(names)}
+    latents = (torch.randn(2, rcfg.in_channels, 6, 10, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in (9, 30)]
+    recipe = SanaRecipe(hip, pad_to=32, device=DEV)
+    hip.train()
+    ref_32.train()
+    opt = FlatAdamW(ad, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0)
+    # optimizer oracle: stock torch AdamW on bf16 CPU copies of the adapter tensors, fed with the HIP gradients (None for an
+    # adapter without a gradient, as peft leaves it) -- isolates the skip semantics from gradient rounding noise
+    cpu_params = {e["module"]: [torch.nn.Parameter(t.detach().cpu().clone()) for t in ad._views(e, ad.flat_param)]
+                  for e in ad.entries}
+    opt_ref = torch.optim.AdamW([p for ps in cpu_params.values() for p in ps], lr=1e-2, weight_decay=0.01)
+
+    def window(seed0):
+        """One optimizer step = two micro-steps with the pattern above, on both sides."""
+        for micro in range(2):
+            ad.active_override = lambda n, micro=micro: pattern[n][micro]
+            hip.accumulate_grads = micro > 0
+            recipe.optimize(latents, embs, torch.Generator().manual_seed(seed0 + micro)).backward()
+            for n, w in wrapped.items():
+                w.module_dropout = 0.0 if pattern[n][micro] else 1.0
+            optimize_ref(ref_32, RefSched(), latents, embs, torch.Generator().manual_seed(seed0 + micro), pad_to=32,
+                         dtype=torch.float32)[0].backward()
+        hip.accumulate_grads = False
+        torch.cuda.synchronize()
+
+    for step in range(2):          # the second window starts with the first one's sums still in the buffers
+        window(3 + 10 * step)
+        hg, fg = [], []
+        for e in ad.entries:
+            w = wrapped[e["module"]]
+            mine = [t.float().cpu() for t in ad._views(e, ad.flat_grad)]
+            if pattern[e["module"]] == (False, False):
+                assert w.lokr_w1.grad is None and all(t.abs().max() == 0 for t in mine), e["module"]
+                continue
+            hg += [t.flatten() for t in mine]
+            fg += [t.grad.flatten() for t in (w.lokr_w1, w.lokr_w2_a, w.lokr_w2_b)]
+            for t, r in zip(mine, (w.lokr_w1, w.lokr_w2_a, w.lokr_w2_b)):
+                assert rel(t, r.grad) <= 4e-2, (e["module"], pattern[e["module"]], rel(t, r.grad))
+        e_h = rel(torch.cat(hg), torch.cat(fg))
+        print(f"[parity] lokr {mode} dropout x accumulation, window {step}: adapter grads hip_vs_fp32={e_h:.3e}")
+        assert e_h <= 1.2e-2
+        before = ad.flat_param.clone()
+        for e in ad.entries:
+            dropped = pattern[e["module"]] == (False, False)
+            for q, t in zip(cpu_params[e["module"]], ad._views(e, ad.flat_grad)):
+                q.grad = None if dropped else t.detach().cpu().clone()
+        opt.step()
+        torch.nn.utils.clip_grad_norm_([q for ps in cpu_params.values() for q in ps if q.grad is not None], 1.0)
+        opt_ref.step()
+        torch.cuda.synchronize()
+        n_bad = n_all = 0
+        for e in ad.entries:
+            lo, hi = e["span"]
+            moved = not torch.equal(before[lo:hi], ad.flat_param[lo:hi])
+            dropped = pattern[e["module"]] == (False, False)
+            assert moved != dropped, (e["module"], moved, dropped)
+            assert e["steps"] == (0 if dropped else step + 1)
+            for t, q in zip(ad._views(e, ad.flat_param), cpu_params[e["module"]]):
+                n_bad += (t.cpu() != q.data).sum().item()
+                n_all += q.numel()
+                assert rel(t, q.data) <= 2e-3, (e["module"], rel(t, q.data))
+        print(f"[parity] lokr {mode} dropout x accumulation, window {step}: {n_bad}/{n_all} adapter parameters differ bitwise "
+              f"from torch AdamW (grad=None entries skipped)")
+        assert n_bad <= 0.005 * n_all

@@ -18,6 +18,7 @@ PEFT adapters, dual-GPU mode, Dreambooth, REPA and DeepSpeed are out of scope (S
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import os
 import random
@@ -174,6 +175,29 @@ class Model:
                 best, dist_ = r, d
         return str(best)
 
+    def load_empty_embeddings(self):
+        """The embedding of the empty prompt that whole-batch CFG dropout substitutes (:306-308,319-323).  The reference gets
+        it from ``extract_embeddings([''])`` -- a text-encoder pass, outside this build's scope -- so it is read from the
+        cache like every other feature: ``empty_embeds.pt`` next to the shards (or in the cwd), holding what that call
+        returns (SANA / PixArt: a list with one ``[L, C]`` tensor of the mask-true rows, train_sana.py:84-94).  A subclass
+        with a text encoder may still override ``extract_embeddings``; it is tried first."""
+        try:
+            with torch.no_grad():
+                return self.extract_embeddings([""])
+        except NotImplementedError:
+            pass
+        cands = [os.path.join(os.path.dirname(q), "empty_embeds.pt") for q in (self.params.local_shard_paths or [])]
+        path = next((c for c in cands + ["empty_embeds.pt"] if os.path.isfile(c)), None)
+        if path is None:
+            raise FileNotFoundError(
+                "train_unconditional_prob > 0 needs the empty-prompt embedding: put `empty_embeds.pt` (the value of "
+                "extract_embeddings(['']): a list with one [L, C] tensor) next to the shards or in the working directory "
+                f"(looked in: {cands + ['empty_embeds.pt']})")
+        emb = torch.load(path, map_location="cpu")
+        if torch.is_tensor(emb):
+            emb = [emb if emb.ndim == 2 else emb[0]]
+        return emb
+
     def save_model(self):
         if getattr(self, "adapters", None) is not None:               # a PeftModel saves only its adapter
             self.adapters.save_pretrained(f"models/{self.global_step}")
@@ -257,11 +281,12 @@ class Model:
         dev = self.accelerator.device
         avg_loss = torch.zeros((), device=dev)
         self.accelerator.wait_for_everyone()
-        if self.empty_embeddings is None and p.train_unconditional_prob > 0:
-            with torch.no_grad():
-                self.empty_embeddings = self.extract_embeddings([""])
+        if self.empty_embeddings is None and p.train_unconditional_prob > 0:       # :306-308
+            self.empty_embeddings = self.load_empty_embeddings()
         steps = p.steps if max_steps is None else min(p.steps, max_steps)
-        self.loss_history = []
+        # last logged losses as device scalars (tests and callers peek at it); bounded: an unbounded list of 0-dim device
+        # tensors pins one 512-byte allocator block per step for the whole run
+        self.loss_history = collections.deque(maxlen=int(os.environ.get("YAT_LOSS_HISTORY", "1024")))
         while self.global_step < steps:
             for batch in self.sampler:
                 ratio, latents, embeddings, repa = batch.ratio, batch.vae_features, batch.embeddings, batch.repa_features

@@ -12,8 +12,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
-#define YAT_OK 0
-#define YAT_EINVAL (-1)
+#include "../../include/yat_hip.h"      // status codes (YAT_OK, YAT_EINVAL, ...) and the entry-point prototypes
 #define YAT_LDS __attribute__((address_space(3)))
 
 #define YAT_CHECK_LAUNCH()                                  \

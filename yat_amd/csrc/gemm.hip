@@ -23,6 +23,8 @@
 #include <math.h>
 #include "common.hpp"
 #include <cstdlib>
+#include <cstddef>
+#include <cstring>
 #include "gemm_common.hpp"
 #include "../../include/yat_hip.h"
 
@@ -174,6 +176,10 @@ double est_time_256(int M, int N, int K, int BNv, int ksplit) {
 
 }  // namespace
 
+// first published layout of yat_gemm_epilogue: struct_size .. rows_per_batch
+static constexpr uint32_t YAT_GEMM_EPILOGUE_V1_BYTES = offsetof(yat_gemm_epilogue, glu_u);
+static_assert(YAT_GEMM_EPILOGUE_V1_BYTES == 64 && sizeof(yat_gemm_epilogue) % 8 == 0, "yat_gemm_epilogue layout");
+
 // argument checks + descriptor shared by the single and the grouped entry points
 static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, const yat_gemm_epilogue* ep, GemmP& p) {
@@ -186,7 +192,13 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
     p = GemmP{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    yat_gemm_epilogue e_{};
     if (ep) {
+        // versioned struct: copy exactly what the caller owns, zero-fill options it does not know (never read past it)
+        const uint32_t sz = ep->struct_size;
+        if (sz < YAT_GEMM_EPILOGUE_V1_BYTES || sz > sizeof(e_) || (sz & 7)) return YAT_EINVAL;
+        memcpy(&e_, ep, sz);
+        ep = &e_;
         p.bias = (const bf16_t*)ep->bias; p.gate = (const bf16_t*)ep->gate; p.res = (const bf16_t*)ep->residual;
         p.aux = (bf16_t*)ep->aux_out; p.ldr = ep->ld_residual ? ep->ld_residual : ldc;
         p.ldaux = ep->ld_aux ? ep->ld_aux : ldc; p.gate_ld = ep->ld_gate; p.rows_per_batch = ep->rows_per_batch;
@@ -208,6 +220,8 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
     p.ksplit = 1;
     return YAT_OK;
 }
+
+extern "C" uint64_t yat_gemm_epilogue_size(void) { return sizeof(yat_gemm_epilogue); }
 
 int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs, hipStream_t stream);
 
@@ -278,12 +292,13 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     p.nbm = (M + BM - 1) / BM; p.nbn = (N + BN - 1) / BN;
     static bool attr_set = false;   // idempotent one-time launch attribute (64 KiB dynamic LDS)
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return YAT_EINVAL;
+        const void* kernels[] = {(const void*)gemm_bf16_kernel<false, false>, (const void*)gemm_bf16_kernel<false, true>,
+                                 (const void*)gemm_bf16_kernel<true, true>, (const void*)gemm_bf16_kernel<true, false>,
+                                 (const void*)gemm_bf16_kernel<false, false, true>};
+        for (const void* k : kernels) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;          // a HIP error (e.g. no device), not an argument error
+        }
         attr_set = true;
     }
     dim3 grid(p.nbm * p.nbn), block(256);

@@ -15,12 +15,63 @@ callback does nothing and gradients keep accumulating in place.
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
 
+class NativeComm:
+    """The C-ABI transport (include/yat_hip.h, communication section): one RCCL communicator owned by libyat_hip.so.
+    Rendezvous: rank 0 draws the 128-byte id and ships it over the launcher's process group (any backend) -- or nowhere in
+    a one-rank job, which needs no process group at all."""
+
+    _instance = None
+
+    @classmethod
+    def get(cls, process_group=None):
+        if cls._instance is None:
+            cls._instance = cls(process_group)
+        return cls._instance
+
+    def __init__(self, process_group=None):
+        from . import lib as _l
+        self._l, self.lib = _l, _l.load()
+        multi = dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.rank = dist.get_rank(process_group) if multi else 0
+        self.world = dist.get_world_size(process_group) if multi else 1
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _l.check(self.lib.yat_comm_unique_id(buf), "yat_comm_unique_id")
+        ident = [bytes(buf.raw)]
+        if multi:
+            dist.broadcast_object_list(ident, src=0, group=process_group)
+        _l.check(self.lib.yat_comm_init(self.rank, self.world, ident[0]), "yat_comm_init")
+
+    def broadcast(self, t, root=0):
+        self._l.check(self.lib.yat_comm_broadcast(t.data_ptr(), t.numel() * t.element_size(), root,
+                                                  torch.cuda.current_stream().cuda_stream), "yat_comm_broadcast")
+
+    def allreduce_async(self, t, bucket_id, producer_stream, comm_stream):
+        self._l.check(self.lib.yat_bucket_allreduce_async(t.data_ptr(), t.numel() * t.element_size(), bucket_id,
+                                                          producer_stream.cuda_stream, comm_stream.cuda_stream),
+                      "yat_bucket_allreduce_async")
+
+    def wait(self, stream, bucket_id=-1):
+        self._l.check(self.lib.yat_comm_wait(bucket_id, stream.cuda_stream), "yat_comm_wait")
+
+    def destroy(self):
+        self._l.check(self.lib.yat_comm_destroy(), "yat_comm_destroy")
+        type(self)._instance = None
+
+
 class HipDDP:
-    def __init__(self, model, process_group=None, average=True, force=False):
+    """``transport``: "torch" = torch.distributed's RCCL process group (default for multi-rank jobs: the launcher has built it
+    anyway), "native" = the library's own communicator through the C ABI (``YAT_COMM=native``; also what a forced one-rank
+    rehearsal uses when no process group exists).  Same buckets, same streams, same arithmetic (RCCL mean) either way."""
+
+    def __init__(self, model, process_group=None, average=True, force=False, transport=None):
         self.model = model
         self.force = force            # run the collectives even in a one-rank group (single-GPU rehearsal of the N>1 path)
         self.pg = process_group
@@ -29,6 +80,14 @@ class HipDDP:
         self.sync = True
         self.on_gpu = model.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=model.flat_grad.device) if self.on_gpu else None
+        transport = transport or os.environ.get("YAT_COMM") or ("torch" if dist.is_initialized() else "native")
+        if transport not in ("torch", "native"):
+            raise ValueError(f"transport {transport!r}: torch | native")
+        self.native = None
+        if transport == "native" and self.on_gpu and (self.world > 1 or force):
+            if not average:
+                raise ValueError("the native transport reduces to the mean (DDP semantics)")
+            self.native = NativeComm.get(process_group)
         self._works = []
         self.bytes_reduced = 0
         model.grad_ready = self.bucket_ready
@@ -36,13 +95,21 @@ class HipDDP:
     def broadcast_parameters(self, src=0):
         """accelerator.prepare -> DDP's rank0 -> all parameter broadcast (trainer.py:253)."""
         if self.world > 1 or self.force:
-            dist.broadcast(self.model.flat_param, src=src, group=self.pg)
+            if self.native is not None:
+                self.native.broadcast(self.model.flat_param, src)
+            else:
+                dist.broadcast(self.model.flat_param, src=src, group=self.pg)
 
     def bucket_ready(self, i):
         if (self.world == 1 and not self.force) or not self.sync:
             return
         lo, hi = self.model.bucket_bounds[i]
         chunk = self.model.flat_grad[lo:hi]
+        self.bytes_reduced += chunk.numel() * chunk.element_size()
+        if self.native is not None:
+            # event on the stream that finished the bucket -> all-reduce on the communication stream, all inside the library
+            self.native.allreduce_async(chunk, i, torch.cuda.current_stream(), self.comm_stream)
+            return
         op = dist.ReduceOp.AVG if (self.average and self.on_gpu) else dist.ReduceOp.SUM
         if self.on_gpu:
             ev = torch.cuda.Event()
@@ -53,11 +120,12 @@ class HipDDP:
         else:  # gloo path used by the CPU multi-process tests
             w = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
             self._works.append((w, chunk))
-        self.bytes_reduced += chunk.numel() * chunk.element_size()
 
     def wait(self):
         """Called before the optimizer: the compute stream waits for every outstanding bucket."""
-        if self.on_gpu:
+        if self.native is not None:
+            self.native.wait(torch.cuda.current_stream())
+        elif self.on_gpu:
             for w in self._works:
                 w.wait()                         # makes the current stream wait; does not block the host
             torch.cuda.current_stream().wait_stream(self.comm_stream)

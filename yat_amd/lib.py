@@ -16,9 +16,15 @@ P, I, I64, U64, F, D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.
 
 
 class GemmEpilogue(C.Structure):
-    _fields_ = [("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
+    """yat_gemm_epilogue (include/yat_hip.h).  ``struct_size`` is filled in here: positional / keyword arguments start at
+    ``bias``."""
+    _fields_ = [("struct_size", C.c_uint32), ("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
                 ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I),
                 ("glu_u", P), ("ld_glu_u", I), ("pre_add", P), ("ld_pre_add", I), ("dact_z", P), ("ld_dact_z", I)]
+
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(GemmEpilogue), *args, **kw)
 
 
 class GemmProblem(C.Structure):
@@ -29,6 +35,7 @@ class GemmProblem(C.Structure):
 # name -> (restype, argtypes)
 SIGNATURES = {
     "yat_version": (I, []),
+    "yat_gemm_epilogue_size": (U64, []),
     "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
     "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P, U64, P]),
     "yat_gemm_grouped_bf16": (I, [I, I, I, C.POINTER(GemmProblem), P]),
@@ -76,6 +83,15 @@ SIGNATURES = {
     "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
     "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
     "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),
+    "yat_comm_unique_id": (I, [P]),
+    "yat_comm_init": (I, [I, I, P]),
+    "yat_comm_world": (I, []),
+    "yat_comm_rank": (I, []),
+    "yat_comm_broadcast": (I, [P, U64, I, P]),
+    "yat_bucket_allreduce_async": (I, [P, U64, I, P, P]),
+    "yat_comm_wait": (I, [I, P]),
+    "yat_comm_destroy": (I, []),
+    "yat_comm_last_error": (C.c_char_p, []),
 }
 
 
@@ -112,5 +128,8 @@ def load() -> C.CDLL:
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        kind = "invalid argument" if rc < 0 else f"hipError_t {rc}"
+        if rc >= 1000 or rc == -2:
+            kind = f"communication error {rc}: {(load().yat_comm_last_error() or b'').decode()}"
+        else:
+            kind = "invalid argument" if rc < 0 else f"hipError_t {rc}"
         raise YatLibraryError(f"{what} failed: {kind}")

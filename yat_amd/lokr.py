@@ -90,7 +90,8 @@ class LoKrAdapters:
                 raise NotImplementedError(f"{key}: full lokr_w2 (r >= max(out_k, in_n)/2) is not built")
             e = dict(module=key[:-7], key=key, out=out_dim, inn=in_dim, out_l=out_l, out_k=out_k, in_m=in_m, in_n=in_n,
                      w_off=(w.data_ptr() - base_ptr) // 2, o1=take(out_l * in_m), oa=take(out_k * self.r),
-                     ob=take(self.r * in_n), active=True)
+                     ob=take(self.r * in_n), active=True, has_grad=False, steps=0)
+            e["span"] = (e["o1"], off)      # [o1, end of w2_b incl. pad): the entry's contiguous, 8-aligned parameter range
             # factored application needs 16-byte rows in every small GEMM: in_n, in_m*R, out multiples of 8
             e["factored"] = (self.mode == "factored" and in_n % 8 == 0 and in_n <= 128 and self.R <= 16 and out_dim % 8 == 0
                              and out_k * self.R * 4 <= 65536)
@@ -105,6 +106,7 @@ class LoKrAdapters:
         self.bucket_bounds = [(0, off)]
         self.param_events = None
         self.grad_ready = None              # HipDDP hook: called once, after project()
+        self.active_override = None         # callable(module name) -> bool replacing the module-dropout draw (tests)
         R = self.R
         fact = [e for e in self.entries if e["factored"]]
         # dense-mode entries keep their delta_w in a shadow of the model's flat weights (allocated only when one exists)
@@ -218,9 +220,14 @@ class LoKrAdapters:
         nothing.  dy [M, rows(gw)] (row stride allowed), x [M, in] contiguous; ``hs``: the H products ``dgrad_term`` already
         made for this dy."""
         M, R, ld = dy.shape[0], self.R, dy.stride(0)
+        acc_all = accumulate
         for e, row0 in self.lookup(gw, self.model.flat_grad):
             if not e["active"]:
                 continue
+            # gradient accumulation x module dropout: an entry dropped on the earlier micro-steps of this window holds
+            # the PREVIOUS window's sums in d_P / d_w2_b / its dense slot -- its first active micro-step overwrites
+            accumulate = acc_all and e["has_grad"]
+            e["has_grad"] = True
             dyb = dy[:, row0:row0 + e["out"]]
             if not e["factored"]:
                 g = self.model.flat_grad[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
@@ -266,8 +273,13 @@ class LoKrAdapters:
     def materialize(self, training=True):
         """Rebuild every delta_w from the current adapter parameters (zeros where module dropout drops the adapter)."""
         self.join_pending_update()
+        first_micro = not getattr(self.model, "accumulate_grads", False)
         for e in self.entries:
+            if first_micro:
+                e["has_grad"] = False       # a new accumulation window: nothing has contributed yet
             e["active"] = (not training) or self.module_dropout <= 0.0 or bool(torch.rand(1) > self.module_dropout)
+            if training and self.active_override is not None:     # tests: a chosen drop pattern instead of the draw
+                e["active"] = bool(self.active_override(e["module"]))
             w1, wa, wb = self._views(e, self.flat_param)
             if e["factored"]:
                 if e["active"]:
@@ -288,7 +300,11 @@ class LoKrAdapters:
         for e in self.entries:
             g1, ga, gb = self._views(e, self.flat_grad)
             if not e["active"]:
-                g1.zero_(); ga.zero_(); gb.zero_()
+                # dropped on this micro-step: contributes nothing.  If an earlier micro-step of the window was active its
+                # sums stay as they are; an entry that has not contributed at all reads as zero gradients (the optimizer
+                # skips it entirely, update_ranges())
+                if not e["has_grad"]:
+                    g1.zero_(); ga.zero_(); gb.zero_()
                 continue
             w1, wa, wb = self._views(e, self.flat_param)
             if e["factored"]:
@@ -302,6 +318,23 @@ class LoKrAdapters:
             ops.lokr_project(w1, wa, wb, self.scale, dd, g1, ga, gb, self._ws)
         if self.grad_ready is not None:
             self.grad_ready(0)
+
+    def update_ranges(self):
+        """Parameter ranges the optimizer step must touch, with each range's own step count: [(lo, hi, step)].  peft leaves
+        a dropped adapter's ``.grad`` None, so torch.optim.AdamW skips it altogether -- no parameter, moment or weight-decay
+        update, and its per-parameter ``step`` (the bias correction) does not advance.  Entries are contiguous in the flat
+        buffer; neighbours with the same count share a launch."""
+        out = []
+        for e in self.entries:
+            if not e["has_grad"]:
+                continue
+            e["steps"] += 1
+            lo, hi = e["span"]
+            if out and out[-1][1] == lo and out[-1][2] == e["steps"]:
+                out[-1] = (out[-1][0], hi, e["steps"])
+            else:
+                out.append((lo, hi, e["steps"]))
+        return out
 
     # ---- checkpoint (peft layout: adapter_model.safetensors + adapter_config.json)
     def state_dict(self):

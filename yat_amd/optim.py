@@ -65,14 +65,23 @@ class FlatAdamW:
 
         bg = self.background_blocks if self.overlap_update else 0
 
-        def update(lo, hi):
+        def update(lo, hi, step_count=None):
             # no gradient clear: every backward overwrites the whole flat gradient (accumulate_grads=False on the
             # first micro-step), like the reference's zero_grad(set_to_none=True) which writes nothing either
             ops.adamw_step(m.flat_param[lo:hi], m.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], coef,
-                           g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
+                           g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                           self.step_count if step_count is None else step_count,
                            zero_grad=False, ema_shadow=None if self.ema_shadow is None else self.ema_shadow[lo:hi],
                            ema_decay=ema_decay, background=bg)
 
+        ranges = getattr(m, "update_ranges", None)
+        if ranges is not None:
+            # an adapter set with module dropout: parameters whose gradient is None in the reference (adapter dropped for
+            # the whole accumulation window) are skipped like torch.optim.AdamW skips them, each range at its own step
+            m.join_pending_update()
+            for lo, hi, sc in ranges():
+                update(lo, hi, sc)
+            return
         if not self.overlap_update:
             update(0, m.numel_flat)
             return
