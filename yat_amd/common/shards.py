@@ -16,12 +16,17 @@ import torch
 
 
 def write_shard(path, samples):
-    """samples: iterable of dicts {__key__, ratio, latent (Tensor), emb (Tensor)}."""
+    """samples: iterable of dicts {__key__, ratio, latent (Tensor), emb (Tensor)[, pooled (Tensor)]}.  ``pooled`` -> an extra
+    ``<key>.pooled.pt`` member: the pooled text projection SD3.5 conditions on (train_sd35.py:76-92 returns it beside the
+    prompt embeddings; the reference's shard writer predates it and stores no such member -- this is the build's extension,
+    read back by ``read_shard`` like any other ``.pt`` member and ignored by recipes that do not use it)."""
     with tarfile.open(path, "w") as tar:
         for s in samples:
             key = s["__key__"]
-            for ext, payload in ((".ratio", str(s["ratio"]).encode()), (".latent.pt", _save(s["latent"])),
-                                 (".emb.pt", _save(s["emb"]))):
+            members = [(".ratio", str(s["ratio"]).encode()), (".latent.pt", _save(s["latent"])), (".emb.pt", _save(s["emb"]))]
+            if s.get("pooled") is not None:
+                members.append((".pooled.pt", _save(s["pooled"])))
+            for ext, payload in members:
                 info = tarfile.TarInfo(key + ext)
                 info.size = len(payload)
                 tar.addfile(info, io.BytesIO(payload))

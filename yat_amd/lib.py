@@ -80,6 +80,10 @@ SIGNATURES = {
     "yat_add_pos_embed": (I, [I64, I, I, P, P, P, P]),
     "yat_ddpm_add_noise": (I, [I, I64, P, P, P, P, P, P]),
     "yat_mse_bf16_chunk": (I, [I, I64, I64, P, P, F, P, P, P, P]),
+    "yat_qknorm_concat_fwd": (I, [I, I, I, I, I, F, P, I, P, I, P, P, P, P, P, I, P, P]),
+    "yat_qknorm_concat_bwd_workspace_bytes": (U64, [I, I, I, I]),
+    "yat_qknorm_concat_bwd": (I, [I, I, I, I, I, P, I, P, I, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, I, P, P]),
+    "yat_joint_rows": (I, [I, I, I, I, P, I, P, I, P, I, I, P]),
     "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
     "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
     "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),

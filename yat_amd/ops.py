@@ -380,6 +380,42 @@ def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, 
     _l.check(rc, "yat_sdpa_bwd")
 
 
+# ----------------------------------------------------------------------------------------------- MMDiT joint attention glue
+def qknorm_concat_fwd(qkv_img, qkv_txt, B, N, T, H, dh, eps, wq_img, wk_img, wq_txt, wk_txt, joint, rstd):
+    """joint [B*(N+T), 3D] <- [RMSNorm_head(q) | RMSNorm_head(k) | v] of the image rows, then of the text rows, per image;
+    qkv_txt None (T = 0): self-attention over the image tokens only (include/yat_hip.h: yat_qknorm_concat_fwd)."""
+    _chk_bf16(qkv_img, qkv_txt, wq_img, wk_img, wq_txt, wk_txt, joint)
+    rc = _lib().yat_qknorm_concat_fwd(B, N, T, H, dh, eps, _p(qkv_img), qkv_img.stride(0), _p(qkv_txt),
+                                      0 if qkv_txt is None else qkv_txt.stride(0), _p(wq_img), _p(wk_img), _p(wq_txt),
+                                      _p(wk_txt), _p(joint), joint.stride(0), _p(rstd), _stream())
+    _l.check(rc, "yat_qknorm_concat_fwd")
+    return joint
+
+
+def qknorm_concat_bwd_workspace_bytes(B, N, T, dh):
+    return int(_lib().yat_qknorm_concat_bwd_workspace_bytes(B, N, T, dh))
+
+
+def qknorm_concat_bwd(qkv_img, qkv_txt, B, N, T, H, dh, wq_img, wk_img, wq_txt, wk_txt, rstd, d_joint, dqkv_img, dqkv_txt,
+                      dwq_img, dwk_img, dwq_txt, dwk_txt, workspace, accumulate_dw=False):
+    _chk_bf16(qkv_img, qkv_txt, d_joint, dqkv_img, dqkv_txt, dwq_img, dwk_img, dwq_txt, dwk_txt)
+    rc = _lib().yat_qknorm_concat_bwd(B, N, T, H, dh, _p(qkv_img), qkv_img.stride(0), _p(qkv_txt),
+                                      0 if qkv_txt is None else qkv_txt.stride(0), _p(wq_img), _p(wk_img), _p(wq_txt),
+                                      _p(wk_txt), _p(rstd), _p(d_joint), d_joint.stride(0), _p(dqkv_img), dqkv_img.stride(0),
+                                      _p(dqkv_txt), 0 if dqkv_txt is None else dqkv_txt.stride(0), _p(dwq_img), _p(dwk_img),
+                                      _p(dwq_txt), _p(dwk_txt), int(accumulate_dw), _p(workspace), _stream())
+    _l.check(rc, "yat_qknorm_concat_bwd")
+
+
+def joint_rows(joint, img, txt, B, N, T, to_joint):
+    """Rows between the joint layout [B*(N+T), C] and the per-stream layouts [B*N, C], [B*T, C] (txt may be None)."""
+    _chk_bf16(joint, img, txt)
+    C_ = img.shape[1]
+    rc = _lib().yat_joint_rows(B, N, T, C_, _p(joint), joint.stride(0), _p(img), img.stride(0), _p(txt),
+                               0 if txt is None else txt.stride(0), int(to_joint), _stream())
+    _l.check(rc, "yat_joint_rows")
+
+
 # ----------------------------------------------------------------------------------------------- GLUMBConv middle
 def dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y, u_out=None):
     """s = bf16(SiLU(conv_inverted output)) as written by the GEMM epilogue; ``u_out`` (optional [M, 2Hc]) keeps the conv

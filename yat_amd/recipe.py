@@ -185,3 +185,59 @@ class _MseBf16Chunk(torch.autograd.Function):
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
         return dpred * g.to(dpred.dtype), None, None
+
+
+class SD3Recipe:
+    """``SD35Trainer.optimize`` (train_sd35.py:165-194) on the HIP path: noise in the latents' dtype from the global RNG on the
+    device (:180, ``randn_tensor`` without a generator) -> logit-normal u on the CPU (:182) -> indices (:183) ->
+    ``scheduler.timesteps[indices]`` (:184) -> ``scheduler.scale_noise`` (:185) = sigma n + (1 - sigma) x in bf16 [RECALL] ->
+    MMDiT with ``pooled_projections`` (:188-191) -> target = noise - latents (:192) -> ``MSELoss()`` evaluated in bf16
+    (:193).  Mix / target are one launch (``yat_flow_mix``: the same three bf16 roundings, the sum commutes), loss and
+    dL/dpred one launch (``yat_mse_bf16_chunk`` over the whole tensor).  A generator, when given, replaces the global streams
+    (device generator -> noise, CPU generator -> noise and u) so tests can pin the draws."""
+
+    def __init__(self, model, scheduler: FlowMatchSchedule | None = None, device="cuda"):
+        self.model = model
+        self.scheduler = scheduler or FlowMatchSchedule(shift=3.0)
+        self.dev = torch.device(device)
+        self._mse_ws = torch.empty(256, dtype=torch.float32, device=self.dev)
+
+    def draw(self, shape, generator=None, noise=None):
+        if noise is None:
+            if generator is not None and generator.device.type != "cuda":
+                noise = torch.randn(shape, generator=generator, device="cpu", dtype=BF16).to(self.dev, non_blocking=True)
+            else:
+                noise = torch.randn(shape, generator=generator, device=self.dev, dtype=BF16)
+        cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
+        _, t, sig = self.scheduler.sample(shape[0], cpu_gen)
+        return noise.to(self.dev), t.to(self.dev, non_blocking=True), sig.to(self.dev, non_blocking=True)
+
+    @staticmethod
+    def stack_embeddings(embeddings):
+        """The sampler hands a list of per-sample (prompt_embeds [T, J], pooled [P]) pairs (shard members ``emb.pt`` /
+        ``pooled.pt``); SD3 prompts are fixed-length (77 CLIP + 256 T5 tokens), so they stack without padding."""
+        if isinstance(embeddings, (tuple, list)) and len(embeddings) == 2 and torch.is_tensor(embeddings[0]) \
+                and embeddings[0].dim() == 3:
+            return embeddings[0], embeddings[1]
+        return torch.stack([e[0] for e in embeddings]), torch.stack([e[1].reshape(-1) for e in embeddings])
+
+    def optimize(self, latents, embeddings, generator=None, return_pred=False, noise=None):
+        prompt, pooled = self.stack_embeddings(embeddings)
+        latents = latents.to(device=self.dev, dtype=BF16).contiguous()
+        noise, timesteps, sigmas = self.draw(latents.shape, generator, noise)
+        noisy, target = ops.flow_mix(latents, noise, sigmas)
+        pred = self.model(noisy, encoder_hidden_states=prompt.to(self.dev, BF16), pooled_projections=pooled.to(self.dev, BF16),
+                          timestep=timesteps).sample
+        loss = _MseBf16Chunk.apply(pred, target, self._mse_ws)
+        return (loss, pred, target) if return_pred else loss
+
+    def train_step_device(self, latents, prompt, pooled, noise, timesteps, sigmas, loss_out):
+        """Straight-line step on device-resident inputs (scripts/bench_sd35.py): mix, forward, loss + dL/dpred, backward."""
+        noisy, target = ops.flow_mix(latents, noise, sigmas, self._scratch("_noisy_buf", latents), self._scratch("_target_buf", latents))
+        pred = self.model.forward_impl(noisy, prompt, pooled, timesteps)
+        dpred = self._scratch("_dpred_buf", pred)
+        ops.mse_bf16_chunk(pred, target, loss_out, dpred, self._mse_ws)
+        self.model.backward_impl(dpred)
+        return loss_out
+
+    _scratch = SanaRecipe._scratch
