@@ -234,7 +234,7 @@ def test_sd3_trainer_runs_from_shards(tmp_path, monkeypatch):
         r = ["1.0", "0.5", "2.0"][i % 3]
         Hpx, Wpx = ASPECT_RATIO_1024_BIN[r]
         samples.append(dict(__key__=f"{i:07d}", ratio=r,
-                            latent=(torch.randn(cfg.in_channels, int(Hpx) // 128, int(Wpx) // 128, generator=g) * 0.5).to(BF),
+                            latent=(torch.randn(cfg.in_channels, int(Hpx) // 128 * 2, int(Wpx) // 128 * 2, generator=g) * 0.5).to(BF),
                             emb=torch.randn(11, cfg.joint_attention_dim, generator=g).to(BF),
                             pooled=torch.randn(cfg.pooled_projection_dim, generator=g).to(BF)))
     path = str(tmp_path / "shard-000000.tar")
