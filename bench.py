@@ -124,6 +124,94 @@ def cpu_baseline(state_dict, cfg_layers=20):
             "cpu_model": cpu}
 
 
+def run_from_shards(args, rank, world, local_rank):
+    """``--data shards``: the benchmark IS the trainer.  Synthetic cached-feature shards (the reference's {ratio, latent.pt,
+    emb.pt} tar format, same shapes and text-length distribution as the resident mode) are written to local disk, then
+    ``train_sana.SanaModel(params).run()`` -- sampler with its decode thread, bucket consensus, one packed H2D per batch, the
+    allocation-free device step, clip + AdamW, loss logging -- runs W + K steps; the clock brackets the last K.  Validation /
+    checkpoint writes are switched off (they are not the step); everything else is the code path a user's training run takes."""
+    import tempfile
+    import torch.distributed as dist
+    from train_sana import SanaModel
+    from yat_amd.common.shards import write_shard
+    from yat_amd.common.training_parameters_reader import TrainingParameters
+    from yat_amd.sana import SanaConfig
+    B = args.batch
+    root = os.path.join(tempfile.gettempdir(), f"yat_bench_shards_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}")
+    os.makedirs(root, exist_ok=True)
+    ratios = {(32, 32): "1.0", (16, 64): "0.25", (24, 42): "0.57", (44, 22): "2.0"}      # ASPECT_RATIO_1024_BIN keys
+    g = torch.Generator().manual_seed(1234 + rank)
+    per_bucket = max(2 * B, 16)
+    samples = []
+    for i in range(per_bucket * len(BUCKETS)):
+        h, w = BUCKETS[i % len(BUCKETS)]
+        L = int(torch.randint(20, 301, (1,), generator=g))
+        samples.append(dict(__key__=f"{rank:02d}{i:06d}", ratio=ratios[(h, w)],
+                            latent=(torch.randn(32, h, w, generator=g) * 0.5).to(torch.bfloat16),
+                            emb=torch.randn(L, 2304, generator=g).to(torch.bfloat16)))
+    write_shard(os.path.join(root, f"shard-{rank:06d}.tar"), samples)
+    del samples
+    if world > 1:
+        dist.barrier()
+    paths = [os.path.join(root, f"shard-{r:06d}.tar") for r in range(world)]
+    cfg_path = os.path.join(root, f"config_{rank}.yaml")
+    with open(cfg_path, "w") as f:
+        f.write("\n".join(["urls:", "  - unused", "local_shard_paths:", *[f"  - {p}" for p in paths], f"num_shards: {world}",
+                           "dataset_seed: 7", f"batch_size: {B}", "learning_rate: 1e-5", f"steps: {args.warmup + args.steps}",
+                           "num_steps_per_validation: 1000000", "validation_prompts:", "  - x", "bfloat16: true",
+                           "aspect_ratio: 1024", "train_unconditional_prob: 0.0", ""]))
+    params = TrainingParameters()
+    params.read_yaml(cfg_path)
+    os.environ.setdefault("YAT_TENSORBOARD", "0")
+    cwd = os.getcwd()
+    os.chdir(root)                                   # the trainer writes models/ and runs/ relative to the cwd
+    trainer = SanaModel(params, config=SanaConfig(num_layers=args.layers))
+    trainer._validate_and_save = lambda: None        # the step-0 validation + 3.2 GB checkpoint write are not the step
+    clock = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def on_step(step):
+        if step == args.warmup:
+            barrier()
+            clock["t0"] = time.perf_counter()
+        elif step == args.warmup + args.steps:
+            barrier()
+            clock["t1"] = time.perf_counter()
+    log(f"rank {rank}/{world}: trainer mode, {args.warmup} + {args.steps} steps from {len(paths)} shard(s) in {root}")
+    trainer.run(on_step=on_step)
+    os.chdir(cwd)
+    elapsed = clock["t1"] - clock["t0"]
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=trainer.accelerator.device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    loss_val = float(trainer.loss_history[-1])
+    if rank == 0:
+        cfg = trainer.model.cfg
+        flops = B * sum(train_flops_per_image(cfg, h * w, 512) for h, w in BUCKETS) / len(BUCKETS)
+        print(json.dumps({
+            "metric": "images/sec (whole node) SANA-1.6B 1024px bf16 training step", "value": world * B * args.steps / elapsed,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic shards on local disk (trainer mode)",
+            "config": {"workload": "train_sana.py end to end: SANA-1.6B (D=2240, 20 blocks) 1024px, bf16, full fine-tune, "
+                                   f"{{ratio, latent.pt, emb.pt}} tar shards -> BucketSampler (decode thread) -> one packed H2D -> "
+                                   f"device step -> clip + AdamW; aspect buckets {BUCKETS}, T=512",
+                       "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",
+                       "num_layers": cfg.num_layers, "params": trainer.model.numel_flat},
+            "loss": loss_val, "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "mfma_util_step": flops / (elapsed / args.steps) / (PEAK_BF16_TFLOPS * 1e12)}))
+    import shutil
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +225,9 @@ def main():
     ap.add_argument("--lora", type=int, default=0, metavar="RANK",
                     help="plain LoRA adapters (lora_algo: lora) of this rank on the README target modules, alpha = rank; "
                          "not the headline line")
+    ap.add_argument("--data", choices=["resident", "shards"], default="resident",
+                    help="resident (headline): features in HBM before the timed region; shards: the whole trainer "
+                         "(train_sana.SanaModel.run) fed from synthetic shards on local disk -- a side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
@@ -162,6 +253,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+
+    if args.data == "shards":
+        run_from_shards(args, rank, world, local_rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from yat_amd import ops
     from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP

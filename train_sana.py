@@ -81,7 +81,15 @@ class SanaModel(Model):
         return out
 
     def optimize(self, ratio, latents, embeddings, repa_tokens, generator: torch.Generator = None):
-        """train_sana.py:163-219 on the HIP path (yat_amd.recipe.SanaRecipe.optimize)."""
+        """train_sana.py:163-219 on the HIP path.  With gradients enabled (the training call, common/trainer.py:337) the step
+        runs on the allocation-free device path -- one packed H2D copy, forward, loss and backward as straight-line launches
+        (yat_amd.recipe.SanaRecipe.optimize_device) -- and the returned loss is marked so that ``accelerator.backward`` does
+        not run a second backward; under ``no_grad`` (exploration trials, :326-336) it is the plain forward + loss."""
+        if torch.is_grad_enabled() and not latents.is_cuda and os.environ.get("YAT_TRAINER_FAST", "1") != "0":
+            loss = self.recipe.optimize_device(latents, embeddings, generator,
+                                               gscale=1.0 / self.accelerator.gradient_accumulation_steps)
+            loss.yat_backward_done = True
+            return loss
         return self.recipe.optimize(latents, embeddings, generator)
 
 

@@ -12,12 +12,20 @@ key (in table order) that is full everywhere is yielded.  Single-process runs ex
 Reference defects not reproduced (SURVEY.md App. B-2,5,6): the TypeError in the cached-path constructor call, the
 silent discard of surplus samples (`.clear()` :267 -- surplus stays queued here) and the one-shard dead-lock of
 ``local_file_getter`` (:81-90 -- shards are cycled in a seeded random order here).
+Asynchronous feed (the reference runs a producer ``mp.Process`` that fills a queue with shard paths, :203-220, and decodes on
+the consumer): here a producer THREAD reads the tars and unpickles the samples (``decode_ahead`` of them, bounded
+queue) while the training thread is inside C-ABI launches (ctypes drops the GIL), so shard decode never sits on the step's
+critical path.  A thread, not a process: nothing is re-executed or forked once the GPU is initialised, and the decoded CPU
+tensors are handed over by reference.  The collectives of the consensus stay on the training thread -- one thread per rank
+talks to the process group.  ``decode_ahead=0`` (or ``YAT_SAMPLER_THREAD=0``) decodes synchronously.
 Out of scope: R2/HTTP download, on-the-fly VAE/text encoding, Dreambooth, dual-GPU and REPA branches.
 """
 from __future__ import annotations
 
 import os
+import queue
 import random
+import threading
 from collections import deque
 
 import torch
@@ -38,8 +46,12 @@ class Batch:
 
 class BucketSampler:
     def __init__(self, shards, accelerator, batch_size, model=None, seed=0, local_paths=None, features_path=None,
-                 max_read_ahead=4096, legacy_cache_dir=None):
+                 max_read_ahead=4096, legacy_cache_dir=None, decode_ahead=None):
         self.accelerator = accelerator
+        if decode_ahead is None:
+            decode_ahead = 0 if os.environ.get("YAT_SAMPLER_THREAD", "1") == "0" else 16 * batch_size
+        self.decode_ahead = int(decode_ahead)
+        self._producer = None
         self.process_index = accelerator.process_index
         self.num_processes = accelerator.num_processes
         self.batch_size = batch_size
@@ -78,6 +90,45 @@ class BucketSampler:
                 rng.shuffle(samples)                               # webdataset .shuffle(1000) stand-in, seeded
                 yield from samples
 
+    def _prefetched(self, stream):
+        """``stream`` drained by a daemon producer thread through a bounded queue; exceptions travel to the consumer."""
+        q = queue.Queue(maxsize=self.decode_ahead)
+        stop = threading.Event()
+        done = object()
+
+        def produce():
+            try:
+                for item in stream:
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(done)
+            except BaseException as e:      # noqa: BLE001 -- re-raised on the training thread
+                q.put(e)
+        t = threading.Thread(target=produce, name="yat-shard-decode", daemon=True)
+        self._producer = (t, stop)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+
+    def close(self):
+        if self._producer is not None:
+            self._producer[1].set()
+            self._producer = None
+
     def process_element(self, elem):
         ratio = float(elem["ratio"])
         if ratio not in self.buckets:
@@ -105,6 +156,8 @@ class BucketSampler:
 
     def __iter__(self):
         stream = self._shard_stream()
+        if self.decode_ahead > 0:
+            stream = self._prefetched(stream)
         while True:
             # read ahead until this rank owns a full bucket (bounded), then ask everyone
             read = 0

@@ -77,7 +77,9 @@ class HipAccelerator:
         yield
 
     def backward(self, loss):
-        (loss / self.gradient_accumulation_steps if self.gradient_accumulation_steps > 1 else loss).backward()
+        # a recipe's device path has already run the backward (scaled by 1 / gradient_accumulation_steps) inside optimize()
+        if not getattr(loss, "yat_backward_done", False):
+            (loss / self.gradient_accumulation_steps if self.gradient_accumulation_steps > 1 else loss).backward()
         if self.ddp is not None and self.sync_gradients:
             self.ddp.wait()
 
@@ -275,7 +277,8 @@ class Model:
         self.ema_model = self.optimizer.ema_shadow
 
     # ---- :298-403
-    def run(self, max_steps=None):
+    def run(self, max_steps=None, on_step=None):
+        """``on_step(global_step)`` (optional) is called after every optimizer step -- bench.py's clock."""
         p = self.params
         self.initialize()
         dev = self.accelerator.device
@@ -322,6 +325,8 @@ class Model:
                         self.flush_log()
                         self._validate_and_save()
                     self.global_step += 1
+                    if on_step is not None:
+                        on_step(self.global_step)
                     if self.global_step >= steps:
                         break
         self.flush_log()

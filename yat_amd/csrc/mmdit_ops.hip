@@ -147,17 +147,24 @@ __global__ __launch_bounds__(THREADS) void qknorm_concat_bwd_kernel(JointBwdP q)
     }
 }
 
-// dw[stream][q|k][dh] (+)= sum over workgroups, fixed order
-__global__ __launch_bounds__(THREADS) void qknorm_dw_kernel(int nblk, int nstream, int dh, const float* partial, bf16_t* dwq_img,
+// dw[stream][q|k][dh] (+)= sum over workgroups.  One workgroup per (stream, q|k): lane group g = tid / dh sums workgroups
+// g, g + G, ... of its channel, the G group sums are added in a fixed order (bit-reproducible).
+__global__ __launch_bounds__(THREADS) void qknorm_dw_kernel(int nblk, int dh, const float* partial, bf16_t* dwq_img,
                                                             bf16_t* dwk_img, bf16_t* dwq_txt, bf16_t* dwk_txt, int accumulate) {
-    const int t = blockIdx.x * THREADS + threadIdx.x;
-    if (t >= nstream * 2 * dh) return;
-    const int st = t / (2 * dh), sec = (t / dh) & 1, ch = t % dh;
+    const int st = blockIdx.x >> 1, sec = blockIdx.x & 1;
+    const int G = THREADS / dh, g = threadIdx.x / dh, ch = threadIdx.x - g * dh;
+    __shared__ float red[THREADS];
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(((int64_t)b * 2 + st) * 2 + sec) * dh + ch];
-    bf16_t* out = st ? (sec ? dwk_txt : dwq_txt) : (sec ? dwk_img : dwq_img);
-    if (accumulate) s += bf2f(out[ch]);
-    out[ch] = f2bf(s);
+    for (int b = g; b < nblk; b += G) s += partial[(((int64_t)b * 2 + st) * 2 + sec) * dh + ch];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < dh) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += red[k * dh + threadIdx.x];
+        bf16_t* out = st ? (sec ? dwk_txt : dwq_txt) : (sec ? dwk_img : dwq_img);
+        if (accumulate) t += bf2f(out[threadIdx.x]);
+        out[threadIdx.x] = f2bf(t);
+    }
 }
 
 // rows of width C (16-byte chunks) between the joint layout and the two per-stream layouts
@@ -193,7 +200,7 @@ bool joint_args_ok(int B, int N, int T, int H, int dh, int ld_img, int ld_txt, i
     return true;
 }
 
-int grid_for_rows(int64_t rows) { return (int)(rows < 2048 ? rows : 2048); }
+int grid_for_rows(int64_t rows) { return (int)(rows < 1024 ? rows : 1024); }
 
 }  // namespace
 
@@ -239,9 +246,9 @@ int yat_qknorm_concat_bwd(int B, int N, int T, int H, int dh, const void* qkv_im
     hipLaunchKernelGGL(qknorm_concat_bwd_kernel, dim3(nblk), dim3(THREADS), 0, (hipStream_t)stream, q);
     YAT_CHECK_LAUNCH();
     const int nst = T ? 2 : 1;
-    hipLaunchKernelGGL(qknorm_dw_kernel, dim3((nst * 2 * dh + THREADS - 1) / THREADS), dim3(THREADS), 0, (hipStream_t)stream,
-                       nblk, nst, dh, (const float*)workspace, (bf16_t*)dwq_img, (bf16_t*)dwk_img, (bf16_t*)dwq_txt,
-                       (bf16_t*)dwk_txt, accumulate_dw);
+    hipLaunchKernelGGL(qknorm_dw_kernel, dim3(nst * 2), dim3(THREADS), 0, (hipStream_t)stream, nblk, dh,
+                       (const float*)workspace, (bf16_t*)dwq_img, (bf16_t*)dwk_img, (bf16_t*)dwq_txt, (bf16_t*)dwk_txt,
+                       accumulate_dw);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

@@ -36,6 +36,45 @@ class _MseLoss(torch.autograd.Function):
         return dpred * g.to(dpred.dtype), None, None
 
 
+class _Stager:
+    """One host->device copy per batch: everything a step needs from the host (cached latents, the CPU-drawn noise, the ragged
+    text embeddings, their offsets, timesteps, sigmas, the attention work list) is packed into ONE pinned buffer and lands in
+    one device buffer with a single asynchronous copy on the step's stream (the reference issues B + 5 small pageable copies
+    per step, train_sana.py:178-193).  Two pinned buffers alternate: a buffer is rewritten only after the copy that read it
+    has completed (an event, long since signalled two steps later)."""
+
+    def __init__(self, dev):
+        self.dev, self.pin, self.ev, self.k, self.land = dev, [None, None], [None, None], 0, None
+
+    def begin(self, nbytes):
+        k = self.k
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        if self.pin[k] is None or self.pin[k].numel() < nbytes:
+            self.pin[k] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8).pin_memory()
+        return self.pin[k]
+
+    def commit(self, nbytes):
+        k = self.k
+        if self.land is None or self.land.numel() < nbytes:
+            self.land = torch.empty(self.pin[k].numel(), dtype=torch.uint8, device=self.dev)
+        self.land[:nbytes].copy_(self.pin[k][:nbytes], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.ev[k] = ev
+        self.k ^= 1
+        return self.land
+
+
+def _layout(sizes):
+    """16-byte aligned offsets of consecutive byte segments -> (offsets, total)."""
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 15) & ~15
+    return offs, o
+
+
 class SanaRecipe:
     def __init__(self, model, scheduler: FlowMatchSchedule | None = None, pad_to: int = 512, device="cuda"):
         self.model = model
@@ -98,16 +137,70 @@ class SanaRecipe:
         loss = _MseLoss.apply(pred, target, self._mse_ws)
         return (loss, pred, target) if return_pred else loss
 
-    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out, kv_work=None):
+    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out, kv_work=None, gscale=1.0):
         """Graph-friendly straight-line step on device-resident inputs: forward, loss+dL/dpred, backward.
         Used by bench.py and the trainer fast path (no autograd objects, no allocation besides pred)."""
         bias, kvl = mask_bias_kvl
         noisy, target = ops.flow_mix(latents, noise, sigmas, self._noisy(latents), self._target(latents))
         pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
         dpred = self._dpred(pred)
-        ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws)
+        ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws, gscale=gscale)
         self.model.backward_impl(dpred)
         return loss_out
+
+    def optimize_device(self, latents, embeddings, generator=None, gscale=1.0):
+        """The trainer's step (train_sana.py:163-219 + the backward of common/trainer.py:344) on the allocation-free path:
+        same draws in the same order as ``optimize`` (noise first, then the timestep indices, both from ``generator`` on the
+        CPU as the reference draws them), but the host side is one packed pinned buffer and ONE H2D copy, and forward, loss,
+        dL/dpred (scaled by ``gscale`` = 1 / gradient_accumulation_steps) and backward are straight-line C-ABI launches with
+        no autograd objects.  -> loss (0-dim fp32 device tensor); the gradients are already in the flat gradient buffer."""
+        if latents.is_cuda or embeddings[0].is_cuda:
+            raise ValueError("optimize_device stages host batches (the sampler yields CPU tensors)")
+        B, T = len(embeddings), self.pad_to
+        C = embeddings[0].shape[1]
+        lens = [int(e.shape[0]) for e in embeddings]
+        if max(lens) > T:
+            raise ValueError(f"embedding longer than pad length {T}")
+        rows = sum(lens)
+        pairs = [(b, t) for b, L in enumerate(lens) for t in range((L + 63) // 64)]          # dK/dV work list (ops.kv_work_list)
+        nlat = latents.numel()
+        (o_lat, o_noise, o_emb, o_off, o_t, o_sig, o_work), total = _layout(
+            [2 * nlat, 2 * nlat, 2 * rows * C, 4 * (B + 1), 4 * B, 2 * B, 8 * len(pairs)])
+        st = self._stager = getattr(self, "_stager", None) or _Stager(self.dev)
+        pin = st.begin(total)
+
+        def seg(o, n, dtype):
+            return pin[o:o + n].view(dtype)
+        seg(o_lat, 2 * nlat, BF16).view(latents.shape).copy_(latents)
+        torch.randn(latents.shape, generator=generator, dtype=BF16, out=seg(o_noise, 2 * nlat, BF16).view(latents.shape))   # :183
+        _, t, sig = self.scheduler.sample(B, generator)                                                                  # :185-204
+        torch.cat([e.to(BF16) for e in embeddings], out=seg(o_emb, 2 * rows * C, BF16).view(rows, C))
+        offs = [0]
+        for L in lens:
+            offs.append(offs[-1] + L)
+        seg(o_off, 4 * (B + 1), torch.int32).copy_(torch.tensor(offs, dtype=torch.int32))
+        seg(o_t, 4 * B, torch.float32).copy_(t)
+        seg(o_sig, 2 * B, BF16).copy_(sig)
+        seg(o_work, 8 * len(pairs), torch.int32).copy_(torch.tensor(pairs, dtype=torch.int32).flatten())
+        land = st.commit(total)
+
+        def dseg(o, n, dtype):
+            return land[o:o + n].view(dtype)
+        lat_d = dseg(o_lat, 2 * nlat, BF16).view(latents.shape)
+        noise_d = dseg(o_noise, 2 * nlat, BF16).view(latents.shape)
+        fixed = getattr(self, "_fixed", None)
+        if fixed is None or fixed[0].shape != (B, T, C):
+            fixed = self._fixed = (torch.empty(B, T, C, dtype=BF16, device=self.dev),
+                                   torch.empty(B, T, dtype=torch.int64, device=self.dev),
+                                   torch.empty(B, T, dtype=torch.float32, device=self.dev),
+                                   torch.empty(B, dtype=torch.int32, device=self.dev),
+                                   torch.zeros(1, dtype=torch.float32, device=self.dev))
+        enc, mask, bias, kvl, loss_out = fixed
+        ops.pad_mask(dseg(o_emb, 2 * rows * C, BF16).view(rows, C), dseg(o_off, 4 * (B + 1), torch.int32), B, T, C, enc, mask,
+                     bias, kvl)                                                                                          # :168-180
+        self.train_step_device(lat_d, enc, (bias, kvl), noise_d, dseg(o_t, 4 * B, torch.float32), dseg(o_sig, 2 * B, BF16),
+                               loss_out, kv_work=dseg(o_work, 8 * len(pairs), torch.int32).view(len(pairs), 2), gscale=gscale)
+        return loss_out[0].clone()
 
     def _scratch(self, name, like):
         t = getattr(self, name, None)
