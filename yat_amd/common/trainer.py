@@ -206,6 +206,12 @@ class Model:
         else:
             self.accelerator.unwrap_model(self.model).save_pretrained(f"models/{self.global_step}")
 
+    def make_optimizer(self, trained):
+        """:246-248 + :347-356 -- clip(1.0) + AdamW (+EMA) over the flat parameter buffer of a HIP model / adapter set."""
+        p = self.params
+        return FlatAdamW(trained, lr=p.learning_rate, weight_decay=p.weight_decay, max_grad_norm=1.0,
+                         use_ema=bool(getattr(p, "use_ema", False)), ema_decay=0.999, overlap_update=True)
+
     def make_sampler(self):
         """Cached-feature sampler over this rank's shard range (the intended path of :165-181)."""
         from .bucket_sampler import BucketSampler
@@ -267,9 +273,7 @@ class Model:
                   f"trainable%: {100.0 * n_ad / (self.model.numel_flat + n_ad):.4f}")       # print_trainable_parameters (:239)
         # with adapters only they are trained (the base has no gradients, so AdamW leaves it alone in the reference too)
         trained = self.adapters if self.adapters is not None else self.model
-        self.optimizer = FlatAdamW(trained, lr=p.learning_rate, weight_decay=p.weight_decay, max_grad_norm=1.0,
-                                   use_ema=bool(getattr(p, "use_ema", False)), ema_decay=0.999,
-                                   overlap_update=True)
+        self.optimizer = self.make_optimizer(trained)
         self.accelerator.prepare(trained)
         self.lr_scheduler = None
         if getattr(p, "warmup_steps", None) is not None:

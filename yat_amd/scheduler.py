@@ -36,16 +36,22 @@ class DDPMSchedule:
     train_pixart_sigma.py:37 loads it; used at :173-176: ``timesteps = scheduler.timesteps[indices]`` (int64, = 999 - index)
     and ``add_noise`` = sqrt(acp_t) x + sqrt(1 - acp_t) n with the table cast to the sample dtype (bf16) first."""
 
-    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02):
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear"):
         self.num_train_timesteps = num_train_timesteps
-        self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        if beta_schedule == "linear":
+            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":           # [RECALL] the SD1.5 scheduler config (train_sd15.py:30-31)
+            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(f"beta_schedule {beta_schedule!r}")
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
         self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
         acp = self.alphas_cumprod.to(torch.bfloat16)
         self.sqrt_alpha_prod = acp ** 0.5                      # bf16 [1000], each op rounded as in add_noise
         self.sqrt_one_minus_alpha_prod = (1 - acp) ** 0.5
         self.config = type("Cfg", (), {"num_train_timesteps": num_train_timesteps, "beta_start": beta_start,
-                                       "beta_end": beta_end, "beta_schedule": "linear"})()
+                                       "beta_end": beta_end, "beta_schedule": beta_schedule})()
 
     def sample(self, batch_size: int, generator: torch.Generator | None = None):
         """-> (timesteps int64 [B], sqrt_alpha_prod bf16 [B], sqrt_one_minus_alpha_prod bf16 [B]) on the CPU; the draw is
