@@ -310,13 +310,16 @@ def main():
     ts_gen = torch.Generator().manual_seed(77 + rank)
 
     OPT_TIMER = None
+    t_dev = torch.empty(B, dtype=torch.float32, device=dev)        # persistent: the step's launch plan holds their addresses
+    sig_dev = torch.empty(B, dtype=torch.bfloat16, device=dev)
 
     def step(i):
         b = batches[i % len(batches)]
         ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)                       # train_sana.py:168-180
         noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)  # :183
         _, t_host, sig_host = recipe.scheduler.sample(B, ts_gen)                                    # :185-204
-        t_dev, sig_dev = t_host.to(dev, non_blocking=True), sig_host.to(dev, non_blocking=True)
+        t_dev.copy_(t_host, non_blocking=True)
+        sig_dev.copy_(sig_host, non_blocking=True)
         recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, sig_dev, loss_dev, kv_work=b["work"])  # :206-218 + bwd
         if ddp:
             ddp.wait()

@@ -253,6 +253,9 @@ int yat_f32_to_bf16(int64_t n, const float* x, void* y, yat_stream_t stream);
 
 /* batched transpose in[B,R,C] -> out[B,C,R]: NCHW latents <-> token-major rows
  * (PatchEmbed flatten/transpose patched_sana_transformer.py:284; unpatchify :336-340). */
+/* clears nbytes at ptr on the stream (the fp32 gradient accumulators the backward zeroes per block): an entry point rather
+ * than a torch op so that a step is nothing but C-ABI calls + stream/event operations (yat_amd/flat.py launch plans) */
+int yat_memset_zero(void* ptr, uint64_t nbytes, yat_stream_t stream);
 int yat_transpose_bf16(int B, int R, int C, const void* in, void* out, yat_stream_t stream);
 
 /* sinusoidal timestep projection (diffusers get_timestep_embedding(t,256,flip_sin_to_cos=True),

@@ -240,3 +240,40 @@ def test_real_width_block_matches_oracle():
     tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
     print(f"[parity] real width: grads hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
     assert tot_h <= 1.3 * tot_b + 1e-3
+
+
+def test_launch_plan_replay_is_bit_identical():
+    """The device path replays a recorded launch plan (yat_amd/flat.py ``planned``) once a (bucket shape, buffer addresses,
+    schedule) combination has run: eight optimizer steps alternating between two buckets, with text lengths -- and hence the
+    attention work list and the staging layout of the ragged rows -- changing every step, must give bit-identical losses and
+    parameters with plans on and off."""
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.optim import FlatAdamW
+    from oracle.sana_ref import SanaConfig as RefCfg
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    rcfg = RefCfg.tiny(num_layers=3, modified_blocks=[1])
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    runs = []
+    for plans in (True, False):
+        hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV).init_synthetic(4)
+        hip.use_plans = plans
+        opt = FlatAdamW(hip, lr=1e-3, weight_decay=0.01, overlap_update=True)
+        recipe = SanaRecipe(hip, pad_to=128, device=DEV)
+        g = torch.Generator().manual_seed(9)
+        losses = []
+        for step in range(8):
+            h, w = ((8, 16), (12, 10))[step % 2]
+            latents = (torch.randn(4, rcfg.in_channels, h, w, generator=g) * 0.5).to(BF)
+            lens = torch.randint(1, 129, (4,), generator=g).tolist()
+            embs = [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in lens]
+            losses.append(recipe.optimize_device(latents, embs, torch.Generator().manual_seed(100 + step)))
+            opt.step()
+        hip.join_pending_update()
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), hip.flat_param.clone(), getattr(hip, "plan_replays", 0), len(hip._plans)))
+    (l_a, p_a, replays, nplans), (l_b, p_b, r_b, n_b) = runs
+    print(f"[plans] {nplans} plans recorded, {replays} replays; losses {l_a.tolist()}")
+    assert r_b == 0 and n_b == 0
+    # step 0 records without optimizer events, steps 1-2 record the steady-state plans of the two buckets (fwd + bwd each)
+    assert replays >= 2 * 4 and nplans <= 8
+    assert torch.equal(l_a, l_b) and torch.equal(p_a, p_b)

@@ -199,6 +199,11 @@ int yat_f32_to_bf16(int64_t n, const float* x, void* y, yat_stream_t stream) {
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
+int yat_memset_zero(void* ptr, uint64_t nbytes, yat_stream_t stream) {
+    if (!ptr || !nbytes) return YAT_EINVAL;
+    const hipError_t e = hipMemsetAsync(ptr, 0, nbytes, (hipStream_t)stream);
+    return e == hipSuccess ? YAT_OK : (int)e;
+}
 int yat_transpose_bf16(int B, int R, int Cc, const void* in, void* out, yat_stream_t stream) {
     if (B <= 0 || R <= 0 || Cc <= 0 || B > 65535 || !in || !out || in == out) return YAT_EINVAL;
     hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, R, Cc,

@@ -8,10 +8,13 @@ still sees the diffusers keys.  Activations kept for the backward live in a pers
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
+
+from . import ops
 
 BF16 = torch.bfloat16
 
@@ -46,6 +49,10 @@ class FlatParamModule(nn.Module):
         self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
         self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation
         self._arena, self._chains, self._side = {}, {}, None
+        self._consts, self._plans = {}, {}
+        # launch plans: replay a recorded step instead of re-deriving ~600 launches in Python (see ``planned``)
+        self.use_plans = os.environ.get("YAT_LAUNCH_PLANS", "1") != "0"
+        self.plan_dynamic = {}            # per-step integers of the recorded calls (ops.Recorder.dynamic), set by the caller
         self._saved = None
         self._anchor = torch.zeros((), device=self.dev, requires_grad=True)
         self.gradient_checkpointing = False
@@ -102,9 +109,87 @@ class FlatParamModule(nn.Module):
         n = math.prod(shape)
         t = self._arena.get(name)
         if t is None or t.numel() < n or t.dtype != dtype:
+            if t is not None:
+                self._plans.clear()       # a buffer moves: every recorded plan may hold its old address
             t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
             self._arena[name] = t
         return t[:n].view(shape)
+
+    def _const(self, name, shape, dtype, value):
+        """A device constant (zeros / a fill value), created once per (name, shape): no per-step fill launch."""
+        key = (name, tuple(shape), dtype, value)
+        t = self._consts.get(key)
+        if t is None:
+            t = self._consts[key] = torch.full(tuple(shape), value, dtype=dtype, device=self.dev)
+        return t
+
+    # ------------------------------------------------------------------ launch plans
+    # The forward / backward of a training step are pure functions of (shapes, buffer addresses, schedule flags): every
+    # activation lives in the arena, so a second step on the same bucket issues the SAME C calls with the SAME arguments.
+    # ``planned`` records them once (ops.Recorder: C-ABI calls through ops._lib(), stream / event operations through the
+    # helpers below) and afterwards replays the flat list: host cost per step drops from ~25 ms of Python (tensor slicing,
+    # stride arithmetic, struct building, stream look-ups for ~600 launches) to one tight loop.  Not a graph capture: the
+    # launches, streams and events are exactly those of the recorded run, and anything dynamic stays dynamic -- the input
+    # buffers' contents, and the integers registered in ``plan_dynamic`` (the length of the attention work list).
+    def planned(self, kind, key, fn):
+        if not self.use_plans or self.adapters is not None or ops.GEMM_TIMER is not None or ops.RECORDER is not None:
+            return fn()
+        key = (kind, torch.cuda.current_stream().cuda_stream) + tuple(key)
+        plan = self._plans.get(key)
+        if plan is not None:
+            self.plan_replays = getattr(self, "plan_replays", 0) + 1
+            for name, slots in plan["dynamic"].items():
+                v = self.plan_dynamic[name]
+                for e, a in slots:
+                    entry = plan["entries"][e]
+                    if entry[1][a] != v:
+                        entry[1] = entry[1][:a] + (v,) + entry[1][a + 1:]
+            for f, args in plan["entries"]:
+                rc = f(*args)
+                if rc:
+                    raise RuntimeError(f"launch plan replay: {getattr(f, '__name__', f)} failed with {rc}")
+            self._saved = plan["saved"] if kind == "fwd" else self._saved
+            return plan["result"]
+        if len(self._plans) >= 128:
+            self._plans.clear()
+        rec = ops.Recorder(ops._l.load())
+        ops.RECORDER = rec
+        try:
+            result = fn()
+        finally:
+            ops.RECORDER = None
+        self._plans[key] = dict(entries=rec.entries, dynamic=rec.dynamic, result=result, saved=self._saved)
+        return result
+
+    # stream / event operations of the model code go through these, so that a recorder sees them
+    def _ev_record(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        if ops.RECORDER is not None:
+            ops.RECORDER.add(ev.record, stream)
+        return ev
+
+    def _ev_wait(self, stream, ev):
+        stream.wait_event(ev)
+        if ops.RECORDER is not None:
+            ops.RECORDER.add(stream.wait_event, ev)
+
+    def _wait_stream(self, waiter, waited):
+        waiter.wait_stream(waited)
+        if ops.RECORDER is not None:
+            ops.RECORDER.add(waiter.wait_stream, waited)
+
+    def _callback(self, fn, *args):
+        """A host callback in launch order (the data-parallel hook): runs now and on every replay, under the torch stream
+        that is current now."""
+        fn(*args)
+        if ops.RECORDER is not None:
+            st = torch.cuda.current_stream()
+
+            def again(st=st, fn=fn, args=args):
+                with torch.cuda.stream(st):
+                    fn(*args)
+            ops.RECORDER.add(again)
 
     def _fused(self, first_key, rows_total, cols=None):
         """Contiguous view spanning consecutive parameter tensors (e.g. to_q|to_k|to_v -> [3D, D])."""

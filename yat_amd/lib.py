@@ -66,6 +66,7 @@ SIGNATURES = {
     "yat_act_bwd": (I, [I64, I, P, P, P, P]),
     "yat_add_bf16": (I, [I64, P, P, P, P]),
     "yat_f32_to_bf16": (I, [I64, P, P, P]),
+    "yat_memset_zero": (I, [P, U64, P]),
     "yat_transpose_bf16": (I, [I, I, I, P, P, P]),
     "yat_timestep_embed_fwd": (I, [I, I, P, P, P]),
     "yat_pad_mask": (I, [I, I, I, P, P, P, P, P, P, P]),

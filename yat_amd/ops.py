@@ -35,8 +35,45 @@ def _gemm_ws(device):
 GEMM_TIMER = None
 
 
+class Recorder:
+    """Launch-plan recording (yat_amd/flat.py ``planned``).  While one is installed every C-ABI call made through ``_lib()``
+    is executed AND appended as ``[fn, args]``; stream / event operations are appended by the model code through
+    FlatParamModule's helpers.  A step over the same buffers is then replayed as a flat list of calls -- no tensor slicing, no
+    stride arithmetic, no struct building, no stream look-ups on the host.  ``dynamic[name]`` lists (entry, argument) slots
+    whose integer value changes from step to step (the length of the attention work list)."""
+
+    _PURE = ("_workspace_bytes", "yat_version", "yat_gemm_epilogue_size", "yat_comm_")
+
+    def __init__(self, real):
+        self._real = real
+        self.entries = []
+        self.dynamic = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if any(tag in name for tag in self._PURE):
+            return fn
+        entries = self.entries
+
+        def call(*args):
+            entries.append([fn, args])
+            return fn(*args)
+        return call
+
+    def add(self, fn, *args):
+        """A host-side stream / event operation (or any callable) in launch order."""
+        self.entries.append([fn, args])
+
+    def mark_dynamic(self, name, arg_index):
+        """The call just recorded takes a per-step integer at ``arg_index``."""
+        self.dynamic.setdefault(name, []).append((len(self.entries) - 1, arg_index))
+
+
+RECORDER = None
+
+
 def _lib():
-    return _l.load()
+    return RECORDER if RECORDER is not None else _l.load()
 
 
 def _stream():
@@ -377,6 +414,8 @@ def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, 
                              _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
                              _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0), _p(work),
                              0 if work is None else work.shape[0], parts, _stream())
+    if RECORDER is not None and work is not None:
+        RECORDER.mark_dynamic("n_work", 25)              # the work list keeps its buffer; its length is per batch
     _l.check(rc, "yat_sdpa_bwd")
 
 
@@ -448,6 +487,14 @@ def act_bwd(x, dy, act, dx=None):
     dx = dx if dx is not None else torch.empty_like(x)
     _l.check(_lib().yat_act_bwd(x.numel(), ACT[act], _p(x), _p(dy), _p(dx), _stream()), "yat_act_bwd")
     return dx
+
+
+def zero_(t):
+    """t.zero_() as a C-ABI call (yat_memset_zero): recordable in a launch plan."""
+    if not t.is_contiguous():
+        raise ValueError("zero_: contiguous tensors only")
+    _l.check(_lib().yat_memset_zero(_p(t), t.numel() * t.element_size(), _stream()), "yat_memset_zero")
+    return t
 
 
 def add_bf16(a, b, out=None):

@@ -90,14 +90,15 @@ class FlatAdamW:
             self._stream = torch.cuda.Stream(device=m.flat_param.device)
         main = torch.cuda.current_stream()
         self._stream.wait_stream(main)
-        events = []
+        # one persistent event per bucket, re-recorded every step: the next forward's waits are then the same calls on
+        # the same objects step after step (a recorded launch plan can hold them)
+        if getattr(self, "_events", None) is None or len(self._events) != len(m.bucket_bounds):
+            self._events = [torch.cuda.Event() for _ in m.bucket_bounds]
         with torch.cuda.stream(self._stream):
-            for lo, hi in m.bucket_bounds:
+            for (lo, hi), ev in zip(m.bucket_bounds, self._events):
                 update(lo, hi)
-                ev = torch.cuda.Event()
                 ev.record(self._stream)
-                events.append(ev)
-        m.param_events = events
+        m.param_events = self._events
 
     def zero_grad(self, set_to_none=False):
         # the gradient clear is fused into step(); explicit calls (e.g. before the first step) still work

@@ -46,18 +46,21 @@ class _Stager:
     def __init__(self, dev):
         self.dev, self.pin, self.ev, self.k, self.land = dev, [None, None], [None, None], 0, None
 
-    def begin(self, nbytes):
+    def begin(self, nbytes, capacity=0):
+        """``capacity``: the most this caller will ever stage for the current shapes -- buffers are sized for it at once, so
+        their addresses (which recorded launch plans hold) do not move when a longer caption arrives."""
         k = self.k
         if self.ev[k] is not None:
             self.ev[k].synchronize()
-        if self.pin[k] is None or self.pin[k].numel() < nbytes:
-            self.pin[k] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8).pin_memory()
+        self.cap = max(getattr(self, "cap", 0), capacity, nbytes)
+        if self.pin[k] is None or self.pin[k].numel() < self.cap:
+            self.pin[k] = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
         return self.pin[k]
 
     def commit(self, nbytes):
         k = self.k
-        if self.land is None or self.land.numel() < nbytes:
-            self.land = torch.empty(self.pin[k].numel(), dtype=torch.uint8, device=self.dev)
+        if self.land is None or self.land.numel() < self.cap:
+            self.land = torch.empty(self.cap, dtype=torch.uint8, device=self.dev)
         self.land[:nbytes].copy_(self.pin[k][:nbytes], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -142,10 +145,17 @@ class SanaRecipe:
         Used by bench.py and the trainer fast path (no autograd objects, no allocation besides pred)."""
         bias, kvl = mask_bias_kvl
         noisy, target = ops.flow_mix(latents, noise, sigmas, self._noisy(latents), self._target(latents))
-        pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
+        dev_path = hasattr(self.model, "forward_device")
+        if dev_path:
+            pred = self.model.forward_device(noisy, enc, timesteps, bias, kvl, kv_work=kv_work)
+        else:
+            pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
         dpred = self._dpred(pred)
         ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws, gscale=gscale)
-        self.model.backward_impl(dpred)
+        if dev_path:
+            self.model.backward_device(dpred)
+        else:
+            self.model.backward_impl(dpred)
         return loss_out
 
     def optimize_device(self, latents, embeddings, generator=None, gscale=1.0):
@@ -164,10 +174,13 @@ class SanaRecipe:
         rows = sum(lens)
         pairs = [(b, t) for b, L in enumerate(lens) for t in range((L + 63) // 64)]          # dK/dV work list (ops.kv_work_list)
         nlat = latents.numel()
-        (o_lat, o_noise, o_emb, o_off, o_t, o_sig, o_work), total = _layout(
-            [2 * nlat, 2 * nlat, 2 * rows * C, 4 * (B + 1), 4 * B, 2 * B, 8 * len(pairs)])
+        max_pairs = B * ((T + 63) // 64)
+        # fixed-size segments first (their device addresses then depend on the bucket shape only: a recorded launch plan
+        # stays valid from batch to batch); the ragged text rows go last
+        (o_lat, o_noise, o_off, o_t, o_sig, o_work, o_emb), total = _layout(
+            [2 * nlat, 2 * nlat, 4 * (B + 1), 4 * B, 2 * B, 8 * max_pairs, 2 * rows * C])
         st = self._stager = getattr(self, "_stager", None) or _Stager(self.dev)
-        pin = st.begin(total)
+        pin = st.begin(total, capacity=total + 2 * (B * T - rows) * C)
 
         def seg(o, n, dtype):
             return pin[o:o + n].view(dtype)
@@ -203,10 +216,12 @@ class SanaRecipe:
         return loss_out[0].clone()
 
     def _scratch(self, name, like):
-        t = getattr(self, name, None)
-        if t is None or t.shape != like.shape:
-            t = torch.empty_like(like)
-            setattr(self, name, t)
+        """One persistent buffer per (name, shape): a bucket that comes back finds its buffers at the same addresses."""
+        cache = self.__dict__.setdefault("_scratch_cache", {})
+        key = (name, tuple(like.shape), like.dtype)
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.empty_like(like)
         return t
 
     def _noisy(self, like):

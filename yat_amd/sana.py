@@ -124,7 +124,7 @@ class _WholeModel(torch.autograd.Function):
     def forward(ctx, anchor, model, latents, enc, timestep, mask):
         ctx.model = model
         work, model.next_kv_work = getattr(model, "next_kv_work", None), None      # one-shot hint from the recipe
-        return model.forward_impl(latents, enc, timestep, mask, kv_work=work)
+        return model.forward_impl(latents, enc, timestep, mask, kv_work=work).clone()     # (the prediction lives in the arena)
 
     @staticmethod
     def backward(ctx, dout):
@@ -174,8 +174,34 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             out = _WholeModel.apply(self._anchor, self, hidden_states, encoder_hidden_states, timestep,
                                     encoder_attention_mask)
         else:
-            out = self.forward_impl(hidden_states, encoder_hidden_states, timestep, encoder_attention_mask)
+            out = self.forward_impl(hidden_states, encoder_hidden_states, timestep, encoder_attention_mask).clone()
         return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    # ------------------------------------------------------------------ device path (launch plans, yat_amd/flat.py)
+    def _schedule_flags(self):
+        return (self.side_wgrad, self.keep_glu_u, self.fwd_chains, self.group_big_wgrad, self.group_small_wgrad,
+                self.defer_wgrad, self.grouped_wgrad, self.training)
+
+    def forward_device(self, latents, enc, timestep, key_bias, kv_len, kv_work=None):
+        """``forward_impl`` on device-resident inputs in persistent buffers, replayed from a launch plan when this (shapes,
+        addresses, schedule) combination has run before.  The prediction is an arena buffer: consume it before the next call."""
+        pev = self.param_events
+        key = (latents.data_ptr(), tuple(latents.shape), enc.data_ptr(), tuple(enc.shape), timestep.data_ptr(),
+               key_bias.data_ptr(), kv_len.data_ptr(), None if pev is None else id(pev[0]), self._schedule_flags())
+        out = self.planned("fwd", key, lambda: self.forward_impl(latents, enc, timestep, None, key_bias=key_bias,
+                                                                 kv_len=kv_len, kv_work=kv_work))
+        self.param_events = None          # consumed by the forward (recorded or replayed)
+        self._saved.kv_work = kv_work
+        return out
+
+    def backward_device(self, dpred):
+        S = self._saved
+        work = S.kv_work
+        if work is not None:
+            self.plan_dynamic["n_work"] = int(work.shape[0])
+        key = (id(S), dpred.data_ptr(), self.accumulate_grads, id(self.grad_ready), None if work is None else work.data_ptr(),
+               self._schedule_flags())
+        self.planned("bwd", key, lambda: self.backward_impl(dpred))
 
     # ------------------------------------------------------------------ forward
     def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None, kv_work=None):
@@ -221,7 +247,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
         def params_ready(bucket, stream=main):
             if pev is not None:
-                stream.wait_event(pev[bucket])
+                self._ev_wait(stream, pev[bucket])
 
         # The text branch (caption projection, RMSNorm, every block's K/V projection) does not depend on the latent
         # stream until the first cross-attention: it runs on the second stream, filling CUs the single-round GEMMs of
@@ -243,13 +269,11 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 bkv, _ = self._fused(pre + "attn2.to_k.bias", 2 * D)
                 S.kv2.append(lin(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D))))
                 if side is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(cur)
-                    S.kv_ready.append(ev)
+                    S.kv_ready.append(self._ev_record(cur))
 
         params_ready(0)
         if side is not None:
-            side.wait_stream(main)
+            self._wait_stream(side, main)
             with torch.cuda.stream(side):
                 text_branch()
         else:
@@ -298,11 +322,11 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         S.modf = buf("modf", (B, 2, D))
         S.hf, S.meanf, S.rstdf = buf("hf", (M, D)), buf("meanf", (M,), f32), buf("rstdf", (M,), f32)
         out_tok = buf("out_tok", (M, Cout))
-        pred = torch.empty(B, Cout, N, dtype=BF16, device=dev)
+        pred = buf("pred", (B, Cout, N))                 # (arena: the caller consumes it before the next forward)
         la_per_image = H1 * 33 * 32
         if cfg.modified_blocks:
-            zero_bias = buf("sa_zero_bias", (B, N), f32).zero_()
-            full_len = torch.full((B,), N, dtype=torch.int32, device=dev)
+            zero_bias = self._const("sa_zero_bias", (B, N), f32, 0.0)
+            full_len = self._const("sa_full_len", (B,), torch.int32, N)
             S.zero_bias, S.full_len = zero_bias, full_len
 
         def run_chain(b0, b1, stream):
@@ -333,7 +357,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                                rows_per_batch=N)
                 lin(A.x1[rs], P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"], out=A.q2[rs])
                 if side is not None:
-                    stream.wait_event(S.kv_ready[i])
+                    self._ev_wait(stream, S.kv_ready[i])
                 kv = A.kv2[ts]
                 ops.sdpa_fwd(A.q2[rs], kv[:, :D], kv[:, D:], nb, N, T, H2, dh2, scale2, key_bias[bs], kv_len[bs], A.o2[rs],
                              A.lse[bs])
@@ -361,20 +385,17 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             run_chain(0, B, main)
         else:
             bounds = [(B * c) // nchain for c in range(nchain + 1)]
-            fork = torch.cuda.Event()
-            fork.record(main)
+            fork = self._ev_record(main)
             joins = []
             for c in range(1, nchain):
                 st = self._chain_stream(c)
-                st.wait_event(fork)
+                self._ev_wait(st, fork)
                 with torch.cuda.stream(st):
                     run_chain(bounds[c], bounds[c + 1], st)
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                joins.append(ev)
+                    joins.append(self._ev_record(st))
             run_chain(bounds[0], bounds[1], main)
             for ev in joins:
-                main.wait_event(ev)
+                self._ev_wait(main, ev)
         self._saved = S
         return pred.view(B, Cout, h, w)
 
@@ -431,7 +452,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             if side is None:
                 fn()
                 return
-            side.wait_stream(torch.cuda.current_stream())
+            self._wait_stream(side, torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 fn()
 
@@ -446,17 +467,19 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             if side is None:
                 run()
                 return
-            side.wait_stream(main)
+            self._wait_stream(side, main)
             with torch.cuda.stream(side):
                 run()
 
         # ---- output head
-        d_out_tok = ops.transpose(dpred.to(BF16).contiguous().view(B, Cout, N), buf("d_out_tok", (B, N, Cout))).view(M, Cout)
+        if dpred.dtype != BF16 or not dpred.is_contiguous():
+            dpred = dpred.to(BF16).contiguous()
+        d_out_tok = ops.transpose(dpred.view(B, Cout, N), buf("d_out_tok", (B, N, Cout))).view(M, Cout)
         wgrad(d_out_tok, S.hf, "proj_out.weight", (Cout, D), "proj_out.bias")
         dhf = ops.linear_dgrad(d_out_tok, P["proj_out.weight"], out=buf("dh", (M, D)))
-        dmodf = buf("dmodf", (B, 2, D), f32).zero_()
-        dtmod = buf("dtmod", (B, 6 * D), f32).zero_()
-        demb = buf("demb", (B, D), f32).zero_()
+        dmodf = ops.zero_(buf("dmodf", (B, 2, D), f32))
+        dtmod = ops.zero_(buf("dtmod", (B, 6 * D), f32))
+        demb = ops.zero_(buf("demb", (B, D), f32))
         dxa, dxb = buf("dx_a", (M, D)), buf("dx_b", (M, D))
         dmodf2d = dmodf.view(B, 2 * D)
         dx = ops.ln_modulate_bwd(S.x_last, S.meanf, S.rstdf, S.modf.view(B, 2 * D)[:, D:2 * D], 2 * D, N, dhf, None, dxa,
@@ -473,10 +496,10 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             A = S.blocks[i]
             par = i & 1
             if set_done[par] is not None:
-                main.wait_event(set_done[par])                # block i+2's weight gradients have read this set
+                self._ev_wait(main, set_done[par])            # block i+2's weight gradients have read this set
                 set_done[par] = None
             mod2d = A.mod.view(B, 6 * D)
-            dmod = buf(f"dmod.{par}", (B, 6, D), f32).zero_()
+            dmod = ops.zero_(buf(f"dmod.{par}", (B, 6, D), f32))
             dmod2d = dmod.view(B, 6 * D)
             deferred = []                                     # (dy, x, dW) of this block
 
@@ -485,7 +508,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 if side is None:
                     fn()
                     return
-                side.wait_stream(main)
+                self._wait_stream(side, main)
                 with torch.cuda.stream(side):
                     fn()
 
@@ -620,22 +643,20 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             if side is None:
                 block_grads()
                 if self.grad_ready is not None:
-                    self.grad_ready(i + 1)
+                    self._callback(self.grad_ready, i + 1)
             else:
-                side.wait_stream(main)
+                self._wait_stream(side, main)
                 with torch.cuda.stream(side):
                     block_grads()
                     # bucket i+1 is complete once the side stream gets here (it has waited for the main stream's
                     # share: the fused bias / depthwise gradients); the DDP hook records its event on the CURRENT
                     # stream, so the all-reduce follows the side stream and the dependent chain never waits for it
                     if self.grad_ready is not None:
-                        self.grad_ready(i + 1)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                set_done[par] = ev
+                        self._callback(self.grad_ready, i + 1)
+                    set_done[par] = self._ev_record(side)
         # ---- embedders (small: back on the main stream)
         if side is not None:
-            main.wait_stream(side)
+            self._wait_stream(main, side)
             side = None
         wgrad(dx, S.x_tok, "patch_embed.proj.weight", (D, Cin), "patch_embed.proj.bias")
         # caption branch
@@ -659,7 +680,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         dz1 = ops.act_bwd(S.z1, de1, "silu", buf("te_d3", (B, D)))
         wgrad(dz1, S.tproj, "time_embed.emb.timestep_embedder.linear_1.weight", (D, 256), "time_embed.emb.timestep_embedder.linear_1.bias")
         if self.grad_ready is not None:
-            self.grad_ready(0)
+            self._callback(self.grad_ready, 0)
         if ad is not None:
             ad.project()                  # d_delta_w (flat gradient slots of the frozen targets) -> adapter gradients
 
