@@ -349,11 +349,6 @@ def main():
             torch.cuda.synchronize()
             log(f"first step done, loss={loss_dev.item():.4f}")
     barrier()
-    th = time.perf_counter()
-    step(args.warmup)                          # host cost of one step: enqueue from an idle GPU, before it can push back
-    host_ms = 1e3 * (time.perf_counter() - th)
-    barrier()
-    log(f"host enqueue of one step from idle: {host_ms:.1f} ms")
     log(f"timing {args.steps} steps")
     t0 = time.perf_counter()
     flops = 0.0
@@ -370,6 +365,16 @@ def main():
         elapsed = te.item()
     loss_val = loss_dev.item()
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps, loss={loss_val:.4f}")
+    # host cost of one step: enqueue onto an idle GPU (nothing pushes back), every bucket's launch plan already recorded
+    host_ms = []
+    for i in range(len(BUCKETS)):
+        barrier()
+        th = time.perf_counter()
+        step(args.warmup + args.steps + i)
+        host_ms.append(1e3 * (time.perf_counter() - th))
+    barrier()
+    log(f"host enqueue of one step onto an idle GPU: {min(host_ms):.1f} ms (per bucket: {', '.join(f'{v:.1f}' for v in host_ms)}; "
+        f"launch plans {'on' if model.use_plans else 'off'})")
 
     # ---- roofline pass (after the timed region): per-launch GEMM durations by HIP events on the launch stream.
     # The step overlaps independent GEMMs on two streams, so in the timed region two kernels share the CUs and
@@ -408,6 +413,7 @@ def main():
                        "num_layers": cfg.num_layers, "params": model.numel_flat},
             "loss": loss_val,
             "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+            "host_enqueue_ms_per_step": min(host_ms),
             "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),
             "algorithmic_tflop_per_step": flops / args.steps / 1e12,
         }
