@@ -29,6 +29,13 @@ for (h, w) in ((32, 32), (16, 64), (24, 42), (44, 22)):
     dz = torch.empty(M, 2 * Hc, dtype=BF, device=dev)
     dw, db = torch.empty_like(wdw), torch.empty_like(bdw)
     ws = torch.empty(ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc), dtype=torch.uint8, device=dev)
+    u = torch.empty(M, 2 * Hc, dtype=BF, device=dev)
+    du = torch.randn(M, 2 * Hc, generator=g, device=dev).to(BF)
+    dzs = torch.empty(2 * Hc, dtype=BF, device=dev)
+    fu = timeit(lambda: ops.dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y, u_out=u))       # the step's configuration: keeps u
+    b2 = timeit(lambda: ops.dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, None, dz, dw, db, ws, dz_colsum=dzs, du=du))   # pass 2 only
+    print(f"dwconv {h:2d}x{w:2d}: in-step config  fwd+u={fu:7.1f}us ({(M * 2 * Hc * 2 + M * Hc) * 2 / fu / 1e6:5.2f} TB/s)  "
+          f"bwd2(du given)={b2:7.1f}us ({(M * 2 * Hc * 4) * 2 / b2 / 1e6:5.2f} TB/s)", flush=True)
     f = timeit(lambda: ops.dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y))
     b_ = timeit(lambda: ops.dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dw, db, ws))
     alg_f = (M * 2 * Hc + M * Hc) * 2
