@@ -323,3 +323,12 @@ def test_lokr_module_dropout_with_gradient_accumulation(mode):
         print(f"[parity] lokr {mode} dropout x accumulation, window {step}: {n_bad}/{n_all} adapter parameters differ bitwise "
               f"from torch AdamW (grad=None entries skipped)")
         assert n_bad <= 0.005 * n_all
+        # next window: the gradient oracle starts from the HIP side's updated adapters with cleared gradients
+        sd = ad.state_dict()
+        for name, w in wrapped.items():
+            pre = f"base_model.model.{name}."
+            with torch.no_grad():
+                w.lokr_w1.copy_(sd[pre + "lokr_w1"].cpu().float())
+                w.lokr_w2_a.copy_(sd[pre + "lokr_w2_a"].cpu().float())
+                w.lokr_w2_b.copy_(sd[pre + "lokr_w2_b"].cpu().float())
+            w.lokr_w1.grad = w.lokr_w2_a.grad = w.lokr_w2_b.grad = None
