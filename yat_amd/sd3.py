@@ -156,6 +156,9 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         offs, total = self._alloc_flat(specs, device)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers, first_key="norm1.linear.weight")
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"     # weight gradients / modulation linears on a 2nd stream
+        # the text stream's own chain (LayerNorm, projections, FFN on B*333 rows: GEMMs of 84..252 tiles that leave most CUs
+        # idle) on a third stream: it meets the image chain only at the joint attention
+        self.text_stream = os.environ.get("YAT_SD3_TEXT_STREAM", "1") != "0"
         self._pos = {}
 
     def init_synthetic(self, seed: int = 0):
@@ -282,6 +285,22 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         else:
             modulations()
 
+        text = self._chain_stream(1) if (self.text_stream and side is not None) else None
+        if text is not None:
+            text.wait_stream(main)                          # c0 (and, transitively, the parameters' readiness)
+
+        def on_text(fn):
+            """The text chain: its own stream when enabled (ordered among itself; explicit events towards the image chain)."""
+            if text is None:
+                return fn()
+            with torch.cuda.stream(text):
+                return fn()
+
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            return ev
+
         scale = 1.0 / math.sqrt(dh)
         S.zero_bias = buf("sa_zero_bias", (B, L), f32).zero_()
         S.len_joint = torch.full((B,), L, dtype=torch.int32, device=dev)
@@ -295,6 +314,8 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             A.x_in, A.c_in = x, c
             if side is not None:
                 main.wait_event(S.mod_ready[i])
+                if text is not None:
+                    text.wait_event(S.mod_ready[i])
             e1, ec = A.emb1, A.embc
             ld1, ldc = n1 * D, nc * D
 
@@ -303,17 +324,22 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                                            buf(f"b{i}.{tag}.mean", (rows,), f32), buf(f"b{i}.{tag}.rstd", (rows,), f32))
             # AdaLayerNormZero on both streams (the last block's text side: AdaLayerNormContinuous, scale first)
             A.h1, A.mean1, A.rstd1 = ln(x, e1[:, 0:D], e1[:, D:2 * D], ld1, N, "h1", M)
-            if last:
-                A.hc, A.cmean1, A.crstd1 = ln(c, ec[:, D:2 * D], ec[:, 0:D], ldc, T, "hc", Mt)
-            else:
-                A.hc, A.cmean1, A.crstd1 = ln(c, ec[:, 0:D], ec[:, D:2 * D], ldc, T, "hc", Mt)
             # joint attention: fused q|k|v projections of both streams -> per-head RMSNorm on q, k + row concatenation
             wqkv, _ = self._fused(b_ + "attn.to_q.weight", 3 * D, D)
             bqkv, _ = self._fused(b_ + "attn.to_q.bias", 3 * D)
             waqkv, _ = self._fused(b_ + "attn.add_q_proj.weight", 3 * D, D)
             baqkv, _ = self._fused(b_ + "attn.add_q_proj.bias", 3 * D)
+
+            def text_pre(c=c):
+                if last:
+                    A.hc, A.cmean1, A.crstd1 = ln(c, ec[:, D:2 * D], ec[:, 0:D], ldc, T, "hc", Mt)
+                else:
+                    A.hc, A.cmean1, A.crstd1 = ln(c, ec[:, 0:D], ec[:, D:2 * D], ldc, T, "hc", Mt)
+                A.qkv_c = lin(A.hc, waqkv, baqkv, out=buf(f"b{i}.qkv_c", (Mt, 3 * D)))
+            on_text(text_pre)
             A.qkv = lin(A.h1, wqkv, bqkv, out=buf(f"b{i}.qkv", (M, 3 * D)))
-            A.qkv_c = lin(A.hc, waqkv, baqkv, out=buf(f"b{i}.qkv_c", (Mt, 3 * D)))
+            if text is not None:
+                main.wait_event(event(text))                # the text side's q | k | v
             A.joint = buf(f"b{i}.joint", (B * L, 3 * D))
             A.jrstd = buf(f"b{i}.jrstd", (B * L, 2 * H), f32)
             ops.qknorm_concat_fwd(A.qkv, A.qkv_c, B, N, T, H, dh, eps, P[b_ + "attn.norm_q.weight"], P[b_ + "attn.norm_k.weight"],
@@ -324,6 +350,8 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             A.o_i = buf(f"b{i}.o_i", (M, D))
             A.o_c = None if last else buf(f"b{i}.o_c", (Mt, D))
             ops.joint_rows(A.o, A.o_i, A.o_c, B, N, T, to_joint=False)
+            if text is not None and not last:
+                text.wait_event(event(main))                # the attention output's text rows
             # hidden = hidden + gate_msa * to_out(attn)
             A.lin1 = buf(f"b{i}.lin1", (M, D))
             xa = lin(A.o_i, P[b_ + "attn.to_out.0.weight"], P[b_ + "attn.to_out.0.bias"], out=buf(f"b{i}.x1", (M, D)),
@@ -355,16 +383,20 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                     gate=e1[:, 5 * D:6 * D], ld_gate=ld1, residual=xa, rows_per_batch=N)
             # text stream (ends inside the attention of the last block)
             if not last:
-                A.clin1 = buf(f"b{i}.clin1", (Mt, D))
-                A.c1 = lin(A.o_c, P[b_ + "attn.to_add_out.weight"], P[b_ + "attn.to_add_out.bias"], out=buf(f"b{i}.c1", (Mt, D)),
-                           aux_out=A.clin1, gate=ec[:, 2 * D:3 * D], ld_gate=ldc, residual=c, rows_per_batch=T)
-                A.hc2, A.cmean2, A.crstd2 = ln(A.c1, ec[:, 3 * D:4 * D], ec[:, 4 * D:5 * D], ldc, T, "hc2", Mt)
-                A.zc = buf(f"b{i}.zc", (Mt, 4 * D))
-                A.fc = lin(A.hc2, P[b_ + "ff_context.net.0.proj.weight"], P[b_ + "ff_context.net.0.proj.bias"],
-                           out=buf(f"b{i}.fc", (Mt, 4 * D)), activation="gelu_tanh", aux_out=A.zc)
-                A.clin3 = buf(f"b{i}.clin3", (Mt, D))
-                c = lin(A.fc, P[b_ + "ff_context.net.2.weight"], P[b_ + "ff_context.net.2.bias"], out=buf(f"b{i}.c3", (Mt, D)),
-                        aux_out=A.clin3, gate=ec[:, 5 * D:6 * D], ld_gate=ldc, residual=A.c1, rows_per_batch=T)
+                def text_post(c=c):
+                    A.clin1 = buf(f"b{i}.clin1", (Mt, D))
+                    A.c1 = lin(A.o_c, P[b_ + "attn.to_add_out.weight"], P[b_ + "attn.to_add_out.bias"],
+                               out=buf(f"b{i}.c1", (Mt, D)), aux_out=A.clin1, gate=ec[:, 2 * D:3 * D], ld_gate=ldc, residual=c,
+                               rows_per_batch=T)
+                    A.hc2, A.cmean2, A.crstd2 = ln(A.c1, ec[:, 3 * D:4 * D], ec[:, 4 * D:5 * D], ldc, T, "hc2", Mt)
+                    A.zc = buf(f"b{i}.zc", (Mt, 4 * D))
+                    A.fc = lin(A.hc2, P[b_ + "ff_context.net.0.proj.weight"], P[b_ + "ff_context.net.0.proj.bias"],
+                               out=buf(f"b{i}.fc", (Mt, 4 * D)), activation="gelu_tanh", aux_out=A.zc)
+                    A.clin3 = buf(f"b{i}.clin3", (Mt, D))
+                    return lin(A.fc, P[b_ + "ff_context.net.2.weight"], P[b_ + "ff_context.net.2.bias"],
+                               out=buf(f"b{i}.c3", (Mt, D)), aux_out=A.clin3, gate=ec[:, 5 * D:6 * D], ld_gate=ldc,
+                               residual=A.c1, rows_per_batch=T)
+                c = on_text(text_post)
         # 5. output head: AdaLayerNormContinuous (scale first) + proj_out + unpatchify
         S.x_last = x
         if side is not None:
@@ -400,13 +432,28 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
 
+        text = self._chain_stream(1) if (self.text_stream and side is not None) else None
+        if text is not None:
+            text.wait_stream(main)
+
+        def on_text(fn):
+            if text is None:
+                return fn()
+            with torch.cuda.stream(text):
+                return fn()
+
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            return ev
+
         def off_chain(fn):
             """Weight / bias / modulation gradients: nothing on the dependent chain reads them -> second stream, right
-            behind their producer."""
+            behind their producer (the stream that is current: the image chain's or the text chain's)."""
             if side is None:
                 fn()
                 return
-            side.wait_stream(main)
+            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 fn()
 
@@ -451,12 +498,15 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             par = i & 1
             if set_done[par] is not None:
                 main.wait_event(set_done[par])             # block i+2's second-stream work has read this buffer set
+                if text is not None:
+                    text.wait_event(set_done[par])
                 set_done[par] = None
 
             def pb(name, shape, dtype=BF16):
                 return buf(f"{name}.{par}", shape, dtype)
             demb1 = buf(f"demb1.{par}.{n1}", (B, ld1), f32).zero_()
-            dembc = buf(f"dembc.{par}.{nc}", (B, ldc), f32).zero_()
+            dembc = buf(f"dembc.{par}.{nc}", (B, ldc), f32)
+            on_text(dembc.zero_)                           # (only the text chain accumulates into it)
             # ---- image feed-forward: x3 = xa + gate_mlp * (f1 W2^T + b2)
             dlin3 = pb("dlin3", (M, D))
             ops.gate_bwd(dx, A.lin3, e1[:, 5 * D:6 * D], ld1, N, dlin3, demb1[:, 5 * D:6 * D], ld1, ws_gate,
@@ -493,24 +543,28 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                          dbias=G[b_ + "attn.to_out.0.bias"], accumulate_bias=acc)
             wgrad(dlin1, A.o_i, G[b_ + "attn.to_out.0.weight"])
             do_i = dgrad(dlin1, P[b_ + "attn.to_out.0.weight"], out=buf("do_i", (M, D)))
-            # ---- text stream
+            # ---- text stream, first half: FFN and to_add_out backward -> the text rows of the attention-output gradient
             do_c = dc1 = None
             if not last:
-                dclin3 = pb("dclin3", (Mt, D))
-                ops.gate_bwd(dc, A.clin3, ec[:, 5 * D:6 * D], ldc, T, dclin3, dembc[:, 5 * D:6 * D], ldc, ws_gatec,
-                             dbias=G[b_ + "ff_context.net.2.bias"], accumulate_bias=acc)
-                wgrad(dclin3, A.fc, G[b_ + "ff_context.net.2.weight"])
-                dfc = dgrad(dclin3, P[b_ + "ff_context.net.2.weight"], out=buf("dfc", (Mt, 4 * D)))
-                dzc = ops.act_bwd(A.zc, dfc, "gelu_tanh", pb("dzc", (Mt, 4 * D)))
-                wgrad(dzc, A.hc2, G[b_ + "ff_context.net.0.proj.weight"], G[b_ + "ff_context.net.0.proj.bias"])
-                dhc2 = dgrad(dzc, P[b_ + "ff_context.net.0.proj.weight"], out=buf("dhc.0", (Mt, D)))
-                dc1 = ops.ln_modulate_bwd(A.c1, A.cmean2, A.crstd2, ec[:, 4 * D:5 * D], ldc, T, dhc2, dc, pb("dc1", (Mt, D)),
-                                          dembc[:, 3 * D:4 * D], dembc[:, 4 * D:5 * D], ldc, ws_lnc)
-                dclin1 = pb("dclin1", (Mt, D))
-                ops.gate_bwd(dc1, A.clin1, ec[:, 2 * D:3 * D], ldc, T, dclin1, dembc[:, 2 * D:3 * D], ldc, ws_gatec,
-                             dbias=G[b_ + "attn.to_add_out.bias"], accumulate_bias=acc)
-                wgrad(dclin1, A.o_c, G[b_ + "attn.to_add_out.weight"])
-                do_c = dgrad(dclin1, P[b_ + "attn.to_add_out.weight"], out=buf("do_c", (Mt, D)))
+                def text_bwd_a(dc=dc):
+                    dclin3 = pb("dclin3", (Mt, D))
+                    ops.gate_bwd(dc, A.clin3, ec[:, 5 * D:6 * D], ldc, T, dclin3, dembc[:, 5 * D:6 * D], ldc, ws_gatec,
+                                 dbias=G[b_ + "ff_context.net.2.bias"], accumulate_bias=acc)
+                    wgrad(dclin3, A.fc, G[b_ + "ff_context.net.2.weight"])
+                    dfc = dgrad(dclin3, P[b_ + "ff_context.net.2.weight"], out=buf("dfc", (Mt, 4 * D)))
+                    dzc = ops.act_bwd(A.zc, dfc, "gelu_tanh", pb("dzc", (Mt, 4 * D)))
+                    wgrad(dzc, A.hc2, G[b_ + "ff_context.net.0.proj.weight"], G[b_ + "ff_context.net.0.proj.bias"])
+                    dhc2 = dgrad(dzc, P[b_ + "ff_context.net.0.proj.weight"], out=buf("dhc.0", (Mt, D)))
+                    dc1_ = ops.ln_modulate_bwd(A.c1, A.cmean2, A.crstd2, ec[:, 4 * D:5 * D], ldc, T, dhc2, dc, pb("dc1", (Mt, D)),
+                                               dembc[:, 3 * D:4 * D], dembc[:, 4 * D:5 * D], ldc, ws_lnc)
+                    dclin1 = pb("dclin1", (Mt, D))
+                    ops.gate_bwd(dc1_, A.clin1, ec[:, 2 * D:3 * D], ldc, T, dclin1, dembc[:, 2 * D:3 * D], ldc, ws_gatec,
+                                 dbias=G[b_ + "attn.to_add_out.bias"], accumulate_bias=acc)
+                    wgrad(dclin1, A.o_c, G[b_ + "attn.to_add_out.weight"])
+                    return dc1_, dgrad(dclin1, P[b_ + "attn.to_add_out.weight"], out=buf("do_c", (Mt, D)))
+                dc1, do_c = on_text(text_bwd_a)
+                if text is not None:
+                    main.wait_event(event(text))
             # ---- joint attention backward
             do_j = buf("do_j", (B * L, D))
             ops.joint_rows(do_j, do_i, do_c, B, N, T, to_joint=True)       # (no text gradient in the last block: zeros)
@@ -527,10 +581,10 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             _, gbqkv = self._fused(b_ + "attn.to_q.bias", 3 * D)
             waqkv, gaqkv = self._fused(b_ + "attn.add_q_proj.weight", 3 * D, D)
             _, gbaqkv = self._fused(b_ + "attn.add_q_proj.bias", 3 * D)
+            if text is not None:
+                text.wait_event(event(main))               # dqkv_c
             wgrad(dqkv, A.h1, gqkv, gbqkv)
-            wgrad(dqkv_c, A.hc, gaqkv, gbaqkv)
             dh1 = dgrad(dqkv, wqkv, out=buf("dh.0", (M, D)))
-            dhc = dgrad(dqkv_c, waqkv, out=buf("dhc.0", (Mt, D)))
             # ---- AdaLayerNormZero backward: both modulations of the image stream share one LayerNorm
             nxt = buf("dx.b", (M, D)) if dx.data_ptr() == buf("dx.a", (M, D)).data_ptr() else buf("dx.a", (M, D))
             if dual:
@@ -541,13 +595,18 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             else:
                 dx = ops.ln_modulate_bwd(A.x_in, A.mean1, A.rstd1, e1[:, D:2 * D], ld1, N, dh1, dxa, nxt,
                                          demb1[:, 0:D], demb1[:, D:2 * D], ld1, ws_ln)
-            dcn = buf("dc.b", (Mt, D)) if (dc is not None and dc.data_ptr() == buf("dc.a", (Mt, D)).data_ptr()) else buf("dc.a", (Mt, D))
-            if last:                                       # AdaLayerNormContinuous: scale first, no residual path
-                dc = ops.ln_modulate_bwd(A.c_in, A.cmean1, A.crstd1, ec[:, 0:D], ldc, T, dhc, None, dcn,
-                                         dembc[:, D:2 * D], dembc[:, 0:D], ldc, ws_lnc)
-            else:
-                dc = ops.ln_modulate_bwd(A.c_in, A.cmean1, A.crstd1, ec[:, D:2 * D], ldc, T, dhc, dc1, dcn,
-                                         dembc[:, 0:D], dembc[:, D:2 * D], ldc, ws_lnc)
+            # ---- text stream, second half: the text side's q | k | v projection and its AdaLayerNorm backward
+            def text_bwd_b(dc=dc, dc1=dc1):
+                wgrad(dqkv_c, A.hc, gaqkv, gbaqkv)
+                dhc = dgrad(dqkv_c, waqkv, out=buf("dhc.0", (Mt, D)))
+                dcn = buf("dc.b", (Mt, D)) if (dc is not None and dc.data_ptr() == buf("dc.a", (Mt, D)).data_ptr()) \
+                    else buf("dc.a", (Mt, D))
+                if last:                                   # AdaLayerNormContinuous: scale first, no residual path
+                    return ops.ln_modulate_bwd(A.c_in, A.cmean1, A.crstd1, ec[:, 0:D], ldc, T, dhc, None, dcn,
+                                               dembc[:, D:2 * D], dembc[:, 0:D], ldc, ws_lnc)
+                return ops.ln_modulate_bwd(A.c_in, A.cmean1, A.crstd1, ec[:, D:2 * D], ldc, T, dhc, dc1, dcn,
+                                           dembc[:, 0:D], dembc[:, D:2 * D], ldc, ws_lnc)
+            dc = on_text(text_bwd_b)
 
             def block_done(demb1=demb1, dembc=dembc, b_=b_, i=i):
                 mod_grads(demb1, b_ + "norm1.linear.weight", b_ + "norm1.linear.bias", f"1.{i & 1}")
@@ -558,12 +617,17 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                 block_done()
             else:
                 side.wait_stream(main)
+                if text is not None:
+                    side.wait_stream(text)                 # the text chain's share of dembc and of this bucket's gradients
                 with torch.cuda.stream(side):
                     block_done()
                     ev = torch.cuda.Event()
                     ev.record(side)
                 set_done[par] = ev
         # ---- embedders (small: back on one stream)
+        if text is not None:
+            main.wait_stream(text)
+            text = None
         if side is not None:
             main.wait_stream(side)
             side = None
