@@ -342,6 +342,25 @@ int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_
                    void* ema_shadow, double ema_decay, int background, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * launch plans: replay a recorded sequence of entry-point calls and stream / event operations in ONE call.
+ * A training step over the same buffers issues the same ~900 launches and ~500 stream / event operations every time
+ * (yat_amd/flat.py records them); replaying the list from C costs ~1 us per entry instead of a host-language call each.
+ * replaces: nothing in the reference -- it is the host-side launch path of the step loop (common/trainer.py:337-344 drives
+ * diffusers / torch, whose per-op dispatch is what a step's host time consists of there too).
+ *   op >= 0: the entry point with that id (yat_plan_op_id(name); any int-returning yat_* function); a[i] = argument i
+ *            (integers and pointers in .i / .p, float and double parameters in .d);
+ *   YAT_PLAN_EVENT_RECORD: hipEventRecord(a[0].p, a[1].p);   YAT_PLAN_STREAM_WAIT_EVENT: hipStreamWaitEvent(a[0].p, a[1].p).
+ * Stops at the first failing entry: returns its status and stores its index in *failed_index.
+ * ------------------------------------------------------------------------------------------ */
+#define YAT_PLAN_MAX_ARGS 30
+#define YAT_PLAN_EVENT_RECORD (-1)
+#define YAT_PLAN_STREAM_WAIT_EVENT (-2)
+typedef union yat_plan_arg { int64_t i; double d; void* p; } yat_plan_arg;
+typedef struct yat_plan_entry { int32_t op; int32_t nargs; yat_plan_arg a[YAT_PLAN_MAX_ARGS]; } yat_plan_entry;
+int yat_plan_op_id(const char* name);    /* -1: not a replayable entry point */
+int yat_plan_replay(const yat_plan_entry* entries, int n, int* failed_index);
+
+/* ------------------------------------------------------------------------------------------ *
  * communication: data-parallel gradient reduction over RCCL / xGMI, one process per GPU.
  * replaces: Accelerate's DDP wrap -- Accelerator(...) + DistributedDataParallelKwargs common/trainer.py:31-37,
  *   accelerator.prepare (rank0 -> all parameter broadcast) :253, the bucketed all-reduce(avg) fired inside

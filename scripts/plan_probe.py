@@ -32,7 +32,7 @@ for plans in (True, False):
         t1 = time.perf_counter(); opt.step(); t2 = time.perf_counter()
         ts.append((1e3 * (t1 - t0), 1e3 * (t2 - t1)))
     torch.cuda.synchronize()
-    n = {k[0]: len(v["entries"]) for k, v in model._plans.items()}
+    n = {k[0]: (v.n_entries, len(v.segments)) for k, v in model._plans.items()}
     print(f"plans={plans}: fwd+bwd host ms {[round(a, 2) for a, _ in ts]}, optimizer host ms {[round(b, 2) for _, b in ts]}; "
           f"plan entries {n}; replays {getattr(model, 'plan_replays', 0)}")
 if os.environ.get("PROFILE"):

@@ -138,18 +138,10 @@ class FlatParamModule(nn.Module):
         plan = self._plans.get(key)
         if plan is not None:
             self.plan_replays = getattr(self, "plan_replays", 0) + 1
-            for name, slots in plan["dynamic"].items():
-                v = self.plan_dynamic[name]
-                for e, a in slots:
-                    entry = plan["entries"][e]
-                    if entry[1][a] != v:
-                        entry[1] = entry[1][:a] + (v,) + entry[1][a + 1:]
-            for f, args in plan["entries"]:
-                rc = f(*args)
-                if rc:
-                    raise RuntimeError(f"launch plan replay: {getattr(f, '__name__', f)} failed with {rc}")
-            self._saved = plan["saved"] if kind == "fwd" else self._saved
-            return plan["result"]
+            out = plan.replay(self.plan_dynamic)
+            if kind == "fwd":
+                self._saved = plan.saved
+            return out
         if len(self._plans) >= 128:
             self._plans.clear()
         rec = ops.Recorder(ops._l.load())
@@ -158,7 +150,8 @@ class FlatParamModule(nn.Module):
             result = fn()
         finally:
             ops.RECORDER = None
-        self._plans[key] = dict(entries=rec.entries, dynamic=rec.dynamic, result=result, saved=self._saved)
+        from .plan import LaunchPlan
+        self._plans[key] = LaunchPlan(rec.entries, rec.dynamic, result=result, saved=self._saved)
         return result
 
     # stream / event operations of the model code go through these, so that a recorder sees them
@@ -166,18 +159,18 @@ class FlatParamModule(nn.Module):
         ev = torch.cuda.Event()
         ev.record(stream)
         if ops.RECORDER is not None:
-            ops.RECORDER.add(ev.record, stream)
+            ops.RECORDER.entries.append(["ev_record", ev, stream])
         return ev
 
     def _ev_wait(self, stream, ev):
         stream.wait_event(ev)
         if ops.RECORDER is not None:
-            ops.RECORDER.add(stream.wait_event, ev)
+            ops.RECORDER.entries.append(["wait_event", stream, ev])
 
     def _wait_stream(self, waiter, waited):
         waiter.wait_stream(waited)
         if ops.RECORDER is not None:
-            ops.RECORDER.add(waiter.wait_stream, waited)
+            ops.RECORDER.entries.append(["wait_stream", waiter, waited])
 
     def _callback(self, fn, *args):
         """A host callback in launch order (the data-parallel hook): runs now and on every replay, under the torch stream
@@ -189,31 +182,4 @@ class FlatParamModule(nn.Module):
             def again(st=st, fn=fn, args=args):
                 with torch.cuda.stream(st):
                     fn(*args)
-            ops.RECORDER.add(again)
-
-    def _fused(self, first_key, rows_total, cols=None):
-        """Contiguous view spanning consecutive parameter tensors (e.g. to_q|to_k|to_v -> [3D, D])."""
-        o = self._offset[first_key]
-        if cols is None:
-            return self.flat_param[o:o + rows_total], self.flat_grad[o:o + rows_total]
-        n = rows_total * cols
-        return self.flat_param[o:o + n].view(rows_total, cols), self.flat_grad[o:o + n].view(rows_total, cols)
-
-    # ------------------------------------------------------------------ streams
-    def join_pending_update(self):
-        """Make the current stream wait for an optimizer update still running on the optimizer's stream."""
-        pev, self.param_events = self.param_events, None
-        if pev is not None:
-            cur = torch.cuda.current_stream()
-            for ev in pev:
-                cur.wait_event(ev)
-
-    def _chain_stream(self, c):
-        if c not in self._chains:
-            self._chains[c] = torch.cuda.Stream(device=self.flat_param.device)
-        return self._chains[c]
-
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat_param.device)
-        return self._side
+            ops.RECORDER.entries.append(["py", again])

@@ -27,6 +27,15 @@ class GemmEpilogue(C.Structure):
         super().__init__(C.sizeof(GemmEpilogue), *args, **kw)
 
 
+class PlanArg(C.Union):
+    _fields_ = [("i", C.c_int64), ("d", C.c_double), ("p", C.c_void_p)]
+
+
+class PlanEntry(C.Structure):
+    """yat_plan_entry (include/yat_hip.h)."""
+    _fields_ = [("op", C.c_int32), ("nargs", C.c_int32), ("a", PlanArg * 30)]
+
+
 class GemmProblem(C.Structure):
     _fields_ = [("M", I), ("N", I), ("K", I), ("A", P), ("lda", I), ("B", P), ("ldb", I), ("C", P), ("ldc", I),
                 ("epilogue", C.POINTER(GemmEpilogue))]
@@ -88,6 +97,8 @@ SIGNATURES = {
     "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
     "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
     "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),
+    "yat_plan_op_id": (I, [C.c_char_p]),
+    "yat_plan_replay": (I, [C.POINTER(PlanEntry), I, C.POINTER(I)]),
     "yat_comm_unique_id": (I, [P]),
     "yat_comm_init": (I, [I, I, P]),
     "yat_comm_world": (I, []),

@@ -37,8 +37,8 @@ GEMM_TIMER = None
 
 class Recorder:
     """Launch-plan recording (yat_amd/flat.py ``planned``).  While one is installed every C-ABI call made through ``_lib()``
-    is executed AND appended as ``[fn, args]``; stream / event operations are appended by the model code through
-    FlatParamModule's helpers.  A step over the same buffers is then replayed as a flat list of calls -- no tensor slicing, no
+    is executed AND appended as ``[fn, args]``; stream / event operations and host callbacks are appended by the model code
+    through FlatParamModule's helpers as tagged entries (yat_amd/plan.py compiles the list for the C-side replay).  A step over the same buffers is then replayed as a flat list of calls -- no tensor slicing, no
     stride arithmetic, no struct building, no stream look-ups on the host.  ``dynamic[name]`` lists (entry, argument) slots
     whose integer value changes from step to step (the length of the attention work list)."""
 
@@ -59,10 +59,6 @@ class Recorder:
             entries.append([fn, args])
             return fn(*args)
         return call
-
-    def add(self, fn, *args):
-        """A host-side stream / event operation (or any callable) in launch order."""
-        self.entries.append([fn, args])
 
     def mark_dynamic(self, name, arg_index):
         """The call just recorded takes a per-step integer at ``arg_index``."""
