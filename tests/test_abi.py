@@ -42,7 +42,7 @@ def test_header_declares_what_we_bind():
         assert len(args) == len(types), (name, len(args), len(types))
         for i, (a, t) in enumerate(zip(args, types)):
             if t == "ptr":
-                assert a is C.c_void_p or issubclass(a, C._Pointer), (name, i, a)
+                assert a in (C.c_void_p, C.c_char_p) or issubclass(a, C._Pointer), (name, i, a)
             else:
                 assert a is _CT[t], (name, i, a, t)
 

@@ -183,3 +183,30 @@ class FlatParamModule(nn.Module):
                 with torch.cuda.stream(st):
                     fn(*args)
             ops.RECORDER.entries.append(["py", again])
+
+    def _fused(self, first_key, rows_total, cols=None):
+        """Contiguous view spanning consecutive parameter tensors (e.g. to_q|to_k|to_v -> [3D, D])."""
+        o = self._offset[first_key]
+        if cols is None:
+            return self.flat_param[o:o + rows_total], self.flat_grad[o:o + rows_total]
+        n = rows_total * cols
+        return self.flat_param[o:o + n].view(rows_total, cols), self.flat_grad[o:o + n].view(rows_total, cols)
+
+    # ------------------------------------------------------------------ streams
+    def join_pending_update(self):
+        """Make the current stream wait for an optimizer update still running on the optimizer's stream."""
+        pev, self.param_events = self.param_events, None
+        if pev is not None:
+            cur = torch.cuda.current_stream()
+            for ev in pev:
+                cur.wait_event(ev)
+
+    def _chain_stream(self, c):
+        if c not in self._chains:
+            self._chains[c] = torch.cuda.Stream(device=self.flat_param.device)
+        return self._chains[c]
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat_param.device)
+        return self._side
