@@ -297,6 +297,17 @@ int yat_ddpm_add_noise(int B, int64_t per_sample, const void* x, const void* noi
 int yat_mse_bf16_chunk(int B, int64_t used, int64_t stride, const void* pred, const void* target, float gscale, float* loss,
                        void* dpred, float* workspace_256, yat_stream_t stream);
 
+/* peft LoHa adapters (lora_algo: loha, LoHaConfig at common/trainer.py:220-224) [RECALL peft/tuners/loha/layer.py HadaWeight]:
+ *   yat_hadamard_scale: out = bf16(bf16(a * b) * scale) -- delta_w = ((w1a w1b) * (w2a w2b)) * scale from the two rank-r
+ *       products (ordinary yat_gemm_bf16 calls);
+ *   yat_hadamard_bwd:   g = bf16(dd * scale); t1 = bf16(g * a2); t2 = bf16(g * a1) -- the element-wise half of HadaWeight's
+ *       hand-written backward (d_w1a = t1 w1b^T, d_w1b = w1a^T t1, d_w2a = t2 w2b^T, d_w2b = w2a^T t2 are GEMMs again).
+ *   rows x cols views (cols % 8 == 0) with row strides in elements. */
+int yat_hadamard_scale(int rows, int cols, const void* a, int lda, const void* b, int ldb, float scale, void* out, int ldo,
+                       yat_stream_t stream);
+int yat_hadamard_bwd(int rows, int cols, const void* dd, int ldd, const void* a1, int ld1, const void* a2, int ld2, float scale,
+                     void* t1, int ldt1, void* t2, int ldt2, yat_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * MMDiT glue (SD3.5-Medium, BASELINE config 4: the reference trains diffusers' SD3Transformer2DModel,
  * train_sd35.py:4,188-191; JointTransformerBlock / JointAttnProcessor2_0 [RECALL], restated in oracle/sd3_ref.py).

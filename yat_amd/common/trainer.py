@@ -247,7 +247,7 @@ class Model:
                 from safetensors.torch import load_file
                 with open(os.path.join(p.lora_pretrained, "adapter_config.json")) as f:
                     conf = json.load(f)
-                algo = {"LORA": "lora", "LOKR": "lokr"}.get(conf.get("peft_type"))
+                algo = {"LORA": "lora", "LOKR": "lokr", "LOHA": "loha"}.get(conf.get("peft_type"))
                 if algo is None:
                     raise NotImplementedError(f"lora_pretrained: peft_type {conf.get('peft_type')!r} is not built")
                 targets, rank = conf["target_modules"], int(conf["r"])
@@ -255,14 +255,17 @@ class Model:
                 drop = conf.get("lora_dropout" if algo == "lora" else "module_dropout", 0.0) or 0.0
                 rslora = bool(conf.get("use_rslora", False))
                 saved = load_file(os.path.join(p.lora_pretrained, "adapter_model.safetensors"))
-            if algo not in ("lokr", "lora"):
-                raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 -- and lora are)")
+            if algo not in ("lokr", "lora", "loha"):
+                raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 --, lora and loha are)")
             if algo == "lora":                                        # :214-219
                 if getattr(p, "lora_use_dora", False):
                     raise NotImplementedError("DoRA is not built")
                 from ..lora import LoRAAdapters
                 self.adapters = LoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora,
                                              seed=int(getattr(p, "dataset_seed", 0) or 0))
+            elif algo == "loha":                                      # :220-224
+                from ..loha import LoHaAdapters
+                self.adapters = LoHaAdapters(self.model, targets, rank, alpha, module_dropout=drop)
             else:                                                     # :226-230
                 from ..lokr import LoKrAdapters
                 self.adapters = LoKrAdapters(self.model, targets, rank, alpha, module_dropout=drop)

@@ -298,6 +298,36 @@ int fill(LokrP& p, int out_l, int out_k, int in_m, int in_n, int r, const void* 
     return YAT_OK;
 }
 
+
+// MODE 0: o1 = bf16(bf16(x * y) * scale).   MODE 1: g = bf16(x * scale); o1 = bf16(g * z); o2 = bf16(g * y)
+//         (x = d_delta, y = A1, z = A2 -> o1 = t1, o2 = t2).
+template <int MODE>
+__global__ __launch_bounds__(256) void hadamard_kernel(int rows, int cols, const bf16_t* x, int ldx, const bf16_t* y, int ldy,
+                                                       const bf16_t* z, int ldz, float scale, bf16_t* o1, int ld1, bf16_t* o2,
+                                                       int ld2) {
+    const int cpr = cols >> 3;
+    const int64_t total = (int64_t)rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) * 8;
+        float xv[8], yv[8], zv[8], a[8], b[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c), xv);
+        unpack8(*reinterpret_cast<const u32x4*>(y + r * ldy + c), yv);
+        if (MODE == 1) unpack8(*reinterpret_cast<const u32x4*>(z + r * ldz + c), zv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (MODE == 0) a[e] = rbf(rbf(xv[e] * yv[e]) * scale);
+            else {
+                const float g = rbf(xv[e] * scale);
+                a[e] = rbf(g * zv[e]);
+                b[e] = rbf(g * yv[e]);
+            }
+        }
+        *reinterpret_cast<u32x4*>(o1 + r * ld1 + c) = pack8(a);
+        if (MODE == 1) *reinterpret_cast<u32x4*>(o2 + r * ld2 + c) = pack8(b);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -403,6 +433,37 @@ int yat_lokr_small_wgrad(int64_t rows, int R, int N, int r_out, const void* a, c
     const int n_out = r_out * N;
     hipLaunchKernelGGL(lokr_small_wgrad_final_kernel, dim3((n_out + 15) / 16), dim3(256), 0, (hipStream_t)stream, G, R, N, npad,
                        r_out, scale, (const float*)workspace, (bf16_t*)out, ldo, accumulate);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+
+// peft LoHa (HadaWeight [RECALL peft/tuners/loha/layer.py]): delta_w = ((w1a w1b) * (w2a w2b)) * scale, bf16 op by op, and
+// the element-wise half of its hand-written backward: g = dd * scale; t1 = g * A2; t2 = g * A1.  rows x cols views with row strides.
+int yat_hadamard_scale(int rows, int cols, const void* a, int lda, const void* b, int ldb, float scale, void* out, int ldo,
+                       yat_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || (cols & 7) || (lda & 7) || (ldb & 7) || (ldo & 7) || lda < cols || ldb < cols || ldo < cols ||
+        !a || !b || !out)
+        return YAT_EINVAL;
+    const int64_t chunks = (int64_t)rows * (cols >> 3);
+    int64_t nb = (chunks + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(hadamard_kernel<0>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rows, cols, (const bf16_t*)a,
+                       lda, (const bf16_t*)b, ldb, (const bf16_t*)nullptr, 0, scale, (bf16_t*)out, ldo, (bf16_t*)nullptr, 0);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_hadamard_bwd(int rows, int cols, const void* dd, int ldd, const void* a1, int ld1, const void* a2, int ld2, float scale,
+                     void* t1, int ldt1, void* t2, int ldt2, yat_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || (cols & 7) || ((ldd | ld1 | ld2 | ldt1 | ldt2) & 7) || ldd < cols || ld1 < cols ||
+        ld2 < cols || ldt1 < cols || ldt2 < cols || !dd || !a1 || !a2 || !t1 || !t2)
+        return YAT_EINVAL;
+    const int64_t chunks = (int64_t)rows * (cols >> 3);
+    int64_t nb = (chunks + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(hadamard_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rows, cols, (const bf16_t*)dd,
+                       ldd, (const bf16_t*)a1, ld1, (const bf16_t*)a2, ld2, scale, (bf16_t*)t1, ldt1, (bf16_t*)t2, ldt2);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

@@ -211,6 +211,25 @@ def lokr_project(w1, w2a, w2b, scale, d_delta2d, dw1, dw2a, dw2b, workspace):
     _l.check(rc, "yat_lokr_project")
 
 
+def hadamard_scale(a2d, b2d, scale, out2d):
+    """out = bf16(bf16(a * b) * scale) on [rows, cols] views (yat_hadamard_scale: LoHa's delta_w)."""
+    _chk_bf16(a2d, b2d, out2d)
+    rows, cols = a2d.shape
+    rc = _lib().yat_hadamard_scale(rows, cols, _p(a2d), a2d.stride(0), _p(b2d), b2d.stride(0), float(scale), _p(out2d),
+                                   out2d.stride(0), _stream())
+    _l.check(rc, "yat_hadamard_scale")
+    return out2d
+
+
+def hadamard_bwd(dd2d, a1, a2, scale, t1, t2):
+    """g = bf16(dd * scale); t1 = bf16(g * a2); t2 = bf16(g * a1) (yat_hadamard_bwd)."""
+    _chk_bf16(dd2d, a1, a2, t1, t2)
+    rows, cols = dd2d.shape
+    rc = _lib().yat_hadamard_bwd(rows, cols, _p(dd2d), dd2d.stride(0), _p(a1), a1.stride(0), _p(a2), a2.stride(0), float(scale),
+                                 _p(t1), t1.stride(0), _p(t2), t2.stride(0), _stream())
+    _l.check(rc, "yat_hadamard_bwd")
+
+
 def lokr_rows_fwd(x2d, wb, t1):
     """t1[rows, R] = x2d[rows, N] wb^T (wb [R, N]) -- the T1 product of the factored LoKr path."""
     _chk_bf16(x2d, wb, t1)
