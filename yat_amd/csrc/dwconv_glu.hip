@@ -17,10 +17,14 @@
 //    one guarded global load per (row, column, half), register double buffer.  ~25 % slower; kept as the general path.
 #include "common.hpp"
 #include "../../include/yat_hip.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int SEG = 8;      // output columns per thread
+#ifndef YAT_DW_SEG
+#define YAT_DW_SEG 8
+#endif
+constexpr int SEG = YAT_DW_SEG;      // output columns per thread
 constexpr int PK = 11;      // partial values per channel: 9 taps, conv bias, column sum of dz
 constexpr int ROWS = 4;     // rows per thread in backward pass 2
 
@@ -172,229 +176,41 @@ __device__ __forceinline__ void load_taps(const bf16_t* wdw, int c, f32x2 (&wv)[
         for (int pr = 0; pr < 2; ++pr) asm volatile("" : "+v"(wv[t][pr]));
 }
 
-#ifndef YAT_DW_TCH
-#define YAT_DW_TCH 32
-#endif
-constexpr int TCH = YAT_DW_TCH;         // channels per half per tile
-constexpr int NCG = TCH / 4;            // 4-channel groups (threads) across a tile pixel
-constexpr int PPP = TCH / 8;            // 16-byte pieces per tile pixel
-constexpr int GPX = 64 / PPP;           // pixels one DMA wave instruction moves
-constexpr int TILE_PAD = 9;
-
-struct TileGeo { int WP, PHp; };
-__host__ __device__ inline TileGeo tile_geo(int w, int R) {
-    TileGeo g;
-    g.WP = w + 1;
-    g.PHp = ((R + 2) * g.WP + 1 + TILE_PAD + 15) & ~15;      // pixel slots per half, multiple of 16 (one DMA instruction)
-    return g;
+// The forward tile kernel in four (channels per tile, workgroups per CU) variants; results are bit-identical across them
+// (every output's taps are applied in the same order), so the choice per shape is pure scheduling.
+#define DW_TCH 32
+#define DW_WPS 3
+namespace v32w3 {
+#include "dwconv_tile_fwd.inc"
 }
-
-// Stage `nrows` image rows (first one ii0; rows outside [0,h) become zeros) of 32 channels starting at element `chan`
-// of a [B,h,w,C2] array into tile slots slot0 + r*WP + 1 + j.  One wave instruction moves 16 consecutive pixels x 64 B:
-// the lane pattern (pixel lane>>2, 16-byte piece lane&3) never changes, only the scalar offset does, so staging costs a
-// few SALU instructions per KiB instead of per-lane index arithmetic.  Slot 0 of every row (the shared zero halo) and the
-// pad are never written here; the whole tile is cleared once per workgroup.
-__device__ __forceinline__ void stage_rows(const __amdgpu_buffer_rsrc_t rs, unsigned char* tile, int slot0, int nrows,
-                                           int ii0, int b, int h, int w, int WP, int C2, int chan, bool lane_ch_ok,
-                                           int wave_s, int nwaves, int lane) {
-    const int ngroups = (w + GPX - 1) / GPX;
-    const uint32_t vlane = (uint32_t)(lane / PPP) * (uint32_t)C2 * 2u + (uint32_t)(lane % PPP) * 16u;
-    int k = 0;
-    for (int r = 0; r < nrows; ++r) {
-        const int ii = ii0 + r;
-        const bool row_ok = ii >= 0 && ii < h;
-        for (int g = 0; g < ngroups; ++g, ++k) {
-            if ((k & (nwaves - 1)) != wave_s) continue;                   // wave-uniform: rows x groups dealt round-robin
-            const int jj0 = g * GPX;
-            const uint32_t soff = row_ok ? (uint32_t)(((((int64_t)b * h + ii) * w + jj0) * C2 + chan) * 2) : 0u;
-            if ((lane / PPP) < w - jj0)                                   // partial last group: EXEC-masked lanes write nothing
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (YAT_LDS void*)(tile + (slot0 + r * WP + 1 + jj0) * (TCH * 2)),
-                                                         16, row_ok && lane_ch_ok ? vlane : YAT_OOB, soff, 0, 0);
-        }
-    }
+#undef DW_TCH
+#undef DW_WPS
+#define DW_TCH 64
+#define DW_WPS 3
+namespace v64w3 {
+#include "dwconv_tile_fwd.inc"
 }
-__device__ __forceinline__ void clear_tile(unsigned char* tile, int bytes) {
-    for (int o = threadIdx.x * 16; o < bytes; o += blockDim.x * 16) *reinterpret_cast<u32x4*>(tile + o) = u32x4{0u, 0u, 0u, 0u};
+#undef DW_WPS
+#define DW_WPS 2
+namespace v64w2 {
+#include "dwconv_tile_fwd.inc"
 }
+#undef DW_TCH
+#undef DW_WPS
+using namespace v32w3;      // pass 2 below shares this variant's staging helpers and tile constants
 
+// Forward: 128-byte pixel slices always; two workgroups per CU (taller bands) for wide rows.  Measured (B = 8, Hc = 5600,
+// forward with the u store, us): 32x32 154 -> 119, 16x64 165 -> 140, 24x42 176 -> 136, 44x22 186 -> 123.
+// Pass 1 (only when u is not kept) stays on the 32-channel variant it was tuned on.
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void dwglu_tile_kernel(int h, int w, int Hc, int B, int R, int rmagic, int nbands,
-                                                            int bpb, int nchunk, const bf16_t* s, uint64_t s_bytes,
-                                                            const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
-                                                            bf16_t* out, bf16_t* u_out) {
-    // s_bytes = bytes of the [B,h,w,2Hc] arrays (s, du, u_out); dy / y are half that.  All global traffic of the run loop goes
-    // through range-checked buffer instructions: a guarded plain store makes the optimizer sink each output's FMAs into
-    // its branch, which keeps three unpacked input columns live (299 VGPRs).
-    // A workgroup owns `bpb` consecutive bands of one (image, 32-channel chunk): taps are loaded and the tile cleared once.
-    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
-    const int ngrp = (nbands + bpb - 1) / bpb;
-    const int total = ngrp * nchunk * B;
-    int u = xcd_unit(total);
-    if (u >= total) return;
-    const int bg = u % ngrp; u /= ngrp;
-    const int cx = u % nchunk, b = u / nchunk;
-    const int ch0 = cx * TCH;
-    const TileGeo geo = tile_geo(w, R);
-    const int WP = geo.WP, PHp = geo.PHp, C2 = 2 * Hc;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, nslots = blockDim.x / NCG;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    clear_tile(tile, 2 * PHp * TCH * 2);
-    // ---- per-thread constants
-    const int cg = lane & (NCG - 1);
-    const int ca = ch0 + cg * 4, cgl = Hc + ca;
-    const bool chan_ok = ca < Hc;
-    // channel pairs as explicit 2-vectors (see pass 2 below): one v_pk_fma_f32 per (tap, pair) with a fixed pairing
-    f32x2 wa[9][2], wg[9][2], ba[2], bg2[2];
-    {
-        const int cs = chan_ok ? ca : 0;
-        load_taps(wdw, cs, wa);
-        load_taps(wdw, Hc + cs, wg);
-        unpack22(*reinterpret_cast<const u32x2*>(bdw + cs), ba);
-        unpack22(*reinterpret_cast<const u32x2*>(bdw + Hc + cs), bg2);
-    }
-    const int nseg = (w + SEG - 1) / SEG, nruns = R * nseg;
-    const int slot = threadIdx.x / NCG;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(s, s_bytes);
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, MODE == 0 ? s_bytes / 2 : s_bytes);
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(MODE == 1 ? dy : s, s_bytes / 2);
-    const __amdgpu_buffer_rsrc_t ru = make_rsrc(u_out ? u_out : out, u_out ? s_bytes : 0);      // forward only, optional
-    const bool lane_ch_ok = ch0 + (lane % PPP) * 8 < Hc;
-
-  for (int rb = bg * bpb; rb < min(nbands, (bg + 1) * bpb); ++rb) {
-    const int i0 = rb * R;
-    __syncthreads();                                        // tile cleared / previous band fully consumed
-    stage_rows(rs, tile, 0, R + 2, i0 - 1, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
-    stage_rows(rs, tile, PHp, R + 2, i0 - 1, b, h, w, WP, C2, Hc + ch0, lane_ch_ok, wave_s, nwaves, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int run = slot; run < nruns; run += nslots) {
-        const int seg = (run * rmagic) >> 16, row = run - seg * R;      // rows fastest: neighbouring runs, other bank group
-        const int i = i0 + row;
-        if (i >= h || !chan_ok) continue;
-        const int j0 = seg * SEG;
-        const unsigned char* pa = tile + ((row * WP + j0) * TCH + cg * 4) * 2;       // row `row` of the tile = image row i-1
-        const unsigned char* pg = pa + PHp * TCH * 2;
-        const int64_t pix0 = ((int64_t)b * h + i) * w + j0;
-        u32x2 dyv[3];                                       // dy of output o is fetched at step o, used at step o + 2
-        f32x2 A[3][2], G[3][2];
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) { A[m][pr] = ba[pr]; G[m][pr] = bg2[pr]; }
-        u32x2 nxt[6];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            nxt[2 * r] = *reinterpret_cast<const u32x2*>(pa + (r * WP) * TCH * 2);
-            nxt[2 * r + 1] = *reinterpret_cast<const u32x2*>(pg + (r * WP) * TCH * 2);
-        }
-#pragma unroll
-        for (int t = 0; t < SEG + 2; ++t) {                 // input column j0 - 1 + t  (tile column j0 + t)
-            u32x2 cur[6];
-#pragma unroll
-            for (int m = 0; m < 6; ++m) cur[m] = nxt[m];
-            if (MODE == 1 && t < SEG)
-                dyv[t % 3] = __builtin_amdgcn_raw_buffer_load_b64(
-                    rdy, j0 + t < w ? (uint32_t)(((pix0 + t) * Hc + ca) * 2) : YAT_OOB, 0, 0);
-            if (t + 1 < SEG + 2) {                          // next column's LDS reads fly under this column's FMAs
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    nxt[2 * r] = *reinterpret_cast<const u32x2*>(pa + (r * WP + t + 1) * TCH * 2);
-                    nxt[2 * r + 1] = *reinterpret_cast<const u32x2*>(pg + (r * WP + t + 1) * TCH * 2);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                f32x2 za[2], zg[2];
-                unpack22(cur[2 * r], za);
-                unpack22(cur[2 * r + 1], zg);
-#pragma unroll
-                for (int dj = 2; dj >= 0; --dj) {           // output o = t - dj takes tap column dj (same order as above)
-                    const int o = t - dj;
-                    if (o < 0 || o >= SEG) continue;
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        A[o % 3][pr] += wa[r * 3 + dj][pr] * za[pr];
-                        G[o % 3][pr] += wg[r * 3 + dj][pr] * zg[pr];
-                    }
-                }
-            }
-            const int o = t - 2;                            // output column j0 + o has now seen all three input columns
-            if (o >= 0) {
-                float ua[4], ug[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ua[e] = rbf(A[o % 3][e >> 1][e & 1]); ug[e] = rbf(G[o % 3][e >> 1][e & 1]); }
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) { A[o % 3][pr] = ba[pr]; G[o % 3][pr] = bg2[pr]; }
-                const bool live = j0 + o < w;
-                if (MODE == 0) {
-                    {   // keep u for the backward (the GLU backward then runs in the dy GEMM's epilogue).  Branch-free:
-                        // without u_out the descriptor has zero records and the range check drops the stores.
-                        const uint32_t uo = live ? (uint32_t)(((pix0 + o) * C2 + ca) * 2) : YAT_OOB;
-                        __builtin_amdgcn_raw_buffer_store_b64(pack4(ua[0], ua[1], ua[2], ua[3]), ru, uo, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(pack4(ug[0], ug[1], ug[2], ug[3]), ru,
-                                                              live ? uo + (uint32_t)Hc * 2 : YAT_OOB, 0, 0);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b64(
-                        pack4(ua[0] * rbf(silu_f(ug[0])), ua[1] * rbf(silu_f(ug[1])), ua[2] * rbf(silu_f(ug[2])),
-                              ua[3] * rbf(silu_f(ug[3]))),
-                        rout, live ? (uint32_t)(((pix0 + o) * Hc + ca) * 2) : YAT_OOB, 0, 0);
-                } else {
-                    float d[4], da[4], dg[4];
-                    unpack4(dyv[o % 3], d);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        da[e] = d[e] * rbf(silu_f(ug[e]));
-                        dg[e] = rbf(d[e] * ua[e]) * dsilu_f(ug[e]);
-                    }
-                    const uint32_t off = live ? (uint32_t)(((pix0 + o) * C2 + ca) * 2) : YAT_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b64(pack4(da[0], da[1], da[2], da[3]), rout, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(pack4(dg[0], dg[1], dg[2], dg[3]), rout,
-                                                          live ? off + (uint32_t)Hc * 2 : YAT_OOB, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);              // keep the unrolled columns from hoisting all their reads
-        }
-    }
-  }
-}
-
-// rows per band: the largest R whose tile leaves room for three workgroups per CU, weighted by how well R * nseg runs
-// fill the 32 run slots and by the (R+2)/R halo re-read
-inline int pick_band_rows(int h, int w, size_t* lds_bytes, int* threads) {
-    const int nseg = (w + SEG - 1) / SEG;
-    int best = 0;
-    double best_score = 0;
-    *threads = 256;
-    const int ns = *threads / NCG;
-    for (int R = 2; R <= 16 && R <= ((h + 1) & ~1); ++R) {
-        const size_t bytes = (size_t)2 * tile_geo(w, R).PHp * TCH * 2;
-        if (bytes > 53248) break;
-        const int nruns = R * nseg, passes = (nruns + ns - 1) / ns;
-        const int nb = (h + R - 1) / R;
-        const double score = (double)nruns / (passes * ns) * R / (R + 2) * h / (nb * R);
-        if (score > best_score) { best_score = score; best = R; }
-    }
-    if (best) *lds_bytes = (size_t)2 * tile_geo(w, best).PHp * TCH * 2;
-    return best;
-}
-
-template <int MODE>
-int launch_tile(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
-                bf16_t* out, bf16_t* u_out, hipStream_t stream) {
-    size_t lds = 0;
-    int threads = 256;
-    const int R = pick_band_rows(h, w, &lds, &threads);
-    const uint64_t s_bytes = (uint64_t)B * h * w * 2 * Hc * 2;
-    if (!R || (Hc & 7) || s_bytes > 0x7fffffffull) return -1;          // caller falls back to the direct kernels
-    const int nbands = (h + R - 1) / R, nchunk = (Hc + TCH - 1) / TCH;
-    // bands per workgroup: as many as still leave >= 3 rounds of workgroups (3 resident per CU)
-    int bpb = nbands;
-    while (bpb > 1 && (int64_t)((nbands + bpb - 1) / bpb) * nchunk * B < 3 * 768) --bpb;
-    const int ngrp = (nbands + bpb - 1) / bpb;
-    hipLaunchKernelGGL((dwglu_tile_kernel<MODE>), dim3(grid8((int64_t)ngrp * nchunk * B)), dim3(threads), lds, stream, h, w,
-                       Hc, B, R, (65536 + R - 1) / R, nbands, bpb, nchunk, s, s_bytes, wdw, bdw, dy, out, u_out);
-    return 0;
+int launch_tile_best(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
+                     bf16_t* out, bf16_t* u_out, hipStream_t stream) {
+    static const int force = getenv("YAT_DW_VARIANT") ? atoi(getenv("YAT_DW_VARIANT")) : 0;     // 1: v32w3, 2: v64w3, 3: v64w2
+    int v = MODE == 0 ? (w > 48 ? 3 : 2) : 1;
+    if (force) v = force;
+    if (v == 3 && v64w2::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream) == 0) return 0;
+    if (v >= 2 && v64w3::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream) == 0) return 0;
+    return v32w3::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream);
 }
 
 // LDS-tiled backward pass 2 (same staging scheme; all 2*Hc channels are independent here, 32 per workgroup):
@@ -696,7 +512,7 @@ int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* w
     const void* z = s;
     if (B <= 0 || h <= 0 || w <= 0 || Hc <= 0 || (Hc & 3) || !z || !wdw || !bdw || !y) return YAT_EINVAL;
     if ((int64_t)h * nseg_of(w) * B * ((Hc / 4 + 63) / 64) * 2 > 0x7fffff00ll) return YAT_EINVAL;
-    if (w <= 64 && launch_tile<0>(B, h, w, Hc, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)bdw, nullptr,
+    if (w <= 64 && launch_tile_best<0>(B, h, w, Hc, (const bf16_t*)z, (const bf16_t*)wdw, (const bf16_t*)bdw, nullptr,
                                   (bf16_t*)y, (bf16_t*)u_out, (hipStream_t)stream) == 0) {
         YAT_CHECK_LAUNCH();
         return YAT_OK;
@@ -730,7 +546,7 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     const int nx = (Hc / 4 + 255) / 256, nx2 = (C2 / 4 + 63) / 64;
     if (!du_in) {                                             // pass 1: recompute u, GLU backward -> du (workspace)
         bf16_t* duw = (bf16_t*)workspace;
-        if (!(w <= 64 && launch_tile<1>(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
+        if (!(w <= 64 && launch_tile_best<1>(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)wdw, (const bf16_t*)bdw,
                                         (const bf16_t*)dy, duw, nullptr, (hipStream_t)stream) == 0))
             hipLaunchKernelGGL((dwconv_glu_kernel<1>), dim3(grid8((int64_t)nx * h * nseg_of(w) * B)), dim3(256), 0,
                                (hipStream_t)stream, h, w, Hc, nseg_of(w), nx, B, (const bf16_t*)s, (const bf16_t*)wdw,
