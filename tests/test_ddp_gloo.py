@@ -49,6 +49,29 @@ def _ddp_worker(rank, world, port, tmp):
     t = ddp.all_reduce_scalar_mean(torch.tensor([float(rank)]))
     assert t.item() == 0.5
 
+    # the REAL model's flat layout and bucket order (built on the CPU: no kernel runs here): buckets complete last block
+    # first, embedders last, exactly as backward_impl reports them; every bucket is reduced once, the tail of the last
+    # bucket (output head) included, and a second "step" reuses the same machinery
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    real = SanaTransformer2DModelHIP(SanaConfig(num_layers=3, num_attention_heads=2, num_cross_attention_heads=2,
+                                                cross_attention_head_dim=32, cross_attention_dim=64, caption_channels=96,
+                                                in_channels=8, out_channels=8, sample_size=4), device="cpu")
+    assert real.bucket_bounds[0][0] == 0 and real.bucket_bounds[-1][1] == real.numel_flat and len(real.bucket_bounds) == 4
+    assert all(a[1] == b[0] for a, b in zip(real.bucket_bounds, real.bucket_bounds[1:]))
+    real.flat_param = real.flat_param.float()
+    real.flat_grad = real.flat_grad.float()                   # gloo has no bf16 all-reduce; the layout is what is under test
+    real.flat_param += rank
+    ddp_real = HipDDP(real)
+    ddp_real.broadcast_parameters()
+    assert torch.all(real.flat_param == 0)
+    for step in range(2):
+        real.flat_grad[:] = torch.arange(real.numel_flat, dtype=torch.float32) * (rank + 1 + step)
+        for i in (3, 2, 1, 0):
+            real.grad_ready(i)
+        ddp_real.wait()
+        assert torch.allclose(real.flat_grad, torch.arange(real.numel_flat, dtype=torch.float32) * (1.5 + step))
+    assert ddp_real.bytes_reduced == 2 * real.numel_flat * 4
+
     # PEFT adapters under data parallel: the adapter set is the "model" HipDDP sees; its single bucket is reduced when
     # project() (the last thing the backward does) reports the gradients complete
     from yat_amd.lora import LoRAAdapters

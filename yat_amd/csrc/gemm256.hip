@@ -117,7 +117,10 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 
     const int ksl = id % p.ksplit;             // K slice of this workgroup (slices of one tile are neighbours -> same XCD)
     id /= p.ksplit;
-    const int GROUP = 4;
+#ifndef YAT_GEMM_GROUP
+#define YAT_GEMM_GROUP 4
+#endif
+    const int GROUP = YAT_GEMM_GROUP;
     const int per_group = GROUP * p.nbn;
     const int gid = id / per_group, first_m = gid * GROUP;
     const int gsz = min(p.nbm - first_m, GROUP);
