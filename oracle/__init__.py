@@ -21,4 +21,8 @@ against reference outputs.  What IS pinned:
   trainer.py:325) and the AdamW / clip arithmetic: both are *stock torch*, the
   same dependency the reference calls, executed here on CPU;
 * the flow-match sigma table known answers quoted in SURVEY.md §8(c).
+
+``python -m oracle.pin_against_diffusers`` closes the gap on any machine that has the reference's dependencies: it
+loads random diffusers models (SANA, PixArt-Sigma, SD3.5, the flow-match scheduler, EMAModel) into these restatements
+with ``strict=True`` and compares outputs and gradients; here (no diffusers, no network) it reports "unpinned" and exits 2.
 """
