@@ -100,6 +100,19 @@ __device__ __forceinline__ bf16x8 frag256(const char* lds, int idx0, int kk, int
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
+// Diagnostic builds only (scripts/build_variant.py ... -DYAT_ABL_*; results are then WRONG, only the time is read): where
+// does the main loop's time go -- waiting for the LDS-DMA to land, issuing it, or the four rendezvous per K-tile?
+#ifdef YAT_ABL_NO_BARRIER
+#define YAT_LOOP_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define YAT_LOOP_BARRIER() YAT_PHASE_BARRIER()
+#endif
+#ifdef YAT_ABL_NO_LDSREAD
+#define YAT_ABL_SKIP_READS 1
+#else
+#define YAT_ABL_SKIP_READS 0
+#endif
+
 // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of `nwg` work items
 __device__ __forceinline__ int xcd_contiguous(int nwg) {
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
@@ -237,24 +250,35 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     //           and waits before its 3rd barrier of iteration t (<= 4t+4).
     for (int t = 0; t < nt; ++t) {
         const char* cur = smem + (t & 1) * G::STAGE;
+#ifndef YAT_ABL_NO_DMA
         if (!DIC && t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * G::STAGE);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
+            if (!YAT_ABL_SKIP_READS || t == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = frag256<A_T, BM>(cur, grp * 128 + i * 16, kk, lane);
+                for (int i = 0; i < 8; ++i) af[i] = frag256<A_T, BM>(cur, grp * 128 + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bfr[j] = frag256<B_T, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
+                for (int j = 0; j < NT; ++j) bfr[j] = frag256<B_T, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef YAT_ABL_NO_VMWAIT
             if (kk == 1 && (!DIC || grp == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
-            YAT_PHASE_BARRIER();
+#endif
+            YAT_LOOP_BARRIER();
             // ---- COMPUTE segment
             int dma_tile = -1;
             if (DIC && kk == 0 && grp == 0 && t + 1 < nt) dma_tile = t + 1;
             if (DIC && kk == 1 && grp == 1 && t + 2 < nt) dma_tile = t + 2;
+#ifdef YAT_ABL_NO_DMA
+            dma_tile = -1;
+#endif
             compute(dma_tile);
+#ifndef YAT_ABL_NO_VMWAIT
             if (DIC && kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 (group 0's pieces)
-            YAT_PHASE_BARRIER();
+#endif
+            YAT_LOOP_BARRIER();
         }
     }
     if (grp == 0) YAT_PHASE_BARRIER();         // pair group 1's last barrier
