@@ -242,8 +242,13 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (Rehearsal of the N > 1 flow on a one-GPU box: YAT_DIST_BACKEND=gloo lets several ranks share
+    # cuda:0 -- RCCL refuses two ranks on one device -- so everything but the transport is exercised.)
+    backend = os.environ.get("YAT_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     # YAT_DDP_FORCE=1: run the whole data-parallel machinery (RCCL group, bucket hooks on the side stream, comm stream,
     # optimizer wait) even with ONE rank -- the only way to exercise that code path on a single-GPU box.
@@ -252,7 +257,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.data == "shards":
         run_from_shards(args, rank, world, local_rank)

@@ -41,13 +41,18 @@ class HipAccelerator:
         self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if device is None:
-            device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+            if torch.cuda.is_available():
+                if os.environ.get("YAT_DIST_BACKEND", "nccl") != "nccl":     # one-GPU rehearsal: ranks share the devices present
+                    local %= max(torch.cuda.device_count(), 1)
+                device = torch.device("cuda", local)
+            else:
+                device = torch.device("cpu")
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
         if self.num_processes > 1 and not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
+            backend = backend or os.environ.get("YAT_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
             dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s))
         self.is_main_process = self.process_index == 0
         self.sync_gradients = True

@@ -205,6 +205,12 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // so the LOAD segments carry only the fragment reads and stay shorter than the partner's COMPUTE segment.
     constexpr bool DIC_ = A_T || B_T;
     constexpr int GAP = (8 * NT) / NPIECE >= 4 ? 4 : 3;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
+    // pieces issued inside the compute segment; the rest follow at the top of the same wave's next LOAD segment (still ahead
+    // of its wait).  All of them by default (measured best, profiles/r02_h_gemm_ablation.txt has the split's numbers).
+#ifndef YAT_GEMM_DMA_SPLIT
+#define YAT_GEMM_DMA_SPLIT 99
+#endif
+    constexpr int NSPLIT = YAT_GEMM_DMA_SPLIT < NPIECE ? YAT_GEMM_DMA_SPLIT : NPIECE;
     static_assert((8 * NT) / GAP >= NPIECE, "not enough MFMA slots for the DMA pieces of a tile");
     auto compute = [&](int dma_tile) {
         char* dst = smem + (dma_tile & 1) * G::STAGE;
@@ -215,7 +221,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             for (int j = 0; j < NT; ++j) {
                 acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
                 const int idx = i * NT + j;
-                if (DIC_ && idx % GAP == GAP - 1 && idx / GAP < NPIECE) {
+                if (DIC_ && idx % GAP == GAP - 1 && idx / GAP < NSPLIT) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (dma_tile >= 0) issue_piece(dma_tile, dst, idx / GAP);
                     __builtin_amdgcn_sched_barrier(0);
@@ -256,6 +262,10 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
+            if (DIC && NSPLIT < NPIECE && t + 1 < nt && ((grp == 0 && kk == 1) || (grp == 1 && kk == 0 && t >= 1))) {
+#pragma unroll
+                for (int j = NSPLIT; j < NPIECE; ++j) issue_piece(t + 1, smem + ((t + 1) & 1) * G::STAGE, j);
+            }
             if (!YAT_ABL_SKIP_READS || t == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) af[i] = frag256<A_T, BM>(cur, grp * 128 + i * 16, kk, lane);

@@ -110,13 +110,19 @@ class HipDDP:
             # event on the stream that finished the bucket -> all-reduce on the communication stream, all inside the library
             self.native.allreduce_async(chunk, i, torch.cuda.current_stream(), self.comm_stream)
             return
-        op = dist.ReduceOp.AVG if (self.average and self.on_gpu) else dist.ReduceOp.SUM
+        rccl = self.on_gpu and dist.get_backend(self.pg) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and rccl) else dist.ReduceOp.SUM
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(chunk, op=op, group=self.pg, async_op=True))
+                if rccl:
+                    self._works.append(dist.all_reduce(chunk, op=op, group=self.pg, async_op=True))
+                else:       # one-GPU rehearsal over gloo (device tensors staged through the host): sum, then the mean
+                    dist.all_reduce(chunk, op=op, group=self.pg)
+                    if self.average:
+                        chunk.div_(self.world)
         else:  # gloo path used by the CPU multi-process tests
             w = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
             self._works.append((w, chunk))
