@@ -97,3 +97,71 @@ def test_forced_ddp_native_transport_is_bit_identical():
     assert torch.equal(x, torch.ones_like(x))
     NativeComm.get().destroy()
     assert lib.yat_comm_world() == 0
+
+
+def _world2_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      YAT_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yat_amd.ddp import HipDDP
+    from yat_amd.optim import FlatAdamW
+    from yat_amd.recipe import SanaRecipe
+    model, cfg = _model()
+    if rank == 1:                                  # broadcast must overwrite this
+        model.flat_param.add_(1.0)
+    ddp = HipDDP(model)
+    ddp.broadcast_parameters()
+    opt = FlatAdamW(model, lr=1e-3, weight_decay=0.01, overlap_update=True)
+    recipe = SanaRecipe(model, pad_to=32, device=DEV)
+    g = torch.Generator().manual_seed(20 + rank)   # every rank its own batch
+    grads = []
+    for s in range(3):                             # step 0 records the launch plans' first versions, 1-2 replay (DDP hooks inside)
+        latents = (torch.randn(4, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+        embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (5, 32, 17, 9)]
+        recipe.optimize_device(latents, embs, torch.Generator().manual_seed(10 + s))
+        ddp.wait()
+        torch.cuda.synchronize()
+        grads.append(model.flat_grad.clone().cpu())
+        opt.step()
+    model.join_pending_update()
+    torch.cuda.synchronize()
+    torch.save(dict(grads=grads, param=model.flat_param.cpu(), replays=getattr(model, "plan_replays", 0)),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_world2_over_gloo_matches_two_single_rank_backwards(tmp_path):
+    """Two processes on this one GPU (gloo transport: RCCL refuses two ranks on one device), each training its own batch on
+    the device path with launch plans on: after the bucketed mean every rank must hold the SAME gradient -- the mean of the two
+    single-rank gradients -- and, after the optimizer, the same parameters.  The single-rank gradients are recomputed here."""
+    import socket
+    import torch.multiprocessing as mp
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.optim import FlatAdamW
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_world2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    assert r0["replays"] >= 2 and r1["replays"] >= 2, "the launch plans were never replayed"
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b), "ranks disagree on the reduced gradient"
+    assert torch.equal(r0["param"], r1["param"])
+    # reference for step 0: the two local gradients from identical initial weights, averaged
+    local = []
+    for rank in (0, 1):
+        model, cfg = _model()
+        recipe = SanaRecipe(model, pad_to=32, device=DEV)
+        g = torch.Generator().manual_seed(20 + rank)
+        latents = (torch.randn(4, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+        embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (5, 32, 17, 9)]
+        recipe.optimize_device(latents, embs, torch.Generator().manual_seed(10))
+        torch.cuda.synchronize()
+        local.append(model.flat_grad.float().cpu())
+    mean = (local[0] + local[1]) / 2
+    err = ((r0["grads"][0].float() - mean).norm() / mean.norm()).item()
+    print(f"[parity] world-2 mean gradient vs the two single-rank gradients: rel_l2={err:.3e}")
+    assert err <= 6e-3
