@@ -277,3 +277,58 @@ def test_launch_plan_replay_is_bit_identical():
     # step 0 records without optimizer events, steps 1-2 record the steady-state plans of the two buckets (fwd + bwd each)
     assert replays >= 2 * 4 and nplans <= 8
     assert torch.equal(l_a, l_b) and torch.equal(p_a, p_b)
+
+
+def test_forward_and_backward_are_hipgraph_capturable():
+    """include/yat_hip.h promises that every entry point only enqueues (no sync, no allocation) and is therefore capturable in a
+    hipGraph.  Substantiated here: the whole forward + loss + backward of a tiny SANA on ONE stream is captured with
+    torch.cuda.graph (hipGraph underneath) after a warm-up that creates the arena, replayed on NEW input contents in the same
+    buffers, and must reproduce the eager run bit for bit."""
+    from oracle.sana_ref import SanaConfig as RefCfg
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd import ops
+    rcfg = RefCfg.tiny(num_layers=2)
+    hip = SanaTransformer2DModelHIP(SanaConfig(**{k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}),
+                                    device=DEV).init_synthetic(2)
+    hip.side_wgrad, hip.fwd_chains, hip.use_plans = False, 1, False          # one stream: the capture stream
+    recipe = SanaRecipe(hip, pad_to=32, device=DEV)
+    B, T, C = 2, 32, rcfg.caption_channels
+    g = torch.Generator(device=DEV).manual_seed(0)
+    lat = torch.empty(B, rcfg.in_channels, 6, 10, dtype=BF, device=DEV)
+    noise, enc = torch.empty_like(lat), torch.empty(B, T, C, dtype=BF, device=DEV)
+    bias = torch.zeros(B, T, device=DEV)
+    kvl = torch.tensor([9, 30], dtype=torch.int32, device=DEV)
+    bias[0, 9:], bias[1, 30:] = -10000.0, -10000.0
+    t = torch.tensor([700.0, 55.0], device=DEV)
+    sig = torch.tensor([0.7, 0.1], device=DEV).to(BF)
+    work = ops.kv_work_list([9, 30], T, DEV)
+    loss = torch.zeros(1, device=DEV)
+
+    def fill(seed):
+        g.manual_seed(seed)
+        lat.copy_((torch.randn(lat.shape, generator=g, device=DEV) * 0.5).to(BF))
+        noise.copy_(torch.randn(lat.shape, generator=g, device=DEV).to(BF))
+        enc.copy_(torch.randn(enc.shape, generator=g, device=DEV).to(BF))
+
+    def step():
+        recipe.train_step_device(lat, enc, (bias, kvl), noise, t, sig, loss, kv_work=work)
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        fill(1)
+        step()                                   # warm-up on the capture stream: arena, workspaces, kernel attributes
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            step()
+        fill(2)                                  # new contents, same addresses
+        graph.replay()
+        stream.synchronize()
+        got = (loss.clone(), hip.flat_grad.clone(), hip._buf("pred", (B, rcfg.out_channels, 60)).clone())
+        step()                                   # eager, same inputs
+        stream.synchronize()
+        want = (loss.clone(), hip.flat_grad.clone(), hip._buf("pred", (B, rcfg.out_channels, 60)).clone())
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), "hipGraph replay differs from the eager launches"
+    assert float(got[0]) == float(got[0]) and got[1].abs().max() > 0
