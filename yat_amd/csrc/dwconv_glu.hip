@@ -555,9 +555,15 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     }
     size_t lds2 = 0;
     int threads2 = 256;
-    const int R2 = w <= 64 && !(C2 & 7) && du_bytes <= 0x7fffffffull ? pick_band_rows_bwd2(h, w, &lds2, &threads2) : 0;
-    int nparts;
-    if (R2) {
+    // pass 2 variants: 64 channels per tile with s, z straight from global (128-byte pixel slices everywhere; 1), or the
+    // 32-channel kernel with all three operands tiled in LDS (2); YAT_DW_BWD2=2 forces the latter
+    static const int bwd2_force = getenv("YAT_DW_BWD2") ? atoi(getenv("YAT_DW_BWD2")) : 0;
+    int nparts = bwd2_force == 2 ? 0 : v64w3::launch_bwd2_gs(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)z, du,
+                                                              (const bf16_t*)wdw, (bf16_t*)dz, ws, (hipStream_t)stream);
+    const bool gs = nparts > 0;
+    const int R2 = !gs && w <= 64 && !(C2 & 7) && du_bytes <= 0x7fffffffull ? pick_band_rows_bwd2(h, w, &lds2, &threads2) : 0;
+    if (gs) {
+    } else if (R2) {
         const int nbands = (h + R2 - 1) / R2, nchunk = (C2 + TCH - 1) / TCH;
         int bpb = nbands;
         while (bpb > 1 && (int64_t)((nbands + bpb - 1) / bpb) * nchunk * B < 4 * 512) --bpb;
@@ -575,9 +581,9 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     }
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((C2 * PK + 63) / 64), dim3(256), 0, (hipStream_t)stream, nparts, C2,
-                       (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, R2 ? (bf16_t*)dz_colsum : (bf16_t*)nullptr, accumulate);
+                       (const float*)ws, (bf16_t*)dwdw, (bf16_t*)dbdw, (R2 || gs) ? (bf16_t*)dz_colsum : (bf16_t*)nullptr, accumulate);
     YAT_CHECK_LAUNCH();
-    if (dz_colsum && !R2)                                     // direct path: the column sum of dz is its own pass
+    if (dz_colsum && !R2 && !gs)                                     // direct path: the column sum of dz is its own pass
         return yat_colsum_bf16(B * h * w, C2, dz, C2, dz_colsum, accumulate, ws, stream);
     return YAT_OK;
 }
