@@ -558,7 +558,9 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     // pass 2 variants: 64 channels per tile with s, z straight from global (128-byte pixel slices everywhere; 1), or the
     // 32-channel kernel with all three operands tiled in LDS (2); YAT_DW_BWD2=2 forces the latter
     static const int bwd2_force = getenv("YAT_DW_BWD2") ? atoi(getenv("YAT_DW_BWD2")) : 0;
-    int nparts = bwd2_force == 2 ? 0 : v64w3::launch_bwd2_gs(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)z, du,
+    // measured (B = 8, Hc = 5600, us, 32-channel all-LDS kernel -> 64-channel global-s/z kernel): 32x32 237 -> 172,
+    // 44x22 228 -> 211, but 24x42 199 -> 216 and 16x64 228 -> 246: narrow rows only
+    int nparts = (bwd2_force == 2 || (bwd2_force == 0 && w > 32)) ? 0 : v64w3::launch_bwd2_gs(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)z, du,
                                                               (const bf16_t*)wdw, (bf16_t*)dz, ws, (hipStream_t)stream);
     const bool gs = nparts > 0;
     const int R2 = !gs && w <= 64 && !(C2 & 7) && du_bytes <= 0x7fffffffull ? pick_band_rows_bwd2(h, w, &lds2, &threads2) : 0;
