@@ -256,3 +256,79 @@ def test_sd3_trainer_runs_from_shards(tmp_path, monkeypatch):
     assert not torch.equal(before, trainer.model.flat_param)
     ck = tmp_path / "models" / "2"
     assert (ck / "config.json").exists() and (ck / "diffusion_pytorch_model.safetensors").exists()
+
+
+@pytest.mark.parametrize("algo", ["lora", "lokr"])
+def test_sd3_adapter_step_matches_oracle(algo):
+    """PEFT adapters on the MMDiT (the reference wraps whatever model the entry point trains, common/trainer.py:212-241): the
+    model's lin / dgrad / wgrad hooks are those of SANA and PixArt.  One adapted step on the tiny configuration -- targets incl.
+    the fused q|k|v and add_q|k|v projections, both FFNs' ``proj`` layers, the AdaLN ``linear``s and the patch embedding --
+    against the oracle's peft-wrapped model in bf16 and fp32."""
+    from oracle.sd3_ref import optimize_ref
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched
+    from yat_amd.recipe import SD3Recipe
+    targets = ["to_q", "to_k", "to_v", "to_out.0", "add_q_proj", "add_k_proj", "add_v_proj", "to_add_out", "linear_1",
+               "linear_2", "proj", "linear"]
+    rcfg, ref_bf, _, hip = _setup({})
+    g = torch.Generator().manual_seed(21)
+    if algo == "lora":
+        from oracle.lora_ref import apply_lora as apply, LoRAWrapped as Wrapped
+        from yat_amd.lora import LoRAAdapters
+        ad = LoRAAdapters(hip, targets, r=4, alpha=4.0)
+        for e in ad.entries:
+            _, bt = ad._views(e, ad.flat_param)
+            bt[:4].copy_((torch.randn(4, e["out"], generator=g) * 0.05).to(BF))
+        names = ("lora_A.weight", "lora_B.weight")
+        attrs = ("lora_A", "lora_B")
+        wrapped = apply(ref_bf, targets, r=4, alpha=4.0)
+    else:
+        from oracle.lokr_ref import apply_lokr as apply, LoKrWrapped as Wrapped
+        from yat_amd.lokr import LoKrAdapters
+        ad = LoKrAdapters(hip, targets, r=2, alpha=4.0)
+        for e in ad.entries:
+            w1 = ad._views(e, ad.flat_param)[0]
+            w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+        names = attrs = ("lokr_w1", "lokr_w2_a", "lokr_w2_b")
+        wrapped = apply(ref_bf, targets, r=2, alpha=4.0)
+    assert sorted(wrapped) == sorted(e["module"] for e in ad.entries)
+    assert "transformer_blocks.0.norm1.linear" in wrapped and "transformer_blocks.0.ff_context.net.0.proj" in wrapped
+    sd = ad.state_dict()
+    for name, w in wrapped.items():
+        for k, a in zip(names, attrs):
+            with torch.no_grad():
+                getattr(w, a).copy_(sd[f"base_model.model.{name}.{k}"].cpu())
+    ref_32 = copy.deepcopy(ref_bf).float()
+    latents = (torch.randn(2, rcfg.in_channels, 12, 8, generator=g) * 0.5).to(BF)
+    prompt = torch.randn(2, 10, rcfg.joint_attention_dim, generator=g).to(BF)
+    pooled = torch.randn(2, rcfg.pooled_projection_dim, generator=g).to(BF)
+    outs = {}
+    for tag, model, dt in (("bf16", ref_bf, BF), ("fp32", ref_32, torch.float32)):
+        model.train()
+        loss, pred, _ = optimize_ref(model, RefSched(), latents, prompt, pooled, torch.Generator().manual_seed(7), dt)
+        loss.backward()
+        outs[tag] = (pred.detach(), {n: [getattr(m, a).grad for a in attrs] for n, m in model.named_modules()
+                                     if isinstance(m, Wrapped)})
+    recipe = SD3Recipe(hip, device=DEV)
+    hip.train()
+    base = hip.flat_param.clone()
+    loss, pred, _ = recipe.optimize(latents, (prompt, pooled), torch.Generator().manual_seed(7), return_pred=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    e_h, e_r = rel(pred, outs["fp32"][0]), rel(outs["bf16"][0], outs["fp32"][0])
+    print(f"[parity] sd3 {algo} pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
+    assert e_h <= 1.3 * e_r + 1e-3
+    hg, bg, fg = [], [], []
+    for e in ad.entries:
+        views = ad._views(e, ad.flat_grad)
+        if algo == "lora":
+            mine = [views[0][:4], views[1][:4].t()]
+        else:
+            mine = list(views)
+        hg += [t.float().flatten().cpu() for t in mine]
+        bg += [t.float().flatten() for t in outs["bf16"][1][e["module"]]]
+        fg += [t.float().flatten() for t in outs["fp32"][1][e["module"]]]
+    hg, bg, fg = torch.cat(hg), torch.cat(bg), torch.cat(fg)
+    e_h, e_r = rel(hg, fg), rel(bg, fg)
+    print(f"[parity] sd3 {algo} adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
+    assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.3 * e_r + 2e-3
+    assert torch.equal(base, hip.flat_param)

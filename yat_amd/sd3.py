@@ -208,8 +208,9 @@ class SD3Transformer2DModelHIP(FlatParamModule):
     # ------------------------------------------------------------------ forward
     def forward_impl(self, latents, enc, pooled, timestep):
         cfg, P = self.cfg, self.P
-        if self.adapters is not None:
-            raise NotImplementedError("PEFT adapters are wired for SANA and PixArt-Sigma; not for the MMDiT yet")
+        ad = self.adapters
+        if ad is not None:
+            ad.materialize(self.training)                     # yat_amd/lora.py / lokr.py / loha.py: this step's adapter state
         D, H, dh, p = cfg.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim, cfg.patch_size
         B, Cin, Hl, Wl = latents.shape
         if Hl % p or Wl % p:
@@ -229,7 +230,13 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None
-        lin = ops.linear_fwd
+
+        def lin(x_, w_, bias_=None, out=None, **ep):
+            """Linear of a (possibly adapted) target: the adapter term is folded in through the GEMM's pre_add epilogue."""
+            tmp = ad.forward_term(x_, w_) if ad is not None else None
+            if tmp is None:
+                return ops.linear_fwd(x_, w_, bias_, out=out, **ep)
+            return ops.linear_fwd(x_, w_, bias_, out=out, pre_add=tmp, **ep)
 
         def params_ready(bucket, stream=main):
             if pev is not None:
@@ -459,14 +466,35 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             with torch.cuda.stream(side):
                 fn()
 
-        def wgrad(dy, x, gw, gbias=None):
+        ad = self.adapters
+        pending_ad = []                   # adapter weight gradients wait for the H product of the dgrad of the same dy
+
+        def wgrad(dy, x, gw, gbias=None, dgrad_follows=True):
+            if ad is not None:            # frozen base: only the adapters' share, launched by the dgrad() of the same dy
+                if dgrad_follows:
+                    pending_ad.append((dy, x, gw))
+                else:
+                    off_chain(lambda: ad.wgrad(dy, x, gw, accumulate=acc))
+                return
+
             def run():
                 ops.linear_wgrad(dy, x, gw, accumulate=acc)
                 if gbias is not None:
                     ops.colsum(dy, gbias, ws_col, accumulate=acc)
             off_chain(run)
 
-        dgrad = ops.linear_dgrad
+        def dgrad(dy_, w_, out=None, residual=None):
+            r_ = ops.linear_dgrad(dy_, w_, out=out, residual=residual)
+            if ad is not None:
+                hs = ad.dgrad_term(dy_, w_, r_)
+                keep = []
+                for item in pending_ad:
+                    if item[0].data_ptr() == dy_.data_ptr():
+                        off_chain(lambda item=item, hs=hs: ad.wgrad(*item, accumulate=acc, hs=hs))
+                    else:
+                        keep.append(item)
+                pending_ad[:] = keep
+            return r_
         # d(silu(temb)): every modulation Linear adds its share (bf16 accumulation, as autograd sums the bf16 branches);
         # lives on the second stream (the modulation gradients are produced there)
         dse = buf("dse", (B, D))
@@ -475,8 +503,11 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         def mod_grads(demb_f32, wkey, bkey, tag):
             """demb [B, k*D] fp32 accumulators -> Linear(silu(temb)) gradients: weight, bias, and the share of d silu(temb)."""
             d_b = ops.f32_to_bf16(demb_f32, buf(f"demb_b.{tag}", tuple(demb_f32.shape)))
-            ops.linear_wgrad(d_b, S.se, G[wkey], accumulate=acc)
-            ops.colsum(d_b, G[bkey], ws_col, accumulate=acc)
+            if ad is None:
+                ops.linear_wgrad(d_b, S.se, G[wkey], accumulate=acc)
+                ops.colsum(d_b, G[bkey], ws_col, accumulate=acc)
+            else:
+                pending_ad.append((d_b, S.se, G[wkey]))
             dgrad(d_b, P[wkey], out=dse, residual=dse if dse_started[0] else None)
             dse_started[0] = True
 
@@ -633,21 +664,26 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         if side is not None:
             main.wait_stream(side)
             side = None
-        wgrad(dx, S.x_tok, G["pos_embed.proj.weight"].view(D, Kp), G["pos_embed.proj.bias"])     # + pos_embed: identity
-        wgrad(dc, S.enc2d, G["context_embedder.weight"], G["context_embedder.bias"])
+        wgrad(dx, S.x_tok, G["pos_embed.proj.weight"].view(D, Kp), G["pos_embed.proj.bias"], dgrad_follows=False)   # + pos_embed: identity
+        wgrad(dc, S.enc2d, G["context_embedder.weight"], G["context_embedder.bias"], dgrad_follows=False)
         # conditioning: d temb = silu'(temb) * dse; temb = timestep branch + pooled branch
         dtemb = ops.act_bwd(S.temb, dse, "silu", buf("te_d0", (B, D)))
         pre = "time_text_embed."
         wgrad(dtemb, S.e1, G[pre + "timestep_embedder.linear_2.weight"], G[pre + "timestep_embedder.linear_2.bias"])
         de1 = dgrad(dtemb, P[pre + "timestep_embedder.linear_2.weight"], out=buf("te_d1", (B, D)))
         dz1 = ops.act_bwd(S.z1, de1, "silu", buf("te_d2", (B, D)))
-        wgrad(dz1, S.tproj, G[pre + "timestep_embedder.linear_1.weight"], G[pre + "timestep_embedder.linear_1.bias"])
+        wgrad(dz1, S.tproj, G[pre + "timestep_embedder.linear_1.weight"], G[pre + "timestep_embedder.linear_1.bias"],
+              dgrad_follows=False)
         wgrad(dtemb, S.p1, G[pre + "text_embedder.linear_2.weight"], G[pre + "text_embedder.linear_2.bias"])
         dp1 = dgrad(dtemb, P[pre + "text_embedder.linear_2.weight"], out=buf("te_d3", (B, D)))
         dzp = ops.act_bwd(S.zp, dp1, "silu", buf("te_d4", (B, D)))
-        wgrad(dzp, S.pooled, G[pre + "text_embedder.linear_1.weight"], G[pre + "text_embedder.linear_1.bias"])
+        wgrad(dzp, S.pooled, G[pre + "text_embedder.linear_1.weight"], G[pre + "text_embedder.linear_1.bias"],
+              dgrad_follows=False)
         if self.grad_ready is not None:
             self.grad_ready(0)
+        if ad is not None:
+            assert not pending_ad, "an adapter weight gradient was queued without a following dgrad()"
+            ad.project()                  # adapter gradients complete (LoKr: d_P -> d_w1, d_w2_a; DDP hook)
 
     # ------------------------------------------------------------------ checkpoint I/O (diffusers layout)
     def save_pretrained(self, path):
