@@ -284,6 +284,9 @@ def test_sd3_adapter_step_matches_oracle(algo):
     else:
         from oracle.lokr_ref import apply_lokr as apply, LoKrWrapped as Wrapped
         from yat_amd.lokr import LoKrAdapters
+        with pytest.raises(NotImplementedError, match="convolution"):       # 'proj' also names the 2x2 patch embedding
+            LoKrAdapters(hip, targets, r=2, alpha=4.0)
+        targets = [t if t != "proj" else "net.0.proj" for t in targets]
         ad = LoKrAdapters(hip, targets, r=2, alpha=4.0)
         for e in ad.entries:
             w1 = ad._views(e, ad.flat_param)[0]

@@ -84,6 +84,10 @@ class LoKrAdapters:
         for key, w in model.P.items():
             if not key.endswith(".weight") or w.dim() < 2 or not is_target(key[:-7], self.targets):
                 continue
+            if w.dim() == 4 and w.shape[2] * w.shape[3] != 1:
+                # peft factorises the CHANNEL counts of a k x k convolution and hangs the kernel on lokr_w2: not this layout
+                raise NotImplementedError(f"{key}: LoKr on a {w.shape[2]}x{w.shape[3]} convolution is not built; name the "
+                                          f"linear targets more narrowly (e.g. 'net.0.proj' instead of 'proj')")
             out_dim, in_dim = w.shape[0], w.numel() // w.shape[0]
             (out_l, out_k), (in_m, in_n) = factorization(out_dim), factorization(in_dim)
             if not (self.r < max(out_k, in_n) / 2):
