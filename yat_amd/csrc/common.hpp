@@ -121,6 +121,10 @@ __device__ __forceinline__ void xcd_contiguous3(int& bx, int& by, int& bz) {
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, YAT_LDS void* lds_wave_base, uint32_t voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_wave_base, 16, voff, 0, 0, 0);
 }
+// same, with the uniform part of the address in the instruction's scalar offset (NOT covered by the buffer range check)
+__device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, YAT_LDS void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_wave_base, 16, voff, soff, 0, 0);
+}
 #define YAT_OOB 0x80000000u
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint64_t bytes) {

@@ -25,6 +25,7 @@
 // Operand layouts, swizzles, swapped-operand MFMA and epilogue are those of gemm.hip.
 #include "common.hpp"
 #include "gemm_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -93,6 +94,27 @@ __device__ __forceinline__ bf16x8 frag256(const char* lds, int idx0, int kk, int
     }
 }
 
+// The k-strided fragment addresses, arranged so a LOAD segment computes almost nothing.  A lane reads rows r0 = 32 kk + 8 g + q
+// and r0 + 4; trswz2 is the same for r0, r0 + 4 and r0 + 32 (it looks at bits 0, 1 and 3 of the row only), so ONE address per
+// 16-column fragment serves both rows and both sub-steps through the instruction's immediate offset.
+//  * 256-column image (operand A always; B of the 256 x 256 tile): the chunk index of fragment f is (first/8 + 2 f + p/2) ^ swz
+//    with `first` a multiple of 64 columns, so bits 1..3 of first/8 are free and the XOR lands on 2 f alone:
+//    address(f) = address(0) ^ (f << 5) -- one per-lane base, one v_xor per fragment.
+//  * 320-column image (B of the 256 x 320 tile): first = 80 wc is not aligned like that; one per-lane address per fragment.
+template <int COLS>
+__device__ __forceinline__ uint32_t tr_lane_addr(uint32_t col0, int lane) {
+    const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const uint32_t r0 = 8 * g + q;
+    const uint32_t c = ((col0 + 4 * p) >> 3) ^ trswz2<COLS>(r0);
+    return r0 * (COLS * 2) + c * 16 + (p & 1) * 8;
+}
+template <int COLS>
+__device__ __forceinline__ bf16x8 frag_tr(uint32_t lds_addr, int kk) {
+    YAT_LDS const char* a = (YAT_LDS const char*)(uintptr_t)lds_addr;
+    return cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((YAT_LDS bf16x4*)(a + kk * 32 * COLS * 2)),
+                __builtin_amdgcn_ds_read_tr16_b64_v4bf16((YAT_LDS bf16x4*)(a + kk * 32 * COLS * 2 + 4 * COLS * 2)));
+}
+
 #define YAT_PHASE_BARRIER()                  \
     do {                                     \
         __builtin_amdgcn_sched_barrier(0);   \
@@ -157,21 +179,48 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     const int nt = (int)(((int64_t)nt_all * (ksl + 1)) / p.ksplit) - kt0;
     const bool ragged = (p.K & (BK - 1)) != 0;
 
-    auto issue = [&](int tl, char* stage) {
-        const int t = kt0 + tl;                                      // global k-tile
-        const bool tail = ragged && t == nt_all - 1;
-        const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;     // valid 16-B chunks in this k-tile (row-mode)
-#pragma unroll
-        for (int j = 0; j < G::PA; ++j) {
-            uint32_t v = pa[j].voff + (uint32_t)t * a_kstep;
-            if (!A_T && tail && pa[j].kchunk >= kvalid) v = YAT_OOB;
-            lds_dma16(ra, (YAT_LDS void*)(stage + (wave + 8 * j) * 1024), v);
+    // A DMA piece costs the issuing wave its instruction AND whatever computes its operands.  The k-tile advance therefore
+    // rides in the instruction's scalar offset (one s_mul per segment, no VALU per piece) and the per-lane offsets stay the
+    // loop-invariant registers of make_piece.  The scalar offset is not part of the buffer range check, so the two cases that
+    // lean on per-lane checks -- the ragged last k-tile (row-mode chunks past K, k-strided rows past K) -- take the CHECKED
+    // form (per-lane add + compare) instead; which form a segment uses is one uniform branch per segment, not per piece.
+    auto is_tail = [&](int tl) { return ragged && kt0 + tl == nt_all - 1; };
+    auto piece = [&](auto checked, int tl, char* stage, int j) {
+        constexpr bool CHECKED = decltype(checked)::value;
+        const int t = kt0 + tl;
+        const bool opa = j < G::PA;
+        const int jj = opa ? j : j - G::PA;
+        if (opa) {
+            YAT_LDS void* dst = (YAT_LDS void*)(stage + (wave + 8 * jj) * 1024);
+            if (CHECKED) {
+                const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;     // valid 16-B chunks in this k-tile (row-mode)
+                uint32_t v = pa[jj].voff + (uint32_t)t * a_kstep;
+                if (!A_T && pa[jj].kchunk >= kvalid) v = YAT_OOB;
+                lds_dma16(ra, dst, v);
+            } else {
+                lds_dma16s(ra, dst, pa[jj].voff, (uint32_t)t * a_kstep);
+            }
+        } else {
+            YAT_LDS void* dst = (YAT_LDS void*)(stage + G::A_BYTES + (wave + 8 * jj) * 1024);
+            if (CHECKED) {
+                const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
+                uint32_t v = pb[jj].voff + (uint32_t)t * b_kstep;
+                if (!B_T && pb[jj].kchunk >= kvalid) v = YAT_OOB;
+                lds_dma16(rb, dst, v);
+            } else {
+                lds_dma16s(rb, dst, pb[jj].voff, (uint32_t)t * b_kstep);
+            }
         }
+    };
+    constexpr int NPIECE = G::PA + G::PB;        // 8 or 9 pieces per wave per tile
+    constexpr bool TIGHT = false;                // (a kernel at the register limit can keep ONE loop body with checked pieces)
+    auto issue = [&](int tl, char* stage) {
+        if (TIGHT || is_tail(tl)) {
 #pragma unroll
-        for (int j = 0; j < G::PB; ++j) {
-            uint32_t v = pb[j].voff + (uint32_t)t * b_kstep;
-            if (!B_T && tail && pb[j].kchunk >= kvalid) v = YAT_OOB;
-            lds_dma16(rb, (YAT_LDS void*)(stage + G::A_BYTES + (wave + 8 * j) * 1024), v);
+            for (int j = 0; j < NPIECE; ++j) piece(std::true_type{}, tl, stage, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) piece(std::false_type{}, tl, stage, j);
         }
     };
 
@@ -182,38 +231,28 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 af[8], bfr[NT];
-    // one DMA piece of tile t (j < PA: operand A, else operand B)
-    auto issue_piece = [&](int tl, char* stage, int j) {
-        const int t = kt0 + tl;
-        const bool tail = ragged && t == nt_all - 1;
-        const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
-        if (j < G::PA) {
-            uint32_t v = pa[j].voff + (uint32_t)t * a_kstep;
-            if (!A_T && tail && pa[j].kchunk >= kvalid) v = YAT_OOB;
-            lds_dma16(ra, (YAT_LDS void*)(stage + (wave + 8 * j) * 1024), v);
-        } else {
-            const int jb = j - G::PA;
-            uint32_t v = pb[jb].voff + (uint32_t)t * b_kstep;
-            if (!B_T && tail && pb[jb].kchunk >= kvalid) v = YAT_OOB;
-            lds_dma16(rb, (YAT_LDS void*)(stage + G::A_BYTES + (wave + 8 * jb) * 1024), v);
-        }
-    };
-    constexpr int NPIECE = G::PA + G::PB;        // 8 or 9 pieces per wave per tile
-
+    // per-lane LDS addresses of the k-strided fragments (tr_lane_addr above): one for A, one (256-column) or NT for B
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(YAT_LDS char*)smem;
+    uint32_t a_tr[1] = {0}, b_tr[NT == 4 ? 1 : NT] = {0};
+    if (A_T) a_tr[0] = tr_lane_addr<BM>(0, lane);
+    if (B_T && NT == 4) b_tr[0] = tr_lane_addr<G::BN>(wc * 64, lane);
+    else if (B_T) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b_tr[j] = tr_lane_addr<G::BN>(wc * 16 * NT + j * 16, lane);
+    }
     // COMPUTE segment: 8 x NT MFMAs on registers; when dma_tile >= 0 this wave's DMA pieces for that tile are
     // issued between groups of 4 MFMAs (the matrix pipe keeps draining queued MFMAs while the wave issues a DMA),
     // so the LOAD segments carry only the fragment reads and stay shorter than the partner's COMPUTE segment.
     constexpr bool DIC_ = A_T || B_T;
     constexpr int GAP = (8 * NT) / NPIECE >= 4 ? 4 : 3;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
-    // pieces issued inside the compute segment; the rest follow at the top of the same wave's next LOAD segment (still ahead
-    // of its wait).  All of them by default (measured best, profiles/r02_h_gemm_ablation.txt has the split's numbers).
-#ifndef YAT_GEMM_DMA_SPLIT
-#define YAT_GEMM_DMA_SPLIT 99
-#endif
-    constexpr int NSPLIT = YAT_GEMM_DMA_SPLIT < NPIECE ? YAT_GEMM_DMA_SPLIT : NPIECE;
     static_assert((8 * NT) / GAP >= NPIECE, "not enough MFMA slots for the DMA pieces of a tile");
-    auto compute = [&](int dma_tile) {
+    // MODE 0: no DMA in this segment; 1: scalar-offset pieces, unconditionally (two scalar instructions + the DMA each);
+    // 2: decided per piece at run time (tile missing / ragged last k-tile) -- only in the last iterations of a K loop;
+    // 3: per piece, tile missing or the checked form (the register-tight kernels' only loop body)
+    auto compute = [&](auto mode_c, int dma_tile) {
+        constexpr int MODE = decltype(mode_c)::value;
         char* dst = smem + (dma_tile & 1) * G::STAGE;
+        const bool checked = MODE == 2 && dma_tile >= 0 && is_tail(dma_tile);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -221,9 +260,15 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             for (int j = 0; j < NT; ++j) {
                 acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
                 const int idx = i * NT + j;
-                if (DIC_ && idx % GAP == GAP - 1 && idx / GAP < NSPLIT) {
+                if (MODE != 0 && idx % GAP == GAP - 1 && idx / GAP < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (dma_tile >= 0) issue_piece(dma_tile, dst, idx / GAP);
+                    if (MODE == 1) piece(std::false_type{}, dma_tile, dst, idx / GAP);
+                    else if (MODE == 3) {
+                        if (dma_tile >= 0) piece(std::true_type{}, dma_tile, dst, idx / GAP);
+                    } else if (dma_tile >= 0) {
+                        if (checked) piece(std::true_type{}, dma_tile, dst, idx / GAP);
+                        else piece(std::false_type{}, dma_tile, dst, idx / GAP);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -254,42 +299,91 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     //           for tile t+1's pieces before its 3rd barrier of iteration t (= 4t+4).
     //   (!DIC) every wave issues tile t+1 at the top of LOAD(t,ks0) [after its 4th barrier of iteration t-1 >= 4t]
     //           and waits before its 3rd barrier of iteration t (<= 4t+4).
-    for (int t = 0; t < nt; ++t) {
+    // The loop body exists per wave group (GRP a constant: which segment carries the DMA is then decided at compile time)
+    // and as a FAST form -- the tile this iteration fetches exists and is a full one, so its pieces are unconditional,
+    // scalar-offset DMAs with no branch and no VALU around them -- plus the general form for the last iterations.  Both
+    // groups execute the same number of barriers per iteration in either form.
+    struct RuntimeGroup { int value; };
+    auto iteration = [&](auto grp_c, auto fast_c, int t) {
+        const int GRP = grp_c.value;           // a constant, except in the kernels that keep ONE loop body (below)
+        constexpr bool FAST = decltype(fast_c)::value;
         const char* cur = smem + (t & 1) * G::STAGE;
 #ifndef YAT_ABL_NO_DMA
-        if (!DIC && t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * G::STAGE);
+        if (!DIC) {
+            char* nxt = smem + ((t + 1) & 1) * G::STAGE;
+            if (FAST) {
+#pragma unroll
+                for (int j = 0; j < NPIECE; ++j) piece(std::false_type{}, t + 1, nxt, j);
+            } else if (t + 1 < nt) {
+                issue(t + 1, nxt);
+            }
+        }
 #endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
-            if (DIC && NSPLIT < NPIECE && t + 1 < nt && ((grp == 0 && kk == 1) || (grp == 1 && kk == 0 && t >= 1))) {
-#pragma unroll
-                for (int j = NSPLIT; j < NPIECE; ++j) issue_piece(t + 1, smem + ((t + 1) & 1) * G::STAGE, j);
-            }
             if (!YAT_ABL_SKIP_READS || t == 0) {
+                const uint32_t st = lds0 + (t & 1) * G::STAGE;
+                if (A_T) {
+                    const uint32_t a0 = a_tr[0] + st + GRP * 256;            // group's rows = columns 128 GRP.. of the image
 #pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = frag256<A_T, BM>(cur, grp * 128 + i * 16, kk, lane);
+                    for (int i = 0; i < 8; ++i) af[i] = frag_tr<BM>(a0 ^ (i << 5), kk);
+                } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bfr[j] = frag256<B_T, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
+                    for (int i = 0; i < 8; ++i) af[i] = frag256<false, BM>(cur, GRP * 128 + i * 16, kk, lane);
+                }
+                if (B_T && NT == 4) {
+                    const uint32_t b0 = b_tr[0] + st + G::A_BYTES;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b0 ^ (j << 5), kk);
+                } else if (B_T) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b_tr[j] + st + G::A_BYTES, kk);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bfr[j] = frag256<false, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef YAT_ABL_NO_VMWAIT
-            if (kk == 1 && (!DIC || grp == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
+            if (kk == 1 && (!DIC || GRP == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
 #endif
             YAT_LOOP_BARRIER();
-            // ---- COMPUTE segment
-            int dma_tile = -1;
-            if (DIC && kk == 0 && grp == 0 && t + 1 < nt) dma_tile = t + 1;
-            if (DIC && kk == 1 && grp == 1 && t + 2 < nt) dma_tile = t + 2;
+            // ---- COMPUTE segment: group 0 carries its DMA (tile t+1) in ks0, group 1 (tile t+2) in ks1
 #ifdef YAT_ABL_NO_DMA
-            dma_tile = -1;
+            compute(std::integral_constant<int, 0>{}, 0);
+#else
+            const int tile = t + 1 + GRP;
+            if constexpr (std::is_same<decltype(grp_c), RuntimeGroup>::value) {       // one MFMA block, per-piece decisions
+                compute(std::integral_constant<int, DIC ? 3 : 0>{}, kk == GRP && tile < nt ? tile : -1);
+            } else if (DIC && kk == GRP) {
+                if (FAST) compute(std::integral_constant<int, 1>{}, tile);
+                else compute(std::integral_constant<int, 2>{}, tile < nt ? tile : -1);
+            } else {
+                compute(std::integral_constant<int, 0>{}, 0);
+            }
 #endif
-            compute(dma_tile);
 #ifndef YAT_ABL_NO_VMWAIT
-            if (DIC && kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 (group 0's pieces)
+            if (DIC && kk == 1 && GRP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 (group 0's pieces)
 #endif
             YAT_LOOP_BARRIER();
         }
+    };
+    auto k_loop = [&](auto grp_c) {
+        // iterations whose fetched tile (t+1; t+2 for group 1 of a DIC kernel) exists and is not the ragged last one
+        const int ahead = DIC ? 1 + grp_c.value : 1;
+        const int nfast = max(0, nt - ahead - (ragged && kt0 + nt == nt_all ? 1 : 0));
+        int t = 0;
+        for (; t < nfast; ++t) iteration(grp_c, std::true_type{}, t);
+        for (; t < nt; ++t) iteration(grp_c, std::false_type{}, t);
+    };
+    if constexpr (TIGHT) {
+        // the 256 x 320 tile with a k-strided A already sits at 253 registers: more than one loop body spills, so these
+        // (two of the step's minor shapes) keep the general form with the group decided at run time
+        for (int t = 0; t < nt; ++t) iteration(RuntimeGroup{grp}, std::false_type{}, t);
+    } else {
+        if (grp == 0) k_loop(std::integral_constant<int, 0>{});
+        else k_loop(std::integral_constant<int, 1>{});
     }
     if (grp == 0) YAT_PHASE_BARRIER();         // pair group 1's last barrier
 
