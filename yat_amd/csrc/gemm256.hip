@@ -135,6 +135,24 @@ __device__ __forceinline__ bf16x8 frag_tr(uint32_t lds_addr, int kk) {
 #define YAT_ABL_SKIP_READS 0
 #endif
 
+// Diagnostic build -DYAT_GEMM_STAMPS (scripts/gemm_stamps.py): every wave of workgroup 0 sums, per K-loop iteration slot, the
+// s_memtime ticks it spent in  [4 kk + 0] LOAD (fragment reads issued and landed, incl. its DMA wait)  [+1] the rendezvous
+// after it  [+2] COMPUTE (MFMA + DMA issue)  [+3] the rendezvous after it (incl. group 0's DMA wait).  The sums go to a
+// buffer of their own that nothing else reads; the product build contains none of this.
+#ifdef YAT_GEMM_STAMPS
+__device__ unsigned int yat_gemm_stamp_buf[8 * 8 + 8];
+#define YAT_STAMP(slot)                                                       \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();         \
+        st_sum[slot] += now_ - st_prev;                                       \
+        st_prev = now_;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    } while (0)
+#else
+#define YAT_STAMP(slot) do {} while (0)
+#endif
+
 // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of `nwg` work items
 __device__ __forceinline__ int xcd_contiguous(int nwg) {
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
@@ -146,6 +164,9 @@ template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GL
 __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     using G = Geo<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef YAT_GEMM_STAMPS
+    const uint32_t st_kernel_begin = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wc = wave & 3;
@@ -231,6 +252,11 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 af[8], bfr[NT];
+#ifdef YAT_GEMM_STAMPS
+    uint32_t st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t st_prev = 0;
+    int st_slot = 0;
+#endif
     // per-lane LDS addresses of the k-strided fragments (tr_lane_addr above): one for A, one (256-column) or NT for B
     const uint32_t lds0 = (uint32_t)(uintptr_t)(YAT_LDS char*)smem;
     uint32_t a_tr[1] = {0}, b_tr[NT == 4 ? 1 : NT] = {0};
@@ -243,13 +269,24 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // COMPUTE segment: 8 x NT MFMAs on registers; when dma_tile >= 0 this wave's DMA pieces for that tile are
     // issued between groups of 4 MFMAs (the matrix pipe keeps draining queued MFMAs while the wave issues a DMA),
     // so the LOAD segments carry only the fragment reads and stay shorter than the partner's COMPUTE segment.
-    constexpr bool DIC_ = A_T || B_T;
+#ifndef YAT_GEMM_DIC_ALL
+#define YAT_GEMM_DIC_ALL 0          // 1: measured +4..6 % on the forward shapes alone, but the step got 2.4 ms SLOWER
+#endif
+    constexpr bool DIC_ = A_T || B_T || YAT_GEMM_DIC_ALL;
     constexpr int GAP = (8 * NT) / NPIECE >= 4 ? 4 : 3;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
     static_assert((8 * NT) / GAP >= NPIECE, "not enough MFMA slots for the DMA pieces of a tile");
     // MODE 0: no DMA in this segment; 1: scalar-offset pieces, unconditionally (two scalar instructions + the DMA each);
     // 2: decided per piece at run time (tile missing / ragged last k-tile) -- only in the last iterations of a K loop;
     // 3: per piece, tile missing or the checked form (the register-tight kernels' only loop body)
-    auto compute = [&](auto mode_c, int dma_tile) {
+    // The rendezvous that ends the segment is executed EARLY MFMAs before its end: the partner group, parked at the end of
+    // its LOAD segment, is released while this wave's last MFMAs are still in the pipe, so the barrier's turnaround overlaps
+    // them instead of idling the matrix pipe.  Legal because a COMPUTE segment touches registers only (every LDS read
+    // retired before the barrier that ends the LOAD segment) and the DMA waits move with the barrier.
+#ifndef YAT_GEMM_EARLY
+#define YAT_GEMM_EARLY 0
+#endif
+    constexpr int EARLY = YAT_GEMM_EARLY;
+    auto compute = [&](auto mode_c, int dma_tile, bool wait_dma) {
         constexpr int MODE = decltype(mode_c)::value;
         char* dst = smem + (dma_tile & 1) * G::STAGE;
         const bool checked = MODE == 2 && dma_tile >= 0 && is_tail(dma_tile);
@@ -271,6 +308,13 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (idx == 8 * NT - 1 - EARLY) {
+                    YAT_STAMP(st_slot);
+#ifndef YAT_ABL_NO_VMWAIT
+                    if (wait_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 (group 0's pieces)
+#endif
+                    YAT_LOOP_BARRIER();
+                }
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -280,7 +324,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // k-contiguous the load segment is short (12-13 ds_read_b128) and absorbs the issue for free, while DMA between
     // MFMAs costs 15-20 %; with a k-strided operand (twice the LDS read instructions + swizzle arithmetic) the load
     // segment is the long pole and the issue belongs in the compute segment (+12..20 %).
-    constexpr bool DIC = A_T || B_T;           // DMA In Compute segment
+    constexpr bool DIC = DIC_;                 // DMA In Compute segment
 
     issue(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,6 +366,9 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
+#ifdef YAT_GEMM_LOADPRIO
+            __builtin_amdgcn_s_setprio(YAT_GEMM_LOADPRIO);
+#endif
             if (!YAT_ABL_SKIP_READS || t == 0) {
                 const uint32_t st = lds0 + (t & 1) * G::STAGE;
                 if (A_T) {
@@ -348,25 +395,28 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #ifndef YAT_ABL_NO_VMWAIT
             if (kk == 1 && (!DIC || GRP == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
 #endif
+            YAT_STAMP(4 * kk + 0);
             YAT_LOOP_BARRIER();
+            YAT_STAMP(4 * kk + 1);
             // ---- COMPUTE segment: group 0 carries its DMA (tile t+1) in ks0, group 1 (tile t+2) in ks1
 #ifdef YAT_ABL_NO_DMA
-            compute(std::integral_constant<int, 0>{}, 0);
+            compute(std::integral_constant<int, 0>{}, 0, false);
 #else
+#ifdef YAT_GEMM_STAMPS
+            st_slot = 4 * kk + 2;
+#endif
             const int tile = t + 1 + GRP;
+            const bool wd = DIC && kk == 1 && GRP == 0;                               // group 0 waits for its pieces of tile t+1
             if constexpr (std::is_same<decltype(grp_c), RuntimeGroup>::value) {       // one MFMA block, per-piece decisions
-                compute(std::integral_constant<int, DIC ? 3 : 0>{}, kk == GRP && tile < nt ? tile : -1);
+                compute(std::integral_constant<int, DIC ? 3 : 0>{}, kk == GRP && tile < nt ? tile : -1, wd);
             } else if (DIC && kk == GRP) {
-                if (FAST) compute(std::integral_constant<int, 1>{}, tile);
-                else compute(std::integral_constant<int, 2>{}, tile < nt ? tile : -1);
+                if (FAST) compute(std::integral_constant<int, 1>{}, tile, wd);
+                else compute(std::integral_constant<int, 2>{}, tile < nt ? tile : -1, wd);
             } else {
-                compute(std::integral_constant<int, 0>{}, 0);
+                compute(std::integral_constant<int, 0>{}, 0, wd);
             }
 #endif
-#ifndef YAT_ABL_NO_VMWAIT
-            if (DIC && kk == 1 && GRP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 (group 0's pieces)
-#endif
-            YAT_LOOP_BARRIER();
+            YAT_STAMP(4 * kk + 3);
         }
     };
     auto k_loop = [&](auto grp_c) {
@@ -377,6 +427,10 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (; t < nfast; ++t) iteration(grp_c, std::true_type{}, t);
         for (; t < nt; ++t) iteration(grp_c, std::false_type{}, t);
     };
+#ifdef YAT_GEMM_STAMPS
+    st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+    const uint32_t st_loop_begin = st_prev;
+#endif
     if constexpr (TIGHT) {
         // the 256 x 320 tile with a k-strided A already sits at 253 registers: more than one loop body spills, so these
         // (two of the step's minor shapes) keep the general form with the group decided at run time
@@ -385,6 +439,15 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         if (grp == 0) k_loop(std::integral_constant<int, 0>{});
         else k_loop(std::integral_constant<int, 1>{});
     }
+#ifdef YAT_GEMM_STAMPS
+    const uint32_t st_loop_end = (uint32_t)__builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yat_gemm_stamp_buf[wave * 8 + i] = st_sum[i];
+        yat_gemm_stamp_buf[64] = (unsigned)nt;
+        if (wave == 0) { yat_gemm_stamp_buf[65] = st_loop_begin - st_kernel_begin; yat_gemm_stamp_buf[66] = st_loop_end - st_loop_begin; }
+    }
+#endif
     if (grp == 0) YAT_PHASE_BARRIER();         // pair group 1's last barrier
 
     // ---- epilogue.  The MFMA layout gives a lane 4 columns of 16 different rows (8-B accesses in 32-B runs).  When
@@ -436,6 +499,10 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next pass overwrites the slab
         }
+#ifdef YAT_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (blockIdx.x == 0 && lane == 0 && wave == 0) yat_gemm_stamp_buf[67] = (uint32_t)__builtin_amdgcn_s_memtime() - st_loop_end;
+#endif
         return;
     }
 #pragma unroll
@@ -593,3 +660,9 @@ int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStre
 #undef YAT_CASE
     return YAT_EINVAL;
 }
+
+#ifdef YAT_GEMM_STAMPS
+extern "C" int yat_debug_gemm_stamps(unsigned int* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(yat_gemm_stamp_buf), sizeof(unsigned int) * 72);
+}
+#endif
