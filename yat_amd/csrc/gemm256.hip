@@ -234,16 +234,18 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         }
     };
     constexpr int NPIECE = G::PA + G::PB;        // 8 or 9 pieces per wave per tile
-    constexpr bool TIGHT = false;                // (a kernel at the register limit can keep ONE loop body with checked pieces)
-    auto issue = [&](int tl, char* stage) {
-        if (TIGHT || is_tail(tl)) {
+    auto issue_range = [&](int tl, char* stage, int j0, int j1) {       // pieces [j0, j1) of tile tl, form chosen once
+        if (is_tail(tl)) {
 #pragma unroll
-            for (int j = 0; j < NPIECE; ++j) piece(std::true_type{}, tl, stage, j);
+            for (int j = 0; j < NPIECE; ++j)
+                if (j >= j0 && j < j1) piece(std::true_type{}, tl, stage, j);
         } else {
 #pragma unroll
-            for (int j = 0; j < NPIECE; ++j) piece(std::false_type{}, tl, stage, j);
+            for (int j = 0; j < NPIECE; ++j)
+                if (j >= j0 && j < j1) piece(std::false_type{}, tl, stage, j);
         }
     };
+    auto issue = [&](int tl, char* stage) { issue_range(tl, stage, 0, NPIECE); };
 
     f32x4 acc[8][NT];
 #pragma unroll
@@ -276,8 +278,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     constexpr int GAP = (8 * NT) / NPIECE >= 4 ? 4 : 3;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
     static_assert((8 * NT) / GAP >= NPIECE, "not enough MFMA slots for the DMA pieces of a tile");
     // MODE 0: no DMA in this segment; 1: scalar-offset pieces, unconditionally (two scalar instructions + the DMA each);
-    // 2: decided per piece at run time (tile missing / ragged last k-tile) -- only in the last iterations of a K loop;
-    // 3: per piece, tile missing or the checked form (the register-tight kernels' only loop body)
+    // 2: decided per piece at run time (tile missing / ragged last k-tile) -- only in the last iterations of a K loop
     // The rendezvous that ends the segment is executed EARLY MFMAs before its end: the partner group, parked at the end of
     // its LOAD segment, is released while this wave's last MFMAs are still in the pipe, so the barrier's turnaround overlaps
     // them instead of idling the matrix pipe.  Legal because a COMPUTE segment touches registers only (every LDS read
@@ -300,9 +301,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                 if (MODE != 0 && idx % GAP == GAP - 1 && idx / GAP < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (MODE == 1) piece(std::false_type{}, dma_tile, dst, idx / GAP);
-                    else if (MODE == 3) {
-                        if (dma_tile >= 0) piece(std::true_type{}, dma_tile, dst, idx / GAP);
-                    } else if (dma_tile >= 0) {
+                    else if (dma_tile >= 0) {
                         if (checked) piece(std::true_type{}, dma_tile, dst, idx / GAP);
                         else piece(std::false_type{}, dma_tile, dst, idx / GAP);
                     }
@@ -324,14 +323,18 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // k-contiguous the load segment is short (12-13 ds_read_b128) and absorbs the issue for free, while DMA between
     // MFMAs costs 15-20 %; with a k-strided operand (twice the LDS read instructions + swizzle arithmetic) the load
     // segment is the long pole and the issue belongs in the compute segment (+12..20 %).
-    constexpr bool DIC = DIC_;                 // DMA In Compute segment
+    constexpr bool DIC = DIC_;                 // DMA In Compute segment (group 0; group 1 too unless stated otherwise)
+#ifndef YAT_GEMM_NT_G1C
+#define YAT_GEMM_NT_G1C 0
+#endif
+    constexpr bool DIC_G1 = DIC || YAT_GEMM_NT_G1C;   // group 1 alone may prefetch tile t+2 from COMPUTE(t,ks1)
 
     issue(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
     if (grp == 1) {
         // (DIC) group 1 issues tile t+2 inside its COMPUTE(t, ks1), so its share of tile 1 goes out here
-        if (DIC && nt > 1) issue(1, smem + G::STAGE);
+        if (DIC_G1 && nt > 1) issue(1, smem + G::STAGE);
         YAT_PHASE_BARRIER();                   // stagger: group 1 runs one segment behind group 0
     }
 
@@ -347,25 +350,44 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // and as a FAST form -- the tile this iteration fetches exists and is a full one, so its pieces are unconditional,
     // scalar-offset DMAs with no branch and no VALU around them -- plus the general form for the last iterations.  Both
     // groups execute the same number of barriers per iteration in either form.
-    struct RuntimeGroup { int value; };
     auto iteration = [&](auto grp_c, auto fast_c, int t) {
-        const int GRP = grp_c.value;           // a constant, except in the kernels that keep ONE loop body (below)
+        constexpr int GRP = decltype(grp_c)::value;
+        constexpr bool dic = GRP == 0 ? DIC : DIC_G1;      // does THIS group issue its DMA from a compute segment?
         constexpr bool FAST = decltype(fast_c)::value;
         const char* cur = smem + (t & 1) * G::STAGE;
+        // (!DIC) pieces of tile t+1 issued at the top of LOAD(t,ks0); group 0 may keep the last NPIECE - H0 of them for the top
+        // of its LOAD(t,ks1) -- it then waits after COMPUTE(t,ks1) like a DIC kernel's group 0 (YAT_GEMM_NT_SPLIT)
+#ifndef YAT_GEMM_NT_SPLIT
+#define YAT_GEMM_NT_SPLIT 99
+#endif
+        const bool g0split = !dic && GRP == 0 && YAT_GEMM_NT_SPLIT < NPIECE;
+        const int H0 = g0split ? YAT_GEMM_NT_SPLIT : NPIECE;
+        char* nxt = smem + ((t + 1) & 1) * G::STAGE;
 #ifndef YAT_ABL_NO_DMA
-        if (!DIC) {
-            char* nxt = smem + ((t + 1) & 1) * G::STAGE;
+        if (!dic) {
             if (FAST) {
 #pragma unroll
-                for (int j = 0; j < NPIECE; ++j) piece(std::false_type{}, t + 1, nxt, j);
+                for (int j = 0; j < NPIECE; ++j)
+                    if (j < H0) piece(std::false_type{}, t + 1, nxt, j);
             } else if (t + 1 < nt) {
-                issue(t + 1, nxt);
+                issue_range(t + 1, nxt, 0, H0);
             }
         }
 #endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
+#ifndef YAT_ABL_NO_DMA
+            if (g0split && kk == 1) {
+                if (FAST) {
+#pragma unroll
+                    for (int j = 0; j < NPIECE; ++j)
+                        if (j >= H0) piece(std::false_type{}, t + 1, nxt, j);
+                } else if (t + 1 < nt) {
+                    issue_range(t + 1, nxt, H0, NPIECE);
+                }
+            }
+#endif
 #ifdef YAT_GEMM_LOADPRIO
             __builtin_amdgcn_s_setprio(YAT_GEMM_LOADPRIO);
 #endif
@@ -393,7 +415,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef YAT_ABL_NO_VMWAIT
-            if (kk == 1 && (!DIC || GRP == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
+            if (kk == 1 && ((!dic && !g0split) || GRP == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed
 #endif
             YAT_STAMP(4 * kk + 0);
             YAT_LOOP_BARRIER();
@@ -406,10 +428,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             st_slot = 4 * kk + 2;
 #endif
             const int tile = t + 1 + GRP;
-            const bool wd = DIC && kk == 1 && GRP == 0;                               // group 0 waits for its pieces of tile t+1
-            if constexpr (std::is_same<decltype(grp_c), RuntimeGroup>::value) {       // one MFMA block, per-piece decisions
-                compute(std::integral_constant<int, DIC ? 3 : 0>{}, kk == GRP && tile < nt ? tile : -1, wd);
-            } else if (DIC && kk == GRP) {
+            const bool wd = (dic || g0split) && kk == 1 && GRP == 0;                               // group 0 waits for its pieces of tile t+1
+            if (dic && kk == GRP) {
                 if (FAST) compute(std::integral_constant<int, 1>{}, tile, wd);
                 else compute(std::integral_constant<int, 2>{}, tile < nt ? tile : -1, wd);
             } else {
@@ -421,7 +441,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     };
     auto k_loop = [&](auto grp_c) {
         // iterations whose fetched tile (t+1; t+2 for group 1 of a DIC kernel) exists and is not the ragged last one
-        const int ahead = DIC ? 1 + grp_c.value : 1;
+        const int ahead = (grp_c.value == 0 ? DIC : DIC_G1) ? 1 + grp_c.value : 1;
         const int nfast = max(0, nt - ahead - (ragged && kt0 + nt == nt_all ? 1 : 0));
         int t = 0;
         for (; t < nfast; ++t) iteration(grp_c, std::true_type{}, t);
@@ -431,14 +451,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
     const uint32_t st_loop_begin = st_prev;
 #endif
-    if constexpr (TIGHT) {
-        // the 256 x 320 tile with a k-strided A already sits at 253 registers: more than one loop body spills, so these
-        // (two of the step's minor shapes) keep the general form with the group decided at run time
-        for (int t = 0; t < nt; ++t) iteration(RuntimeGroup{grp}, std::false_type{}, t);
-    } else {
-        if (grp == 0) k_loop(std::integral_constant<int, 0>{});
-        else k_loop(std::integral_constant<int, 1>{});
-    }
+    if (grp == 0) k_loop(std::integral_constant<int, 0>{});
+    else k_loop(std::integral_constant<int, 1>{});
 #ifdef YAT_GEMM_STAMPS
     const uint32_t st_loop_end = (uint32_t)__builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && lane == 0) {
