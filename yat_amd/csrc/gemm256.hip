@@ -275,7 +275,14 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #define YAT_GEMM_DIC_ALL 0          // 1: measured +4..6 % on the forward shapes alone, but the step got 2.4 ms SLOWER
 #endif
     constexpr bool DIC_ = A_T || B_T || YAT_GEMM_DIC_ALL;
-    constexpr int GAP = (8 * NT) / NPIECE >= 4 ? 4 : 3;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
+    // One piece every GAP MFMAs from the start of the segment.  A wave's memory instructions drain in order, so pieces issued
+    // near the END of a compute segment are still in the address pipeline when the following LOAD segment's fragment reads
+    // queue up behind them (stamps: that LOAD took 840..900 ticks against 410..490 for the wave's other one); with GAP 2 the
+    // pieces are out by mid-segment (the LOAD drops to 500..580, the carrying compute segment grows 760 -> 820).
+#ifndef YAT_GEMM_GAP
+#define YAT_GEMM_GAP 2
+#endif
+    constexpr int GAP = YAT_GEMM_GAP;      // 256 x 192 tile: 24 MFMAs carry 7 pieces -> one every 3
     static_assert((8 * NT) / GAP >= NPIECE, "not enough MFMA slots for the DMA pieces of a tile");
     // MODE 0: no DMA in this segment; 1: scalar-offset pieces, unconditionally (two scalar instructions + the DMA each);
     // 2: decided per piece at run time (tile missing / ragged last k-tile) -- only in the last iterations of a K loop
