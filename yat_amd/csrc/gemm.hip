@@ -168,7 +168,17 @@ double est_time_128(int M, int N, int K) {
 }
 double est_time_256(int M, int N, int K, int BNv, int ksplit) {
     const double tiles = (double)((M + 255) / 256) * ((N + BNv - 1) / BNv) * ksplit;
-    const double rounds = ceil(tiles / 256.0);
+    // A GEMM of the training step seldom has the chip to itself (weight gradients on the side stream beside the dgrad chain, two
+    // forward chains): the CUs its last round leaves idle are taken by its neighbour, so what a tile-shape / split-K choice
+    // costs the STEP is its CU-time (tiles x time per tile), not whole rounds -- as long as the kernel still spreads over
+    // enough CUs not to become the side stream's critical path (a 25-tile, K = 32768 weight gradient left unsplit is cheap in
+    // CU-time and 0.75 ms long).  rounds = max(tiles / 256, floor): a launch is charged at least `floor` of the chip, which
+    // makes the model split K until ~96 workgroups exist and no further.  Measured in the step, one box, all benches
+    // (scripts/gpu_policy_sweep.sh): whole rounds (w = 1) -> this: SANA 88.3 -> 86.0 ms, PixArt 235.2 -> 231.7, LoKr B=32
+    // 353.9 -> 352.1; floor 0.25 loses PixArt (260), no floor loses LoKr (431) and PixArt (315).
+    static const double round_w = getenv("YAT_GEMM_ROUND_W") ? atof(getenv("YAT_GEMM_ROUND_W")) : 0.0;
+    static const double round_floor = getenv("YAT_GEMM_ROUND_FLOOR") ? atof(getenv("YAT_GEMM_ROUND_FLOOR")) : 0.375;
+    const double rounds = round_w * ceil(tiles / 256.0) + (1.0 - round_w) * fmax(tiles / 256.0, round_floor);
     double t = rounds * ((2.0 * 256 * BNv * (double)K / ksplit) / 5.0e12 + 8e-6);   // + per-workgroup fixed cost
     if (ksplit > 1) t += (ksplit + 0.5) * (double)M * N * 4.0 / 4.0e12 + 3e-6;      // slab write + reduce pass
     return t;
