@@ -65,6 +65,13 @@ typedef struct yat_gemm_epilogue {
 
 uint64_t yat_gemm_epilogue_size(void);   /* sizeof(yat_gemm_epilogue) in this build of the library */
 
+/* Host hint for the tile-shape / split-K policy of the entry points below (variant 0): how many independent streams of
+ * GEMMs the caller keeps in flight (1 = each GEMM has the chip to itself, the default; the training step declares 2: two
+ * forward chains, dgrad beside wgrad).  With more than one, a launch is charged its CU-time (but at least 3/8 of the
+ * chip) instead of whole rounds, so it is not split or narrowed to fill a round its neighbour would have filled.  Process-wide, read at launch time; 1..8.  No reference counterpart (torch
+ * picks its GEMM algorithms per call, unaware of the caller's streams).                                                      */
+int yat_gemm_set_concurrency(int streams);
+
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
  * b_t=0: B is [N,K] (k contiguous, nn.Linear weight layout); b_t=1: B is [K,N].
  * (0,0) forward y = x W^T; (0,1) dgrad dx = dy W; (1,1) wgrad dW = dy^T x; (1,0) x^T W^T.

@@ -166,19 +166,31 @@ double est_time_128(int M, int N, int K) {
     const double rounds = ceil(tiles / 512.0);
     return rounds * 2.0 * (2.0 * 128 * 128 * (double)K) / 3.4e12;
 }
+int g_gemm_streams = 1;      // host hint: independent GEMM streams sharing the chip
+
 double est_time_256(int M, int N, int K, int BNv, int ksplit) {
     const double tiles = (double)((M + 255) / 256) * ((N + BNv - 1) / BNv) * ksplit;
     // A GEMM of the training step seldom has the chip to itself (weight gradients on the side stream beside the dgrad chain, two
-    // forward chains): the CUs its last round leaves idle are taken by its neighbour, so what a tile-shape / split-K choice
-    // costs the STEP is its CU-time (tiles x time per tile), not whole rounds -- as long as the kernel still spreads over
-    // enough CUs not to become the side stream's critical path (a 25-tile, K = 32768 weight gradient left unsplit is cheap in
-    // CU-time and 0.75 ms long).  rounds = max(tiles / 256, floor): a launch is charged at least `floor` of the chip, which
-    // makes the model split K until ~96 workgroups exist and no further.  Measured in the step, one box, all benches
-    // (scripts/gpu_policy_sweep.sh): whole rounds (w = 1) -> this: SANA 88.3 -> 86.0 ms, PixArt 235.2 -> 231.7, LoKr B=32
-    // 353.9 -> 352.1; floor 0.25 loses PixArt (260), no floor loses LoKr (431) and PixArt (315).
-    static const double round_w = getenv("YAT_GEMM_ROUND_W") ? atof(getenv("YAT_GEMM_ROUND_W")) : 0.0;
-    static const double round_floor = getenv("YAT_GEMM_ROUND_FLOOR") ? atof(getenv("YAT_GEMM_ROUND_FLOOR")) : 0.375;
-    const double rounds = round_w * ceil(tiles / 256.0) + (1.0 - round_w) * fmax(tiles / 256.0, round_floor);
+    // forward chains), and a whole-round model then picks wrongly: it splits K (slab traffic + a reduce kernel) or takes the
+    // narrower tile to fill a last round that the neighbouring stream would have filled anyway.  The host says how many
+    // independent GEMM streams it keeps in flight (yat_gemm_set_concurrency).  One: whole rounds, the choice that is fastest
+    // for the launch alone.  More: the launch is charged its CU-time (tiles / 256 rounds) but at least 0.375 of the chip, so K
+    // is still split until ~96 workgroups exist (a 25-tile K = 32768 weight gradient left unsplit is cheap in CU-time and
+    // 0.75 ms long: the side stream becomes the critical path).  Measured in the step on one box, every bench
+    // (scripts/gpu_policy_sweep.sh): whole rounds -> this: SANA 88.3 -> 86.0 ms, PixArt 235 -> 232, LoKr B=32 354 -> 352;
+    // floor 0.25 loses PixArt (260), no floor loses LoKr (431) and PixArt (315); planning for a 128-CU share with whole
+    // rounds of THAT (the obvious model) keeps half the gain (87.4).  YAT_GEMM_ROUND_W / _FLOOR: the sweep's knobs.
+    static const char* rw_env = getenv("YAT_GEMM_ROUND_W");
+    double rounds;
+    if (rw_env) {
+        static const double round_w = atof(rw_env);
+        static const double round_floor = getenv("YAT_GEMM_ROUND_FLOOR") ? atof(getenv("YAT_GEMM_ROUND_FLOOR")) : 0.375;
+        rounds = round_w * ceil(tiles / 256.0) + (1.0 - round_w) * fmax(tiles / 256.0, round_floor);
+    } else if (g_gemm_streams <= 1) {
+        rounds = ceil(tiles / 256.0);                        // alone on the chip: whole rounds
+    } else {
+        rounds = fmax(tiles / 256.0, 0.375);                 // sharing it: CU-time, but spread over >= 96 CUs
+    }
     double t = rounds * ((2.0 * 256 * BNv * (double)K / ksplit) / 5.0e12 + 8e-6);   // + per-workgroup fixed cost
     if (ksplit > 1) t += (ksplit + 0.5) * (double)M * N * 4.0 / 4.0e12 + 3e-6;      // slab write + reduce pass
     return t;
@@ -232,6 +244,13 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
 }
 
 extern "C" uint64_t yat_gemm_epilogue_size(void) { return sizeof(yat_gemm_epilogue); }
+
+extern "C" int yat_gemm_set_concurrency(int streams) {
+    static const int forced = getenv("YAT_GEMM_CONCURRENCY") ? atoi(getenv("YAT_GEMM_CONCURRENCY")) : 0;
+    if (streams < 1 || streams > 8) return YAT_EINVAL;
+    g_gemm_streams = forced >= 1 && forced <= 8 ? forced : streams;
+    return YAT_OK;
+}
 
 int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs, hipStream_t stream);
 

@@ -91,6 +91,11 @@ def _chk_bf16(*ts):
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
+def gemm_concurrency(streams: int):
+    """yat_gemm_set_concurrency: how many independent GEMM streams the caller keeps in flight (recorded in launch plans)."""
+    _l.check(_lib().yat_gemm_set_concurrency(int(streams)), "yat_gemm_set_concurrency")
+
+
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
          activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
          glu_u=None, pre_add=None, dact_z=None):

@@ -340,6 +340,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             ops.patch_rearrange(out_tok[rs], pred[bs], nb, cfg.out_channels, Hl, Wl, p, False, False)
 
         nchain = 1 if ad is not None else max(1, min(self.fwd_chains, B))
+        ops.gemm_concurrency(nchain)              # the GEMM policy plans each launch for its share of the chip
         if nchain == 1:
             run_chain(0, B, main)
         else:
@@ -366,6 +367,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         S = self._saved
         if S is None:
             raise RuntimeError("backward_impl called without a saved forward")
+        ops.gemm_concurrency(2 if self.side_wgrad else 1)     # dgrad chain beside the weight gradients' stream
         cfg, P, G = self.cfg, self.P, self.G
         D, H, dh, p = cfg.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim, cfg.patch_size
         B, N, M, T, Mt = S.B, S.N, S.M, S.T, S.Mt

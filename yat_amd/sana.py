@@ -381,6 +381,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
         # (with adapters: one chain, so that the T1 product of every target covers the whole batch and the backward reuses it)
         nchain = 1 if ad is not None else max(1, min(self.fwd_chains, B))
+        ops.gemm_concurrency(nchain)              # the GEMM policy plans each launch for its share of the chip
         if nchain == 1:
             run_chain(0, B, main)
         else:
@@ -404,6 +405,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         S = self._saved
         if S is None:
             raise RuntimeError("backward_impl called without a saved forward")
+        ops.gemm_concurrency(2 if self.side_wgrad else 1)     # dgrad chain beside the weight gradients' stream
         cfg, P, G = self.cfg, self.P, self.G
         D, Hc, H1, H2, dh2 = cfg.inner_dim, cfg.ffn_hidden, cfg.num_attention_heads, cfg.num_cross_attention_heads, \
             cfg.cross_attention_head_dim

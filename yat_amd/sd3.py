@@ -208,6 +208,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
     # ------------------------------------------------------------------ forward
     def forward_impl(self, latents, enc, pooled, timestep):
         cfg, P = self.cfg, self.P
+        ops.gemm_concurrency(1)                   # one forward chain (the side stream only carries the small modulation linears)
         ad = self.adapters
         if ad is not None:
             ad.materialize(self.training)                     # yat_amd/lora.py / lokr.py / loha.py: this step's adapter state
@@ -423,6 +424,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         S = self._saved
         if S is None:
             raise RuntimeError("backward_impl called without a saved forward")
+        ops.gemm_concurrency(2 if self.side_wgrad else 1)     # dgrad chain beside the weight gradients' stream
         cfg, P, G = self.cfg, self.P, self.G
         D, H, dh, p = cfg.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim, cfg.patch_size
         B, N, M, T, Mt, L = S.B, S.N, S.M, S.T, S.Mt, S.L
