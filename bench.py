@@ -450,10 +450,11 @@ def main():
             # (algorithmic 2 B/param read for the norm + 14 B/param for the update; PMC: profiles/r01_g_pmc_per_kernel.txt
             # shows exactly 12.8 GB fetched + 9.6 GB written by adamw_kernel per step)
             oms = sum(a.elapsed_time(b_) for a, b_ in opt_timer) / max(1, len(opt_timer))
-            obytes = 16.0 * model.numel_flat
+            nopt = trained.numel_flat                 # what the optimizer walks: the model, or only the adapters' flat buffer
+            obytes = 16.0 * nopt
             res["roofline_hbm"] = {"bound": "hbm", "kernel": "gradnorm_partial_kernel + adamw_kernel (clip + AdamW step)",
                                    "achieved": obytes / (oms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                   "frac": obytes / (oms * 1e-3) / 1e9 / 8000.0, "traffic": 14.0 * model.numel_flat + 2.0 * model.numel_flat,
+                                   "frac": obytes / (oms * 1e-3) / 1e9 / 8000.0, "traffic": 16.0 * nopt,
                                    "ms": oms, "mode": "serialized-stream pass"}
         if timer and args.gemm_detail:
             agg = {}
