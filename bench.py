@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the serialized GEMM-timing pass")
+    ap.add_argument("--phases", default=None, metavar="FILE",
+                    help="after the timed region, time the phases of 6 steps with HIP events and write them to FILE")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -383,6 +385,48 @@ def main():
     barrier()
     log(f"host enqueue of one step onto an idle GPU: {min(host_ms):.1f} ms (per bucket: {', '.join(f'{v:.1f}' for v in host_ms)}; "
         f"launch plans {'on' if model.use_plans else 'off'})")
+
+    # ---- optional phase probe (after the timed region; nothing of it runs otherwise): GPU timestamps of the step's phases
+    # from a handful of HIP events per step -- unlike a profiler's kernel trace it does not slow the host's enqueue, so the
+    # streams overlap as they do in the timed region.
+    if args.phases and rank == 0:
+        side, opt_stream = model._side_stream(), None
+        rows = []
+        barrier()
+        for i in range(6):
+            ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "fwd", "bwd_main", "side", "norm", "opt")}
+            b = batches[(args.warmup + args.steps + i) % len(batches)]
+            main = torch.cuda.current_stream()
+            ev["start"].record(main)
+            ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)
+            noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)
+            _, t_host, sig_host = recipe.scheduler.sample(B, ts_gen)
+            t_dev.copy_(t_host, non_blocking=True)
+            sig_dev.copy_(sig_host, non_blocking=True)
+            noisy, target = ops.flow_mix(b["lat"], noise, sig_dev, recipe._noisy(b["lat"]), recipe._target(b["lat"]))
+            pred = model.forward_device(noisy, enc, t_dev, bias, kvl, kv_work=b["work"])
+            ev["fwd"].record(main)
+            dpred = recipe._dpred(pred)
+            ops.mse_fwd_bwd(pred, target, loss_dev, dpred, recipe._mse_ws)
+            model.backward_device(dpred)
+            ev["bwd_main"].record(main)        # main stream after the backward (includes its join with the side stream)
+            ev["side"].record(side)            # side stream: the last weight gradient
+            opt.step()
+            ev["norm"].record(main)            # gradient norm + clip coefficient (main stream)
+            ev["opt"].record(opt._stream if opt._stream is not None else main)
+            rows.append(ev)
+        barrier()
+        with open(args.phases, "w") as f:
+            f.write("# ms after the step's first launch (HIP events; B=%d, buckets round-robin)\n" % B)
+            f.write("# step  forward_done  backward_done(main,joined)  side_stream_done  gradnorm_done  adamw_done  next_step_start\n")
+            for i, ev in enumerate(rows):
+                nxt = rows[i + 1]["start"] if i + 1 < len(rows) else None
+                f.write("%5d %13.2f %27.2f %17.2f %14.2f %11.2f %16s\n" % (
+                    i, ev["start"].elapsed_time(ev["fwd"]), ev["start"].elapsed_time(ev["bwd_main"]),
+                    ev["start"].elapsed_time(ev["side"]), ev["start"].elapsed_time(ev["norm"]),
+                    ev["start"].elapsed_time(ev["opt"]),
+                    "%.2f" % ev["start"].elapsed_time(nxt) if nxt is not None else "-"))
+        log(f"phase probe written to {args.phases}")
 
     # ---- roofline pass (after the timed region): per-launch GEMM durations by HIP events on the launch stream.
     # The step overlaps independent GEMMs on two streams, so in the timed region two kernels share the CUs and

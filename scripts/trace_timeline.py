@@ -49,3 +49,19 @@ for r in win:
 print("non-GEMM kernels, summed durations (overlapped run):")
 for k, v in non.most_common(12):
     print(f"  {v:7.2f} ms  {k}")
+
+# gaps on the busiest queue: where does the critical stream wait?
+q = max(set(r[2] for r in win), key=lambda q_: sum(r[1] - r[0] for r in win if r[2] == q_))
+seq = sorted([r for r in win if r[2] == q])
+gaps = [(seq[i + 1][0] - seq[i][1], seq[i][3][:50], seq[i + 1][3][:50]) for i in range(len(seq) - 1)]
+tot = sum(g[0] for g in gaps if g[0] > 0) / 1e6
+print(f"queue {q}: {len(seq)} kernels, gaps between consecutive kernels total {tot:.2f} ms; "
+      f"{sum(1 for g in gaps if g[0] > 20000)} gaps > 20 us = {sum(g[0] for g in gaps if g[0] > 20000) / 1e6:.2f} ms; "
+      f"median gap {sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3:.1f} us")
+agg = collections.Counter()
+for g, a, b in gaps:
+    if g > 20000:
+        agg[(a, b)] += g / 1e6
+print("largest waits (after -> before), summed over the step:")
+for (a, b), v in agg.most_common(12):
+    print(f"  {v:6.2f} ms  {a}  ->  {b}")
