@@ -315,6 +315,18 @@ int yat_hadamard_scale(int rows, int cols, const void* a, int lda, const void* b
 int yat_hadamard_bwd(int rows, int cols, const void* dd, int ldd, const void* a1, int ld1, const void* a2, int ld2, float scale,
                      void* t1, int ldt1, void* t2, int ldt2, yat_stream_t stream);
 
+/* DoRA (LoraConfig(..., use_dora=params.lora_use_dora), common/trainer.py:215-220) [RECALL peft/tuners/lora/dora.py]:
+ * with lw = lora_B lora_A (an ordinary yat_gemm_bf16 call), u = bf16(W + bf16(scaling*lw)), n_j = bf16(||u_j||) (detached) and
+ * s_j = bf16(mag_j / n_j), peft's result = base(x) + (s-1)(x W^T) + s*scaling*lora(x) equals base(x) + x delta^T with
+ *   yat_dora_delta: delta_j = bf16(s_j (W_j + scaling lw_j) - W_j); s_buf / n_buf (fp32 [rows]) keep s and n for the backward;
+ *   yat_dora_bwd:   from dd = d_delta (the dense weight gradient dy^T x): dmag_j = bf16((sum_l dd[j,l] u[j,l]) / n_j) and
+ *                   t1 = bf16(bf16(s_j*scaling) * dd) -- d_lora_B = t1 lora_A^T and d_lora_A = lora_B^T t1 are GEMMs again.
+ * rows x cols views (cols % 8 == 0), row strides in elements. */
+int yat_dora_delta(int rows, int cols, const void* W, int ldw, const void* lw, int ldl, const void* mag, float scaling,
+                   void* delta, int ldd, float* s_buf, float* n_buf, yat_stream_t stream);
+int yat_dora_bwd(int rows, int cols, const void* dd, int ldd, const void* W, int ldw, const void* lw, int ldl, float scaling,
+                 const float* s_buf, const float* n_buf, void* t1, int ldt, void* dmag, yat_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * MMDiT glue (SD3.5-Medium, BASELINE config 4: the reference trains diffusers' SD3Transformer2DModel,
  * train_sd35.py:4,188-191; JointTransformerBlock / JointAttnProcessor2_0 [RECALL], restated in oracle/sd3_ref.py).

@@ -109,7 +109,7 @@ def test_overfits_a_fixed_batch():
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
 
 
-@pytest.mark.parametrize("algo", ["lokr", "lora", "loha"])
+@pytest.mark.parametrize("algo", ["lokr", "lora", "loha", "dora"])
 def test_trainer_lokr_config(tmp_path, monkeypatch, algo):
     """BASELINE config 5 plumbing end to end on a tiny model: lora_* YAML keys -> LoKr (or plain LoRA) adapters on the README
     target modules, frozen base, AdamW over the adapter set only, peft-layout adapter checkpoint."""
@@ -127,7 +127,8 @@ def test_trainer_lokr_config(tmp_path, monkeypatch, algo):
     yaml_path.write_text("\n".join([
         "urls:", "  - unused", "local_shard_paths:", *[f"  - {p}" for p in paths], "num_shards: 2", "dataset_seed: 7",
         "batch_size: 4", "learning_rate: 1e-3", "steps: 4", "num_steps_per_validation: 2", "validation_prompts:", "  - x",
-        "bfloat16: true", "lora_rank: 2", "lora_alpha: 2", f"lora_algo: {algo}", *(["lora_dropout: 0.05"] if algo in ("lokr", "loha") else []),
+        "bfloat16: true", "lora_rank: 2", "lora_alpha: 2", f"lora_algo: {'lora' if algo == 'dora' else algo}", *(["lora_use_dora: true"] if algo == "dora" else []),
+        *(["lora_dropout: 0.05"] if algo in ("lokr", "loha") else []),
         "lora_target_modules:", *[f"  - {t}" for t in targets], "aspect_ratio: 1024", ""]))
     monkeypatch.chdir(tmp_path)
     params = TrainingParameters()
@@ -153,6 +154,13 @@ def test_trainer_lokr_config(tmp_path, monkeypatch, algo):
     assert type(resumed.adapters) is type(trainer.adapters)
     for k, v in resumed.adapters.state_dict().items():
         assert torch.equal(v.cpu(), sd[k]), k
+    if algo == "dora":         # lora_use_dora is true when the key is present (common/training_parameters_reader.py:142,192)
+        from yat_amd.dora import DoRAAdapters
+        assert isinstance(trainer.adapters, DoRAAdapters) and conf["peft_type"] == "LORA" and conf["use_dora"] is True
+        assert len(sd) == 3 * len(trainer.adapters.entries)
+        assert sd["base_model.model.transformer_blocks.1.attn2.to_out.0.lora_magnitude_vector.weight"].shape == (128,)
+        assert any(v.abs().max() > 0 for k, v in sd.items() if k.endswith("lora_B.weight")), "lora_B never left its zero init"
+        return
     if algo == "lora":
         assert conf["peft_type"] == "LORA" and len(sd) == 2 * len(trainer.adapters.entries)
         assert sd["base_model.model.transformer_blocks.1.attn2.to_out.0.lora_B.weight"].shape == (128, 2)

@@ -246,6 +246,7 @@ class Model:
             algo = getattr(p, "lora_algo", "lora")
             targets, rank, alpha = p.lora_target_modules, p.lora_rank, p.lora_alpha
             drop, rslora, saved = getattr(p, "lora_dropout", 0.0) or 0.0, bool(getattr(p, "lora_use_rslora", False)), None
+            dora_saved = False
             if getattr(p, "lora_pretrained", None):
                 # :236 PeftModel.from_pretrained(model, path, is_trainable=True): the saved adapter's own config decides
                 import json
@@ -259,12 +260,14 @@ class Model:
                 alpha = conf["lora_alpha"] if algo == "lora" else conf["alpha"]
                 drop = conf.get("lora_dropout" if algo == "lora" else "module_dropout", 0.0) or 0.0
                 rslora = bool(conf.get("use_rslora", False))
+                dora_saved = bool(conf.get("use_dora", False))
                 saved = load_file(os.path.join(p.lora_pretrained, "adapter_model.safetensors"))
             if algo not in ("lokr", "lora", "loha"):
-                raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 --, lora and loha are)")
-            if algo == "lora":                                        # :214-219
-                if getattr(p, "lora_use_dora", False):
-                    raise NotImplementedError("DoRA is not built")
+                raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 --, lora (+ DoRA) and loha are)")
+            if algo == "lora" and (getattr(p, "lora_use_dora", False) or dora_saved):      # :214-219 with use_dora=True
+                from ..dora import DoRAAdapters
+                self.adapters = DoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora)
+            elif algo == "lora":                                      # :214-219
                 from ..lora import LoRAAdapters
                 self.adapters = LoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora,
                                              seed=int(getattr(p, "dataset_seed", 0) or 0))

@@ -328,6 +328,64 @@ __global__ __launch_bounds__(256) void hadamard_kernel(int rows, int cols, const
     }
 }
 
+// DoRA (peft LoraConfig(use_dora=True), common/trainer.py:215-220) [RECALL peft/tuners/lora/dora.py DoraLinearLayer]: with
+// lw = lora_B lora_A (bf16), u = bf16(W + bf16(scaling * lw)), n_j = bf16(||u_j||_2) (detached), s_j = bf16(m_j / n_j):
+//   result = base(x) + (s - 1) (x W^T) + s scaling lora(x)  =  base(x) + x delta^T  with  delta_j = s_j (W_j + scaling lw_j) - W_j.
+// One workgroup per output row: pass 1 the norm, pass 2 the delta row (the row is re-read from L2).
+// MODE 0: delta + (s, n) out.  MODE 1 (backward): dm_j = (sum_l dd[j,l] u[j,l]) / n_j and t1 = bf16(s_j * scaling * dd).
+template <int MODE>
+__global__ __launch_bounds__(256) void dora_kernel(int cols, const bf16_t* W, int ldw, const bf16_t* lw, int ldl,
+                                                   const bf16_t* mag, float scaling, bf16_t* out, int ldo, float* s_buf,
+                                                   float* n_buf, const bf16_t* dd, int ldd, bf16_t* dmag) {
+    __shared__ float red[4];
+    const int j = blockIdx.x, cpr = cols >> 3;
+    const bf16_t* wr = W + (int64_t)j * ldw;
+    const bf16_t* lr = lw + (int64_t)j * ldl;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < cpr; c += 256) {
+        float wv[8], lv[8], dv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(wr + c * 8), wv);
+        unpack8(*reinterpret_cast<const u32x4*>(lr + c * 8), lv);
+        if (MODE == 1) unpack8(*reinterpret_cast<const u32x4*>(dd + (int64_t)j * ldd + c * 8), dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = rbf(wv[e] + rbf(scaling * lv[e]));
+            acc += MODE == 0 ? u * u : dv[e] * u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    float s, n;
+    if (MODE == 0) {
+        n = rbf(sqrtf(tot));
+        s = rbf(bf2f(mag[j]) / n);
+        if (threadIdx.x == 0) { s_buf[j] = s; n_buf[j] = n; }
+    } else {
+        s = s_buf[j];
+        n = n_buf[j];
+        if (threadIdx.x == 0) dmag[j] = f2bf(tot / n);
+    }
+    for (int c = threadIdx.x; c < cpr; c += 256) {
+        float a[8];
+        if (MODE == 0) {
+            float wv[8], lv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(wr + c * 8), wv);
+            unpack8(*reinterpret_cast<const u32x4*>(lr + c * 8), lv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = s * (wv[e] + scaling * lv[e]) - wv[e];
+        } else {
+            float dv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dd + (int64_t)j * ldd + c * 8), dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = rbf(rbf(s * scaling) * dv[e]);
+        }
+        *reinterpret_cast<u32x4*>(out + (int64_t)j * ldo + c * 8) = pack8(a);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -464,6 +522,32 @@ int yat_hadamard_bwd(int rows, int cols, const void* dd, int ldd, const void* a1
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(hadamard_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rows, cols, (const bf16_t*)dd,
                        ldd, (const bf16_t*)a1, ld1, (const bf16_t*)a2, ld2, scale, (bf16_t*)t1, ldt1, (bf16_t*)t2, ldt2);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+// DoRA: see dora_kernel above.  W, lw (= lora_B lora_A), delta / t1 are rows x cols bf16 views (cols % 8 == 0) with row strides
+// in elements; mag / dmag bf16 [rows]; s_buf / n_buf fp32 [rows] written by yat_dora_delta and read by yat_dora_bwd.
+int yat_dora_delta(int rows, int cols, const void* W, int ldw, const void* lw, int ldl, const void* mag, float scaling,
+                   void* delta, int ldd, float* s_buf, float* n_buf, yat_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || (cols & 7) || ((ldw | ldl | ldd) & 7) || ldw < cols || ldl < cols || ldd < cols || !W || !lw ||
+        !mag || !delta || !s_buf || !n_buf)
+        return YAT_EINVAL;
+    hipLaunchKernelGGL(dora_kernel<0>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, cols, (const bf16_t*)W, ldw,
+                       (const bf16_t*)lw, ldl, (const bf16_t*)mag, scaling, (bf16_t*)delta, ldd, s_buf, n_buf,
+                       (const bf16_t*)nullptr, 0, (bf16_t*)nullptr);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_dora_bwd(int rows, int cols, const void* dd, int ldd, const void* W, int ldw, const void* lw, int ldl, float scaling,
+                 const float* s_buf, const float* n_buf, void* t1, int ldt, void* dmag, yat_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || (cols & 7) || ((ldw | ldl | ldd | ldt) & 7) || ldw < cols || ldl < cols || ldd < cols ||
+        ldt < cols || !W || !lw || !dd || !t1 || !dmag || !s_buf || !n_buf)
+        return YAT_EINVAL;
+    hipLaunchKernelGGL(dora_kernel<1>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, cols, (const bf16_t*)W, ldw,
+                       (const bf16_t*)lw, ldl, (const bf16_t*)nullptr, scaling, (bf16_t*)t1, ldt, (float*)s_buf, (float*)n_buf,
+                       (const bf16_t*)dd, ldd, (bf16_t*)dmag);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

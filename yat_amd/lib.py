@@ -93,6 +93,8 @@ SIGNATURES = {
     "yat_mse_bf16_chunk": (I, [I, I64, I64, P, P, F, P, P, P, P]),
     "yat_hadamard_scale": (I, [I, I, P, I, P, I, F, P, I, P]),
     "yat_hadamard_bwd": (I, [I, I, P, I, P, I, P, I, F, P, I, P, I, P]),
+    "yat_dora_delta": (I, [I, I, P, I, P, I, P, F, P, I, P, P, P]),
+    "yat_dora_bwd": (I, [I, I, P, I, P, I, P, I, F, P, P, P, I, P, P]),
     "yat_qknorm_concat_fwd": (I, [I, I, I, I, I, F, P, I, P, I, P, P, P, P, P, I, P, P]),
     "yat_qknorm_concat_bwd_workspace_bytes": (U64, [I, I, I, I]),
     "yat_qknorm_concat_bwd": (I, [I, I, I, I, I, P, I, P, I, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, I, P, P]),

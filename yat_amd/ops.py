@@ -235,6 +235,24 @@ def hadamard_bwd(dd2d, a1, a2, scale, t1, t2):
     _l.check(rc, "yat_hadamard_bwd")
 
 
+def dora_delta(w, lw, mag, scaling, delta, s_buf, n_buf):
+    """delta_j = s_j (W_j + scaling lw_j) - W_j with s_j = mag_j / ||W_j + scaling lw_j|| (yat_dora_delta); s, n -> fp32 buffers."""
+    _chk_bf16(w, lw, mag, delta)
+    rows, cols = w.shape
+    rc = _lib().yat_dora_delta(rows, cols, _p(w), w.stride(0), _p(lw), lw.stride(0), _p(mag), float(scaling), _p(delta),
+                               delta.stride(0), _p(s_buf), _p(n_buf), _stream())
+    _l.check(rc, "yat_dora_delta")
+
+
+def dora_bwd(dd, w, lw, scaling, s_buf, n_buf, t1, dmag):
+    """dmag_j = (sum_l dd[j,l] u[j,l]) / n_j; t1 = bf16(bf16(s_j scaling) * dd) (yat_dora_bwd)."""
+    _chk_bf16(dd, w, lw, t1, dmag)
+    rows, cols = w.shape
+    rc = _lib().yat_dora_bwd(rows, cols, _p(dd), dd.stride(0), _p(w), w.stride(0), _p(lw), lw.stride(0), float(scaling),
+                             _p(s_buf), _p(n_buf), _p(t1), t1.stride(0), _p(dmag), _stream())
+    _l.check(rc, "yat_dora_bwd")
+
+
 def lokr_rows_fwd(x2d, wb, t1):
     """t1[rows, R] = x2d[rows, N] wb^T (wb [R, N]) -- the T1 product of the factored LoKr path."""
     _chk_bf16(x2d, wb, t1)
