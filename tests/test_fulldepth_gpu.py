@@ -42,20 +42,21 @@ def full_models():
     return hip, ref_bf
 
 
-@pytest.mark.parametrize("h,w,lens", [(32, 32, (300, 41)), (24, 42, (17, 233))])
+@pytest.mark.parametrize("h,w,lens", [(32, 32, (300, 41)), (24, 42, (233,))])      # (the second bucket with one image: host time)
 def test_full_depth_step_matches_oracle(full_models, h, w, lens):
     from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
     from yat_amd.recipe import SanaRecipe
     hip, ref_bf = full_models
     cfg = ref_bf.cfg
     g = torch.Generator().manual_seed(1000 + h)
-    latents = (torch.randn(2, cfg.in_channels, h, w, generator=g) * 0.5).to(BF)
+    nb = len(lens)
+    latents = (torch.randn(nb, cfg.in_channels, h, w, generator=g) * 0.5).to(BF)
     embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in lens]
     tap_blocks = (0, 4, 9, 19)
 
     recipe = SanaRecipe(hip, pad_to=512, device=DEV)
     loss, pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
-    taps_h = {i: hip._saved.blocks[i].x3.detach().clone().view(2, h * w, -1) for i in tap_blocks}
+    taps_h = {i: hip._saved.blocks[i].x3.detach().clone().view(nb, h * w, -1) for i in tap_blocks}
     loss.backward()
     torch.cuda.synchronize()
     grads_h = hip.flat_grad.detach().float().cpu()
