@@ -26,7 +26,7 @@ for name, lay, m, n, k in SHAPES:
     b = (torch.randn((k, n) if b_t else (n, k), device=dev) * 0.05).to(BF)
     out = torch.empty(m, n, dtype=BF, device=dev)
     ref = None
-    VARS = (1, 4, 5, 204, 205, 405, 0)
+    VARS = (1, 4, 5, 6, 204, 205, 405, 0)
     times = {v: [] for v in VARS}
     for r in range(rounds + 1):
         for v in VARS:
@@ -68,7 +68,7 @@ for name, lay, m, n, k in SHAPES:
     lib_tf = fl / (sorted(lib_t)[len(lib_t) // 2] * 1e-3) / 1e12
     line = {v: (fl / (sorted(t)[len(t) // 2] * 1e-3) / 1e12 if t else 0.0) for v, t in times.items()}
     res[name] = line
-    print(f"{name:12s} {lay} {m:6d}x{n:6d}x{k:6d}  v128={line[1]:7.1f}  v256={line[4]:7.1f}  v320={line[5]:7.1f}  "
+    print(f"{name:12s} {lay} {m:6d}x{n:6d}x{k:6d}  v128={line[1]:7.1f}  v256={line[4]:7.1f}  v320={line[5]:7.1f}  1w256={line[6]:7.1f}  "
           f"2x256={line[204]:7.1f}  2x320={line[205]:7.1f}  4x320={line[405]:7.1f}  auto={line[0]:7.1f} TF   "
           f"[vendor lib yardstick {lib_tf:7.1f}]", flush=True)
 tot_fl = {v: 0.0 for v in (1, 4, 5, 0)}
