@@ -292,10 +292,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #define YAT_GEMM_DIC_ALL 0          // 1: measured +4..6 % on the forward shapes alone, but the step got 2.4 ms SLOWER
 #endif
     constexpr bool DIC_ = A_T || B_T || YAT_GEMM_DIC_ALL;
-    // One piece every GAP MFMAs from the start of the segment.  A wave's memory instructions drain in order, so pieces issued
-    // near the END of a compute segment are still in the address pipeline when the following LOAD segment's fragment reads
-    // queue up behind them (stamps: that LOAD took 840..900 ticks against 410..490 for the wave's other one); with GAP 2 the
-    // pieces are out by mid-segment (the LOAD drops to 500..580, the carrying compute segment grows 760 -> 820).
+    // One piece every GAP MFMAs from the start of the segment (2 or 4: no measurable difference once the transposing reads
+    // stopped waiting for the DMA, see frag_tr).
 #ifndef YAT_GEMM_GAP
 #define YAT_GEMM_GAP 2
 #endif
@@ -387,17 +385,25 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         const bool g0split = !dic && GRP == 0 && YAT_GEMM_NT_SPLIT < NPIECE;
         const int H0 = g0split ? YAT_GEMM_NT_SPLIT : NPIECE;
         char* nxt = smem + ((t + 1) & 1) * G::STAGE;
-#ifndef YAT_ABL_NO_DMA
-        if (!dic) {
-            if (FAST) {
-#pragma unroll
-                for (int j = 0; j < NPIECE; ++j)
-                    if (j < H0) piece(std::false_type{}, t + 1, nxt, j);
-            } else if (t + 1 < nt) {
-                issue_range(t + 1, nxt, 0, H0);
-            }
-        }
+        // (!dic) YAT_GEMM_NT_READS_FIRST=1 puts the pieces AFTER the fragment reads of LOAD(t,ks0) (the reads then do not queue
+        // behind nine pieces): +3..4 % on the forward shapes alone, 84.4 -> 84.6 ms in the step (both orders) -- off.
+#ifndef YAT_GEMM_NT_READS_FIRST
+#define YAT_GEMM_NT_READS_FIRST 0
 #endif
+        auto nt_issue = [&]() {
+#ifndef YAT_ABL_NO_DMA
+            if (!dic) {
+                if (FAST) {
+#pragma unroll
+                    for (int j = 0; j < NPIECE; ++j)
+                        if (j < H0) piece(std::false_type{}, t + 1, nxt, j);
+                } else if (t + 1 < nt) {
+                    issue_range(t + 1, nxt, 0, H0);
+                }
+            }
+#endif
+        };
+        if (!YAT_GEMM_NT_READS_FIRST) nt_issue();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // ---- LOAD segment
@@ -436,6 +442,11 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) bfr[j] = frag256<false, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
                 }
+            }
+            if (YAT_GEMM_NT_READS_FIRST && kk == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                nt_issue();
+                __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef YAT_ABL_NO_VMWAIT
