@@ -137,7 +137,7 @@ def test_gemm_grouped_wgrad(ops):
         ops.wgrad_grouped(items * 2)                      # more than 8 problems
 
 
-@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("variant", [4, 5, 6])             # 6: the one-wave-per-SIMD experiment (gemm1w)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 64), (512, 640, 192), (300, 328, 96), (1024, 2240, 5600), (777, 1000, 264)])
 def test_gemm256_all_layouts(ops, variant, M, N, K):
     """The 256-row staggered-wave-group kernel (gemm256.hip), every layout, ragged M/N/K tails."""
@@ -156,7 +156,7 @@ def test_gemm256_all_layouts(ops, variant, M, N, K):
         close(out, (xt.float().T @ w.float().T).to(BF), f"gemm256v{variant}_tt {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("variant", [4, 5, 6])
 def test_gemm256_epilogue_and_identity(ops, variant):
     n = 512
     eye = torch.eye(n, dtype=BF, device=DEV)
@@ -184,7 +184,7 @@ def test_gemm256_epilogue_and_identity(ops, variant):
     close(s_out, F.silu(linr).to(BF), f"gemm256v{variant}_epi_silu")
 
 
-@pytest.mark.parametrize("code", [204, 405, 205, 804, 304, 1005])
+@pytest.mark.parametrize("code", [204, 405, 205, 804, 304, 1005, 306])
 def test_gemm256_split_k(ops, code):
     """Split-K (fp32 slabs + reduce kernel with the fused epilogue), forced via variant = 100*ksplit + tile."""
     M, N, K = 520, 648, 2048 + 96                     # ragged everything; K tail lands in the last slice
