@@ -53,9 +53,11 @@ __device__ __forceinline__ uint32_t trswz2(uint32_t krow) {
     return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
 }
 
-// loop-invariant part of one DMA piece: byte offset of this lane's 16-B chunk at k-tile 0 (or OOB),
-// and (row-mode only) the source chunk index inside the 64-wide k-tile for the ragged-K check.
-struct Piece { uint32_t voff; uint32_t kchunk; };
+// loop-invariant part of one DMA piece: byte offset of this lane's 16-B chunk at k-tile 0 (or OOB).  The source chunk index
+// inside the 64-wide k-tile that the ragged-K check of a row-mode piece needs is the same for every piece of a wave
+// (pieces are 8 rows apart per wave step of 8 or 4, and the swizzle looks at (row >> 1) & 7): piece_kchunk().
+struct Piece { uint32_t voff; };
+__device__ __forceinline__ uint32_t piece_kchunk(int wave, int lane) { return swz128(wave * 8 + (lane >> 3), lane & 7); }
 
 template <bool KSTRIDED, int ROWS_OR_COLS>
 __device__ __forceinline__ Piece make_piece(int piece, int lane, int ld, int idx0, int idx_max) {
@@ -64,7 +66,6 @@ __device__ __forceinline__ Piece make_piece(int piece, int lane, int ld, int idx
         const int r = piece * 8 + (lane >> 3);
         const int c = swz128(r, lane & 7);
         const int gi = idx0 + r;
-        pc.kchunk = c;
         pc.voff = gi < idx_max ? (uint32_t)(((int64_t)gi * ld + c * 8) * 2) : YAT_OOB;
     } else {
         constexpr int ROWB = ROWS_OR_COLS * 2;                 // bytes per k-row of the LDS image
@@ -72,7 +73,6 @@ __device__ __forceinline__ Piece make_piece(int piece, int lane, int ld, int idx
         const uint32_t r = o / ROWB, slot = (o % ROWB) >> 4;
         const uint32_t c = slot ^ trswz2<ROWS_OR_COLS>(r);
         const int gi = idx0 + c * 8;
-        pc.kchunk = 0;
         pc.voff = gi < idx_max ? (uint32_t)(((int64_t)r * ld + gi) * 2) : YAT_OOB;   // k-rows past K: buffer range check
     }
     return pc;
@@ -210,6 +210,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     for (int j = 0; j < G::PA; ++j) pa[j] = make_piece<A_T, BM>(wave + 8 * j, lane, p.lda, m0, p.M);
 #pragma unroll
     for (int j = 0; j < G::PB; ++j) pb[j] = make_piece<B_T, G::BN>(wave + 8 * j, lane, p.ldb, n0, p.N);
+    const uint32_t kchunk = piece_kchunk(wave, lane);
     const uint32_t a_kstep = A_T ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
     const uint32_t b_kstep = B_T ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
     const int nt_all = (p.K + BK - 1) / BK;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             if (CHECKED) {
                 const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;     // valid 16-B chunks in this k-tile (row-mode)
                 uint32_t v = pa[jj].voff + (uint32_t)t * a_kstep;
-                if (!A_T && pa[jj].kchunk >= kvalid) v = YAT_OOB;
+                if (!A_T && kchunk >= kvalid) v = YAT_OOB;
                 lds_dma16(ra, dst, v);
             } else {
                 lds_dma16s(ra, dst, pa[jj].voff, (uint32_t)t * a_kstep);
@@ -243,7 +244,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             if (CHECKED) {
                 const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
                 uint32_t v = pb[jj].voff + (uint32_t)t * b_kstep;
-                if (!B_T && pb[jj].kchunk >= kvalid) v = YAT_OOB;
+                if (!B_T && kchunk >= kvalid) v = YAT_OOB;
                 lds_dma16(rb, dst, v);
             } else {
                 lds_dma16s(rb, dst, pb[jj].voff, (uint32_t)t * b_kstep);
@@ -665,6 +666,7 @@ __device__ __forceinline__ void gemm1w_body(const GemmP p, int id) {
     for (int j = 0; j < G::PA; ++j) pa[j] = make_piece<A_T, BM>(wave + 4 * j, lane, p.lda, m0, p.M);
 #pragma unroll
     for (int j = 0; j < G::PB; ++j) pb[j] = make_piece<B_T, G::BN>(wave + 4 * j, lane, p.ldb, n0, p.N);
+    const uint32_t kchunk = piece_kchunk(wave, lane);
     const uint32_t a_kstep = A_T ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
     const uint32_t b_kstep = B_T ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
     const int nt_all = (p.K + BK - 1) / BK;
@@ -686,7 +688,7 @@ __device__ __forceinline__ void gemm1w_body(const GemmP p, int id) {
         if (CHECKED) {
             const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
             uint32_t v = pc.voff + (uint32_t)t * kstep;
-            if (!kstr && pc.kchunk >= kvalid) v = YAT_OOB;
+            if (!kstr && kchunk >= kvalid) v = YAT_OOB;
             lds_dma16(opa ? ra : rb, dst, v);
         } else {
             lds_dma16s(opa ? ra : rb, dst, pc.voff, (uint32_t)t * kstep);
