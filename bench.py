@@ -179,12 +179,15 @@ def run_from_shards(args, rank, world, local_rank):
             barrier()
             clock["t0"] = time.perf_counter()
         elif step == args.warmup + args.steps:
+            clock["t_issue"] = time.perf_counter()       # host done enqueueing the timed steps (it runs ahead of the GPU)
             barrier()
             clock["t1"] = time.perf_counter()
     log(f"rank {rank}/{world}: trainer mode, {args.warmup} + {args.steps} steps from {len(paths)} shard(s) in {root}")
     trainer.run(on_step=on_step)
     os.chdir(cwd)
     elapsed = clock["t1"] - clock["t0"]
+    log(f"trainer mode: host enqueue time {1e3 * (clock['t_issue'] - clock['t0']) / args.steps:.1f} ms/step, "
+        f"step {1e3 * elapsed / args.steps:.1f} ms")
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=trainer.accelerator.device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
