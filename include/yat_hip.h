@@ -61,6 +61,11 @@ typedef struct yat_gemm_epilogue {
     int ld_dact_z;         /* produces the activation's output gradient: C = bf16(bf16(result) * act'(z)), `activation`       */
                            /* selecting act (1 SiLU, 2 GELU-tanh) -- FeedForward's GELU in PixArt-Sigma (net.0 -> net.2);      */
                            /* excludes the other options                                                                       */
+    void* a_rowsum_out;    /* bf16 [M] or NULL (wgrad layout (1,1) only, no split-K): out[m] = bf16(sum_k A_op[m,k]) -- the     */
+    int a_rowsum_accumulate; /* BIAS gradient of the Linear whose weight gradient this GEMM computes (A = dy: column sums of    */
+                           /* dy), from one extra MFMA per A fragment against a fragment of ones in the workgroups of the first */
+                           /* column tile instead of a second pass over dy; accumulate: out[m] = bf16(bf16(sum) + out[m])      */
+                           /* (gradient accumulation, the `residual` = C convention)                                           */
 } yat_gemm_epilogue;
 
 uint64_t yat_gemm_epilogue_size(void);   /* sizeof(yat_gemm_epilogue) in this build of the library */

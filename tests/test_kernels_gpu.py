@@ -725,3 +725,37 @@ def test_dgrad_with_activation_backward_epilogue(ops, act, M, N, K):
     (F.gelu(zf, approximate="tanh") if act == "gelu_tanh" else F.silu(zf)).backward(rb(dy.float() @ w.float()))
     # against torch: the bf16 rounding of the intermediate can flip with the accumulation order, so one extra ulp
     close(fused, zf.grad.to(BF), f"dgrad_act_{act} {M}x{N}x{K}", ulps=3.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(2240, 512, 4096), (520, 648, 2048 + 96), (256, 256, 64), (4480, 2240, 1000)])
+def test_wgrad_with_fused_bias_gradient(ops, M, N, K):
+    """yat_gemm_epilogue.a_rowsum_out: the weight-gradient GEMM dW = dy^T x also returns the bias gradient (column sums of dy,
+    i.e. row sums of its A operand) from one extra MFMA per A fragment against ones -- vs torch, plain and accumulating, and
+    the weight gradient itself must be bit-identical to the launch without it."""
+    dy, x = rnd(K, M, scale=0.5, seed=120), rnd(K, N, seed=121)          # wgrad layout: tokens are the reduction dimension
+    ref_w = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm(dy, x, ref_w, a_t=True, b_t=True, M=M, N=N, K=K, variant=4)
+    out, db = torch.empty(M, N, dtype=BF, device=DEV), torch.full((M,), 7.0, dtype=BF, device=DEV)
+    ops.gemm(dy, x, out, a_t=True, b_t=True, M=M, N=N, K=K, a_rowsum=db)
+    assert torch.equal(out, ref_w)
+    ref_b = dy.float().sum(0)
+    close(db, ref_b.to(BF), f"wgrad_rowsum {M}x{N}x{K}")
+    # accumulate (gradient accumulation): dW += and db += with the bf16 rounding of the += convention
+    ops.gemm(dy, x, out, a_t=True, b_t=True, M=M, N=N, K=K, residual=out, a_rowsum=db, a_rowsum_accumulate=True)
+    close(db, (rb(ref_b) + rb(ref_b)).to(BF), f"wgrad_rowsum_acc {M}x{N}x{K}")
+    # through the helpers the models call: single launch and grouped launch
+    w2, b2 = torch.empty(M, N, dtype=BF, device=DEV), torch.empty(M, dtype=BF, device=DEV)
+    ops.linear_wgrad(dy, x, w2, bias_grad=b2)
+    assert torch.equal(w2, ref_w)
+    close(b2, ref_b.to(BF), "linear_wgrad bias_grad")
+    w3, b3 = torch.empty(M, N, dtype=BF, device=DEV), torch.empty(M, dtype=BF, device=DEV)
+    w4 = torch.empty(N, N, dtype=BF, device=DEV)
+    ops.wgrad_grouped([(dy, x, w3, b3), (x, x, w4)])
+    assert torch.equal(w3, ref_w)
+    close(b3, ref_b.to(BF), "wgrad_grouped bias_grad")
+    # argument checks: only the weight-gradient layout, no split-K, not the 320-wide tile
+    from yat_amd import lib as L
+    with pytest.raises(L.YatLibraryError):
+        ops.gemm(x, x, w4, M=N, N=N, K=K, a_rowsum=b2[:N].contiguous())          # forward layout
+    with pytest.raises(L.YatLibraryError):
+        ops.gemm(dy, x, out, a_t=True, b_t=True, M=M, N=N, K=K, a_rowsum=db, variant=204)

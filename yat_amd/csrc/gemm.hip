@@ -235,6 +235,9 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
         p.dact_z = (const bf16_t*)ep->dact_z; p.ld_z = ep->ld_dact_z;
         if (p.dact_z && (p.bias || p.gate || p.res || p.aux || p.glu_u || p.pre_add || !p.act || (p.ld_z & 3) || p.ld_z < N))
             return YAT_EINVAL;
+        p.rowsum = (bf16_t*)ep->a_rowsum_out; p.rowsum_acc = ep->a_rowsum_accumulate;
+        if (p.rowsum && (!a_t || !b_t || p.bias || p.gate || p.aux || p.act || p.glu_u || p.pre_add || p.dact_z))
+            return YAT_EINVAL;                                   // weight-gradient layout, plain (or accumulating) epilogue
     }
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
@@ -261,6 +264,7 @@ extern "C" int yat_gemm_grouped_bf16(int a_t, int b_t, int count, const yat_gemm
         const yat_gemm_problem& q = problems[i];
         const int rc = fill_gemm_p(a_t, b_t, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.epilogue, ps[i]);
         if (rc) return rc;
+        if (ps[i].rowsum && !(a_t && b_t)) return YAT_EINVAL;
     }
     return yat_gemm256_grouped_launch(a_t, b_t, count, ps, (hipStream_t)stream);
 }
@@ -288,6 +292,10 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     if (p.glu_u) {                              // GLU-backward epilogue lives in the 256-row kernel only
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
         if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
+    }
+    if (p.rowsum) {                             // bias gradient fused into the weight gradient: 256 x 256 tile (the 320-wide
+        if (ksplit != 1 || (variant != 0 && variant != 4)) return YAT_EINVAL;   // one has no registers for the extra
+        variant = 4;                            // accumulators), whole K in one workgroup
     }
     static const int max_ksplit = getenv("YAT_GEMM_MAX_KSPLIT") ? atoi(getenv("YAT_GEMM_MAX_KSPLIT")) : 32;
     static const bool pow2_only = getenv("YAT_GEMM_KSPLIT_POW2") && atoi(getenv("YAT_GEMM_KSPLIT_POW2"));

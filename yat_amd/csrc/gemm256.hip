@@ -177,7 +177,8 @@ __device__ __forceinline__ int xcd_contiguous(int nwg) {
 }
 
 // One workgroup's whole job: `id` = work item inside problem p (tile x K slice, before the row-group swizzle).
-template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GLU backward, 2 standard + pre_add, 3 act backward
+template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GLU backward, 2 standard + pre_add, 3 act backward,
+                                                         //      4 standard + row sums of A (wgrad + bias gradient)
 __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     using G = Geo<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,6 +273,15 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 af[8], bfr[NT];
+    // EPI 4: the bias gradient of the Linear whose weight gradient this is = row sums of A (= dy^T) over K, from one extra MFMA
+    // per A fragment against a fragment of ones -- in the waves that own column slice 0 of the FIRST column tile only (every
+    // column tile sees the same A panel).  All 16 result columns of such a tile are equal; column 0 is stored.
+    const bool rs_wave = EPI == 4 && p.rowsum != nullptr && tn == 0 && wc == 0;
+    f32x4 racc[EPI == 4 ? 8 : 1];
+    if (EPI == 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #ifdef YAT_GEMM_STAMPS
     uint32_t st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t st_prev = 0;
@@ -329,6 +339,13 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                         else piece(std::false_type{}, dma_tile, dst, idx / GAP);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if (EPI == 4 && idx == 8 * NT - 1 && rs_wave) {
+                    bf16x8 ones;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) racc[q] = mfma16(ones, af[q], racc[q]);
                 }
                 if (idx == 8 * NT - 1 - EARLY) {
                     YAT_STAMP(st_slot);
@@ -500,6 +517,17 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #endif
     if (grp == 0) YAT_PHASE_BARRIER();         // pair group 1's last barrier
 
+    if (EPI == 4 && rs_wave && p.ksplit == 1 && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + grp * 128 + i * 16 + lane;
+            if (m < p.M) {
+                float v = racc[i][0];
+                if (p.rowsum_acc) v = rbf(v) + bf2f(p.rowsum[m]);
+                p.rowsum[m] = f2bf(v);
+            }
+        }
+    }
     // ---- epilogue.  The MFMA layout gives a lane 4 columns of 16 different rows (8-B accesses in 32-B runs).  When
     // everything is 16-B aligned the accumulators go through the (now free) LDS instead: each wave transposes 32 rows
     // at a time in a private padded fp32 slab and reads back 8 consecutive columns per lane, so bias / gate / residual
@@ -596,7 +624,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_grouped_kernel(GroupedP gp) {
     const int id = xcd_contiguous(gp.first[gp.ngroups]);
     int g = 0;
     while (g + 1 < gp.ngroups && id >= gp.first[g + 1]) ++g;
-    gemm256_body<A_T, B_T, NT>(gp.g[g], id - gp.first[g]);
+    // the weight-gradient layout carries the row sums of A (bias gradients) for the problems that ask for them
+    gemm256_body<A_T, B_T, NT, (A_T && B_T && NT == 4) ? 4 : 0>(gp.g[g], id - gp.first[g]);
 }
 
 template <bool A_T, bool B_T, int NT>
@@ -932,6 +961,10 @@ int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStre
     if (p.dact_z) {                // activation-backward epilogue: dgrad layout only, no split-K
         if (a_t || !b_t || p.ksplit > 1) return YAT_EINVAL;
         return nt_variant == 5 ? launch256<false, true, 5, 3>(p, stream) : launch256<false, true, 4, 3>(p, stream);
+    }
+    if (p.rowsum) {                // weight gradient + bias gradient: (1,1) layout, 256 x 256 tile, whole K per workgroup
+        if (!a_t || !b_t || p.ksplit > 1 || nt_variant != 4) return YAT_EINVAL;
+        return launch256<true, true, 4, 4>(p, stream);
     }
     if (p.pre_add) {               // adapter addend: only the forward layout (x W^T) is instantiated, no split-K
         if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;

@@ -21,6 +21,8 @@ struct GemmP {
     int ld_pre;
     const bf16_t* dact_z;  // activation-backward epilogue: z = the activation's input, [M, ld_z]; C = bf16(d) * act'(z)
     int ld_z;
+    bf16_t* rowsum;        // wgrad layout: [M] row sums of the A operand over K (the Linear's bias gradient) or null
+    int rowsum_acc;
 };
 
 // GLU backward fused into the producer of dy (= this GEMM's result d, rounded to bf16 like the Linear's output):

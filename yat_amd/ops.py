@@ -7,6 +7,7 @@ that entry point replaces.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -98,19 +99,20 @@ def gemm_concurrency(streams: int):
 
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
          activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
-         glu_u=None, pre_add=None, dact_z=None):
+         glu_u=None, pre_add=None, dact_z=None, a_rowsum=None, a_rowsum_accumulate=False):
     """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
-    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add, dact_z)
+    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add, dact_z, a_rowsum)
     lda = lda if lda is not None else (M if a_t else K)
     ldb = ldb if ldb is not None else (N if b_t else K)
     ldc = ldc if ldc is not None else N
     ep = None
     if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None \
-            or glu_u is not None or pre_add is not None or dact_z is not None:
+            or glu_u is not None or pre_add is not None or dact_z is not None or a_rowsum is not None:
         ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
                              ld_residual, rows_per_batch, _p(glu_u), 0 if glu_u is None else glu_u.stride(0),
                              _p(pre_add), 0 if pre_add is None else pre_add.stride(0),
-                             _p(dact_z), 0 if dact_z is None else dact_z.stride(0))
+                             _p(dact_z), 0 if dact_z is None else dact_z.stride(0),
+                             _p(a_rowsum), int(bool(a_rowsum_accumulate)))
     timer = GEMM_TIMER
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,30 +165,43 @@ def linear_dgrad_act(dy2d, w, z, act, out=None):
     return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, activation=act, dact_z=z)
 
 
-def linear_wgrad(dy2d, x2d, out, accumulate=False):
-    """dW = dy^T x : dy [M,N], x [M,K] -> out [N,K] (optionally += for gradient accumulation)."""
+FUSE_BIAS_GRAD = os.environ.get("YAT_FUSE_BIAS_GRAD", "1") != "0"
+
+
+def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=None):
+    """dW = dy^T x : dy [M,N], x [M,K] -> out [N,K] (optionally += for gradient accumulation).  ``bias_grad`` [N]: the bias
+    gradient (column sums of dy) from the same launch (yat_gemm_epilogue.a_rowsum_out) -- or, with YAT_FUSE_BIAS_GRAD=0 and a
+    ``colsum_ws``, from the separate yat_colsum_bf16 pass it replaces."""
     M, N = dy2d.shape
     K = x2d.shape[1]
-    return gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=N, ldb=K, ldc=K,
-                residual=out if accumulate else None)
+    fused = bias_grad is not None and FUSE_BIAS_GRAD
+    r = gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=dy2d.stride(0), ldb=K, ldc=K,
+             residual=out if accumulate else None, a_rowsum=bias_grad if fused else None, a_rowsum_accumulate=accumulate)
+    if bias_grad is not None and not fused:
+        colsum(dy2d, bias_grad, colsum_ws, accumulate=accumulate)
+    return r
 
 
 def wgrad_grouped(items, accumulate=False):
-    """yat_gemm_grouped_bf16 for a set of weight gradients: items = [(dy [M,N], x [M,K], out [N,K]), ...], all
-    dW = dy^T x (optionally += out) in ONE launch of 256x256 tiles (see include/yat_hip.h)."""
+    """yat_gemm_grouped_bf16 for a set of weight gradients: items = [(dy [M,N], x [M,K], out [N,K][, bias_grad [N]]), ...], all
+    dW = dy^T x (optionally += out) in ONE launch of 256x256 tiles (see include/yat_hip.h); a 4th member gets the bias
+    gradient (column sums of dy) from the same launch."""
     n = len(items)
     probs = (_l.GemmProblem * n)()
     eps = (_l.GemmEpilogue * n)()
     flops = 0.0
-    for i, (dy, x, out) in enumerate(items):
-        _chk_bf16(dy, x, out)
+    for i, item in enumerate(items):
+        dy, x, out = item[:3]
+        bias_grad = item[3] if len(item) > 3 and FUSE_BIAS_GRAD else None      # optional 4th member: the bias gradient [N]
+        _chk_bf16(dy, x, out, bias_grad)
         M, N = dy.shape
         K = x.shape[1]
         pr = probs[i]
         pr.M, pr.N, pr.K = N, K, M
         pr.A, pr.lda, pr.B, pr.ldb, pr.C, pr.ldc = _p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), K
-        if accumulate:
-            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out), 0, 0, K, 0, None, 0, None, 0)
+        if accumulate or bias_grad is not None:
+            eps[i] = _l.GemmEpilogue(None, None, 0, None, _p(out) if accumulate else None, 0, 0, K, 0, None, 0, None, 0,
+                                     None, 0, _p(bias_grad), int(bool(accumulate)))
             pr.epilogue = C.pointer(eps[i])
         flops += 2.0 * M * N * K
     timer = GEMM_TIMER

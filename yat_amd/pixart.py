@@ -417,9 +417,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
                 return
 
             def run():
-                ops.linear_wgrad(dy, x, gw, accumulate=acc)
-                if gbias is not None:
-                    ops.colsum(dy, gbias, ws_col, accumulate=acc)
+                ops.linear_wgrad(dy, x, gw, accumulate=acc, bias_grad=gbias, colsum_ws=ws_col)      # bias gradient: same launch
             off_chain(run)
 
         # ---- output head

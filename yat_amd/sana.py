@@ -463,9 +463,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 if ad is not None:        # frozen base: only the adapters' share (nothing at all for a non-target)
                     ad.wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
                     return
-                ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc)
-                if bias_key is not None:
-                    ops.colsum(dy, G[bias_key], ws_col, accumulate=acc)
+                ops.linear_wgrad(dy, x, G[key].view(shape2d), accumulate=acc,
+                                 bias_grad=None if bias_key is None else G[bias_key], colsum_ws=ws_col)   # bias gradient: same launch
             if side is None:
                 run()
                 return
@@ -533,9 +532,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                     return
 
                 def run():
-                    ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
-                    if bias is not None:
-                        ops.colsum(dy_, bias, ws_col, accumulate=acc)
+                    ops.linear_wgrad(dy_, x_, gw_, accumulate=acc, bias_grad=bias, colsum_ws=ws_col)
                 off_chain(run)
 
             # x3 = x2 + gate_mlp * lin3
@@ -599,10 +596,13 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 # 2240 x 2240 x 8192 each: 81 tiles of 256 x 256 -- alone they need split-K (fp32 slabs + a reduce launch);
                 # together 243 full-K tiles fill the 256 CUs in one round
                 def small_grads(small=small):
-                    ops.wgrad_grouped([(a, b, c) for a, b, c, _ in small], accumulate=acc)
-                    for a, _, _, bias_ in small:
-                        if bias_ is not None:
-                            ops.colsum(a, bias_, ws_col, accumulate=acc)
+                    fuse = ops.FUSE_BIAS_GRAD
+                    ops.wgrad_grouped([(a, b, c, bias_) if (fuse and bias_ is not None) else (a, b, c)
+                                       for a, b, c, bias_ in small], accumulate=acc)          # bias gradients: same launch
+                    if not fuse:
+                        for a, _, _, bias_ in small:
+                            if bias_ is not None:
+                                ops.colsum(a, bias_, ws_col, accumulate=acc)
                 off_chain(small_grads)
             dattn = dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf(f"dqkv.{par}", (M, 3 * D))

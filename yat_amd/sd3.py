@@ -480,9 +480,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                 return
 
             def run():
-                ops.linear_wgrad(dy, x, gw, accumulate=acc)
-                if gbias is not None:
-                    ops.colsum(dy, gbias, ws_col, accumulate=acc)
+                ops.linear_wgrad(dy, x, gw, accumulate=acc, bias_grad=gbias, colsum_ws=ws_col)      # bias gradient: same launch
             off_chain(run)
 
         def dgrad(dy_, w_, out=None, residual=None):
@@ -506,8 +504,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             """demb [B, k*D] fp32 accumulators -> Linear(silu(temb)) gradients: weight, bias, and the share of d silu(temb)."""
             d_b = ops.f32_to_bf16(demb_f32, buf(f"demb_b.{tag}", tuple(demb_f32.shape)))
             if ad is None:
-                ops.linear_wgrad(d_b, S.se, G[wkey], accumulate=acc)
-                ops.colsum(d_b, G[bkey], ws_col, accumulate=acc)
+                ops.linear_wgrad(d_b, S.se, G[wkey], accumulate=acc, bias_grad=G[bkey], colsum_ws=ws_col)
             else:
                 pending_ad.append((d_b, S.se, G[wkey]))
             dgrad(d_b, P[wkey], out=dse, residual=dse if dse_started[0] else None)
