@@ -174,7 +174,10 @@ def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=Non
     ``colsum_ws``, from the separate yat_colsum_bf16 pass it replaces."""
     M, N = dy2d.shape
     K = x2d.shape[1]
-    fused = bias_grad is not None and FUSE_BIAS_GRAD
+    # fused only where the shape policy would not split K anyway (>= 96 tiles of 256 x 256: csrc/gemm.hip est_time_256) -- the
+    # fused form is one workgroup per tile over the whole K, and a 25-tile, K = 32768 weight gradient (PixArt's D x D) left
+    # unsplit makes the weight-gradient stream the critical path (PixArt 228 -> 244 ms when it was fused unconditionally)
+    fused = bias_grad is not None and FUSE_BIAS_GRAD and ((N + 255) // 256) * ((K + 255) // 256) >= 96
     r = gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=dy2d.stride(0), ldb=K, ldc=K,
              residual=out if accumulate else None, a_rowsum=bias_grad if fused else None, a_rowsum_accumulate=accumulate)
     if bias_grad is not None and not fused:
