@@ -745,8 +745,11 @@ def test_wgrad_with_fused_bias_gradient(ops, M, N, K):
     close(db, (rb(ref_b) + rb(ref_b)).to(BF), f"wgrad_rowsum_acc {M}x{N}x{K}")
     # through the helpers the models call: single launch and grouped launch
     w2, b2 = torch.empty(M, N, dtype=BF, device=DEV), torch.empty(M, dtype=BF, device=DEV)
-    ops.linear_wgrad(dy, x, w2, bias_grad=b2)
-    assert torch.equal(w2, ref_w)
+    ops.linear_wgrad(dy, x, w2, bias_grad=b2)       # fused from 96 tiles on, else the separate column-sum pass: same contract
+    if ((M + 255) // 256) * ((N + 255) // 256) >= 96:
+        assert torch.equal(w2, ref_w)
+    else:
+        close(w2, ref_w, "linear_wgrad (policy may split K)")
     close(b2, ref_b.to(BF), "linear_wgrad bias_grad")
     w3, b3 = torch.empty(M, N, dtype=BF, device=DEV), torch.empty(M, dtype=BF, device=DEV)
     w4 = torch.empty(N, N, dtype=BF, device=DEV)

@@ -181,6 +181,8 @@ def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=Non
     r = gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=dy2d.stride(0), ldb=K, ldc=K,
              residual=out if accumulate else None, a_rowsum=bias_grad if fused else None, a_rowsum_accumulate=accumulate)
     if bias_grad is not None and not fused:
+        if colsum_ws is None:                                   # (the models pass their arena buffer)
+            colsum_ws = torch.empty(int(_lib().yat_colsum_workspace_bytes(M, N)), dtype=torch.uint8, device=dy2d.device)
         colsum(dy2d, bias_grad, colsum_ws, accumulate=accumulate)
     return r
 
