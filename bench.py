@@ -41,7 +41,9 @@ BUCKETS = [(32, 32), (16, 64), (24, 42), (44, 22)]
 
 
 def train_flops_per_image(cfg, N, T):
-    """Algorithmic training FLOPs of one image: 6 x forward MACs (fwd + dgrad + wgrad), no recompute."""
+    """Algorithmic training FLOPs of one image: 6 x forward MACs (fwd + dgrad + wgrad), no recompute.  T = text rows that
+    are computed for the image: 512 when the padding rows go through the text side as in the reference, the prompt's own
+    length (batch mean) when the text rows are packed -- the skipped rows are not counted as work."""
     D, Hc, Cc = cfg.inner_dim, cfg.ffn_hidden, cfg.caption_channels
     blk = (N * D * 3 * D + N * D * D            # qkv, attn1.out
            + 2 * 33 * 32 * N * cfg.num_attention_heads   # linear attention state + apply
@@ -195,7 +197,10 @@ def run_from_shards(args, rank, world, local_rank):
     loss_val = float(trainer.loss_history[-1])
     if rank == 0:
         cfg = trainer.model.cfg
-        flops = B * sum(train_flops_per_image(cfg, h * w, 512) for h, w in BUCKETS) / len(BUCKETS)
+        # text rows computed per image: the prompts' own lengths (uniform 20..300 in the synthetic shards, mean 160) when
+        # the recipe packs the text rows, the reference's 512 otherwise
+        trows = 160.0 if (os.environ.get("YAT_TEXT_PACK", "1") != "0" and not (args.lokr or args.lora)) else 512
+        flops = B * sum(train_flops_per_image(cfg, h * w, trows) for h, w in BUCKETS) / len(BUCKETS)
         print(json.dumps({
             "metric": "images/sec (whole node) SANA-1.6B 1024px bf16 training step", "value": world * B * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -313,7 +318,7 @@ def main():
             offs.append(offs[-1] + L)
         src = torch.randn(offs[-1], Cc, generator=g, device=dev).to(torch.bfloat16)
         batches.append(dict(h=h, w=w, lat=lat, src=src, offsets=torch.tensor(offs, dtype=torch.int32, device=dev),
-                            work=ops.kv_work_list(lens, T, dev)))
+                            work=ops.kv_work_list(lens, T, dev), lens=lens, rows=offs[-1]))
     enc = torch.empty(B, T, Cc, dtype=torch.bfloat16, device=dev)
     mask = torch.empty(B, T, dtype=torch.int64, device=dev)
     bias = torch.empty(B, T, dtype=torch.float32, device=dev)
@@ -326,14 +331,29 @@ def main():
     t_dev = torch.empty(B, dtype=torch.float32, device=dev)        # persistent: the step's launch plan holds their addresses
     sig_dev = torch.empty(B, dtype=torch.bfloat16, device=dev)
 
+    def stage_text(b):
+        """pad + mask (train_sana.py:168-180): packed text rows (no padding rows through the text-side GEMMs, see
+        SanaRecipe.packs_text / SanaTransformer2DModelHIP.forward_impl) unless YAT_TEXT_PACK=0 or an adapter is wrapped"""
+        if recipe.packs_text(b["lens"]):
+            enc_b = recipe.packed_enc(B, T, Cc, b["rows"])
+            ops.pack_mask(b["src"], b["offsets"], B, T, Cc, enc_b, mask, bias, kvl)
+            return enc_b, b["offsets"][:B]
+        ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)
+        return enc, None
+
+    def text_rows(b):
+        """text rows per image that the step computes (FLOP accounting)"""
+        return b["rows"] / B if recipe.packs_text(b["lens"]) else T
+
     def step(i):
         b = batches[i % len(batches)]
-        ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)                       # train_sana.py:168-180
+        enc_b, kv_off = stage_text(b)                                                               # train_sana.py:168-180
         noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)  # :183
         _, t_host, sig_host = recipe.scheduler.sample(B, ts_gen)                                    # :185-204
         t_dev.copy_(t_host, non_blocking=True)
         sig_dev.copy_(sig_host, non_blocking=True)
-        recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, sig_dev, loss_dev, kv_work=b["work"])  # :206-218 + bwd
+        recipe.train_step_device(b["lat"], enc_b, (bias, kvl), noise, t_dev, sig_dev, loss_dev, kv_work=b["work"],
+                                 kv_off=kv_off)                                                     # :206-218 + bwd
         if ddp:
             ddp.wait()
         if OPT_TIMER is not None:           # roofline pass only: HIP events around clip + AdamW on its stream
@@ -344,7 +364,7 @@ def main():
             OPT_TIMER.append((e0, e1))
         else:
             opt.step()                                                                              # trainer.py:347-356
-        return b["h"] * b["w"]
+        return b["h"] * b["w"], text_rows(b)
 
     def barrier():
         if world > 1 or force_ddp:
@@ -366,8 +386,8 @@ def main():
     t0 = time.perf_counter()
     flops = 0.0
     for i in range(args.steps):
-        ntok = step(args.warmup + i)
-        flops += B * train_flops_per_image(cfg, ntok, T)
+        ntok, trows = step(args.warmup + i)
+        flops += B * train_flops_per_image(cfg, ntok, trows)
     issue = time.perf_counter() - t0          # host time to enqueue all steps (the host runs ahead of the GPU)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -401,13 +421,13 @@ def main():
             b = batches[(args.warmup + args.steps + i) % len(batches)]
             main = torch.cuda.current_stream()
             ev["start"].record(main)
-            ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)
+            enc_b, kv_off = stage_text(b)
             noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)
             _, t_host, sig_host = recipe.scheduler.sample(B, ts_gen)
             t_dev.copy_(t_host, non_blocking=True)
             sig_dev.copy_(sig_host, non_blocking=True)
             noisy, target = ops.flow_mix(b["lat"], noise, sig_dev, recipe._noisy(b["lat"]), recipe._target(b["lat"]))
-            pred = model.forward_device(noisy, enc, t_dev, bias, kvl, kv_work=b["work"])
+            pred = model.forward_device(noisy, enc_b, t_dev, bias, kvl, kv_work=b["work"], kv_off=kv_off)
             ev["fwd"].record(main)
             dpred = recipe._dpred(pred)
             ops.mse_fwd_bwd(pred, target, loss_dev, dpred, recipe._mse_ws)
@@ -463,7 +483,9 @@ def main():
                                     + (f"LoKr rank {args.lokr} adapters on a frozen base (BASELINE config 5), " if args.lokr
                                        else f"LoRA rank {args.lora} adapters on a frozen base, " if args.lora
                                        else "full fine-tune, ") +
-                                    f"cached latents/text embeds, aspect buckets {BUCKETS} round-robin, T=512, AdamW+clip"),
+                                    f"cached latents/text embeds, aspect buckets {BUCKETS} round-robin, prompts of 20..300 tokens "
+                                    + ("(text rows packed: the masked padding rows to T=512 are not computed)"
+                                       if recipe.packs_text(batches[0]["lens"]) else "padded to T=512") + ", AdamW+clip"),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",
                        "num_layers": cfg.num_layers, "params": model.numel_flat},
             "loss": loss_val,

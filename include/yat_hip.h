@@ -185,6 +185,19 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
                  int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
                  const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,
                  int n_work, int parts, yat_stream_t stream);
+/* Packed keys: the same two operations when the text side keeps NO padding rows (train_sana.py:168-176 pads every prompt
+ * to 512 rows; the K / V projections of the padding are computed there and then masked out with the -10000 bias, their
+ * probabilities and gradients being exactly zero).  Image b's K / V (and dK / dV) rows are
+ * [kv_row_offsets[b], kv_row_offsets[b] + kv_len[b]) of one [kv_rows, ldkv] matrix (kv_len[b] >= 1 for every image);
+ * key_bias / kv_len / work_list keep their [B, T] / [B] / (batch, tile) meaning.  Rows of dk / dv outside those ranges are
+ * not written.  Results are bit-identical to the padded entry points on the same keys. */
+int yat_sdpa_fwd_packed(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                        int ldkv, const int* kv_row_offsets, int kv_rows, const float* key_bias, const int* kv_len, void* out,
+                        int ldo, float* lse, yat_stream_t stream);
+int yat_sdpa_bwd_packed(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                        int ldkv, const int* kv_row_offsets, int kv_rows, const float* key_bias, const int* kv_len,
+                        const void* out, int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                        void* dk, void* dv, int lddkv, const int* work_list, int n_work, int parts, yat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * GLUMBConv middle: SiLU -> depthwise 3x3 (pad 1, bias) -> chunk2 -> a * SiLU(g)
@@ -282,6 +295,10 @@ int yat_timestep_embed_fwd(int B, int dim, const float* t, void* out, yat_stream
  * src: bf16 concatenation of the B [L_i, C] matrices; offsets: int32 [B+1] row offsets. */
 int yat_pad_mask(int B, int T, int C, const void* src, const int* offsets, void* dst, int64_t* mask, float* key_bias,
                  int* kv_len, yat_stream_t stream);
+/* the same without padding rows: dst [rows_padded, C] = the source rows followed by zero rows (rows_padded >= offsets[B]);
+ * mask / key_bias / kv_len exactly as yat_pad_mask writes them ([B, T] / [B]).  Feeds the packed-key attention above. */
+int yat_pack_mask(int B, int T, int C, int rows_padded, const void* src, const int* offsets, void* dst, int64_t* mask,
+                  float* key_bias, int* kv_len, yat_stream_t stream);
 /* noisy = bf16(bf16((1-s)*x) + bf16(s*n)), target = bf16(n - x); sigma: bf16 [B] */
 int yat_flow_mix(int B, int64_t per_sample, const void* x, const void* noise, const void* sigma, void* noisy,
                  void* target, yat_stream_t stream);

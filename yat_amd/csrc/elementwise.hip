@@ -100,6 +100,32 @@ __global__ void pad_mask_kernel(int B, int T, int C, const bf16_t* src, const in
     }
 }
 
+// the same without padding rows: row r of dst is source row r (r < offsets[B]) or zeros (r < rows_padded)
+__global__ void pack_mask_kernel(int B, int T, int C, int rows_padded, const bf16_t* src, const int* offsets, bf16_t* dst,
+                                 int64_t* mask, float* key_bias, int* kv_len) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row < rows_padded) {
+        const bool keep = row < offsets[B];
+        const bf16_t* s = src + (int64_t)row * C;
+        bf16_t* d = dst + (int64_t)row * C;
+        const int nchunk = C >> 3;
+        for (int c = lane; c < nchunk; c += 64) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (keep) v = *reinterpret_cast<const u32x4*>(s + c * 8);
+            *reinterpret_cast<u32x4*>(d + c * 8) = v;
+        }
+    }
+    if (row < B * T && lane == 0) {
+        const int b = row / T, t = row % T;
+        const int L = offsets[b + 1] - offsets[b];
+        const bool keep = t < L;
+        if (mask) mask[row] = keep ? 1 : 0;
+        if (key_bias) key_bias[row] = keep ? 0.0f : rbf(-10000.0f);
+        if (kv_len && t == 0) kv_len[b] = L < T ? L : T;
+    }
+}
+
 // noisy = (1 - s) * x + s * n (each op rounded to bf16); target = n - x
 __global__ void flow_mix_kernel(int B, int64_t per, const bf16_t* x, const bf16_t* nz, const bf16_t* sigma, bf16_t* noisy,
                                 bf16_t* target) {
@@ -222,6 +248,15 @@ int yat_pad_mask(int B, int T, int C, const void* src, const int* offsets, void*
                  int* kv_len, yat_stream_t stream) {
     if (B <= 0 || T <= 0 || C <= 0 || (C & 7) || !src || !offsets || !dst) return YAT_EINVAL;
     hipLaunchKernelGGL(pad_mask_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, T, C,
+                       (const bf16_t*)src, offsets, (bf16_t*)dst, mask, key_bias, kv_len);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+int yat_pack_mask(int B, int T, int C, int rows_padded, const void* src, const int* offsets, void* dst, int64_t* mask,
+                  float* key_bias, int* kv_len, yat_stream_t stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || (C & 7) || rows_padded <= 0 || !src || !offsets || !dst) return YAT_EINVAL;
+    const int rows = rows_padded > B * T ? rows_padded : B * T;
+    hipLaunchKernelGGL(pack_mask_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, T, C, rows_padded,
                        (const bf16_t*)src, offsets, (bf16_t*)dst, mask, key_bias, kv_len);
     YAT_CHECK_LAUNCH();
     return YAT_OK;

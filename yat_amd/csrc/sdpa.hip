@@ -114,7 +114,13 @@ struct SdpaP {
     uint64_t bias_bytes;             // bytes of the key-bias array (B*T*4)
     const int* work; int n_work;     // dK/dV kernel: compact list of (batch, key tile) pairs, or null for the dense grid
     int xcd_remap;                   // workgroup index -> (tile, head, image) so that an XCD owns contiguous (image, head) runs
+    // Packed keys (yat_sdpa_*_packed): image b's K / V (and dK / dV) rows are [kv_off[b], kv_off[b] + kv_len[b]) of one
+    // matrix without padding rows; key_bias / kv_len keep their [B, T] / [B] layout.  Null: rows [b T, b T + T).
+    const int* kv_off;
 };
+// first K / V row of image b and the row limit of its keys (rows at or past it read as zero and are never written)
+__device__ __forceinline__ int64_t kv_row0(const SdpaP& p, int b) { return p.kv_off ? (int64_t)p.kv_off[b] : (int64_t)b * p.T; }
+__device__ __forceinline__ int64_t kv_row_limit(const SdpaP& p, int64_t r0, int klim) { return r0 + (p.kv_off ? klim : p.T); }
 
 // ------------------------------------------------------------------------------------------ forward
 // One stage = K (ROW image) + V (TR image) + the 64 key-bias floats.  Two stages in LDS: tile t+1 (and its bias, by
@@ -140,9 +146,10 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
 
+    const int64_t kvr0 = kv_row0(p, b), kvrl = kv_row_limit(p, kvr0, klim);
     auto stage = [&](int k0, char* base) {
-        stage64x128<IMG_ROW>(rk, base, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rv, base + TILE, (int64_t)b * p.T + k0, (int64_t)b * p.T + p.T, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_ROW>(rk, base, kvr0 + k0, kvrl, p.ldkv, col0, p.dh, wave, lane);
+        stage64x128<IMG_TR>(rv, base + TILE, kvr0 + k0, kvrl, p.ldkv, col0, p.dh, wave, lane);
         if (wave == 0) {
             const int key = k0 + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
@@ -275,8 +282,9 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
     const int64_t qlim = (int64_t)b * p.N + p.N;
 
+    const int64_t kvr0 = kv_row0(p, b), kvrl = kv_row_limit(p, kvr0, klim);
     auto stage = [&](int k0, char* base) {
-        const int64_t r0 = (int64_t)b * p.T + k0, rl = (int64_t)b * p.T + p.T;
+        const int64_t r0 = kvr0 + k0, rl = kvrl;
         stage64x128<IMG_TR>(rk, base, r0, rl, p.ldkv, col0, p.dh, wave, lane);
         stage64x128<IMG_ROW>(rv, base + TILE, r0, rl, p.ldkv, col0, p.dh, wave, lane);
         if (wave == 0) {
@@ -407,7 +415,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
 
     if (tile >= ntiles) return;                 // dense-grid fallback only: masked tile, zeros written by its owner below
     // exact zero gradients for the fully masked key tiles of this (b, h): tile t owns tiles t + ntiles, t + 2 ntiles, ...
-    for (int tz = tile + ntiles; tz * KT < p.T; tz += ntiles) {
+    // (packed keys: there are no such rows)
+    for (int tz = tile + ntiles; !p.kv_off && tz * KT < p.T; tz += ntiles) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int kz = tz * KT + wave * (16 * KB) + kb * 16 + li;
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes), rdo = make_rsrc(p.dout, p.do_bytes);
     const uint64_t stat_bytes = p.stat_bytes;
     const __amdgpu_buffer_rsrc_t rlse = make_rsrc(p.lse, stat_bytes), rdel = make_rsrc(p.delta, stat_bytes);
-    const int64_t klimrow = (int64_t)b * p.T + p.T;
+    const int64_t kvr0 = kv_row0(p, b), klimrow = kv_row_limit(p, kvr0, klim);
     bf16x8 kf[KB][KS], vf[KB][KS];
     float kb_[KB];
     bool kvalid[KB];
@@ -436,14 +445,14 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int key = k0 + kb * 16 + li;
-        const int64_t krow = (int64_t)b * p.T + key;
+        const int64_t krow = kvr0 + key;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kf[kb][ks] = frag_global(p.k, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
             vf[kb][ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
         }
-        kvalid[kb] = key < p.T;
-        kb_[kb] = kvalid[kb] ? p.bias[(int64_t)b * p.T + key] : -1e30f;        // keys past T: P = exp2(-huge) = 0
+        kvalid[kb] = krow < klimrow;                // padded layout: key < T; packed: key < kv_len (the next row is another image's)
+        kb_[kb] = key < p.T ? p.bias[(int64_t)b * p.T + key] : -1e30f;        // keys past T: P = exp2(-huge) = 0
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { adk[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
@@ -585,8 +594,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     for (int kb = 0; kb < KB; ++kb) {
         if (!kvalid[kb]) continue;
         const int key = k0 + kb * 16 + li;
-        bf16_t* dkp = p.dk + ((int64_t)b * p.T + key) * p.lddkv + col0;
-        bf16_t* dvp = p.dv + ((int64_t)b * p.T + key) * p.lddkv + col0;
+        bf16_t* dkp = p.dk + (kvr0 + key) * p.lddkv + col0;
+        bf16_t* dvp = p.dv + (kvr0 + key) * p.lddkv + col0;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + 4 * g;
@@ -668,24 +677,24 @@ int launch_dkv(const SdpaP& p, int B, int wide, hipStream_t stream) {
      : (dh) <= 112 ? fn<4, 7>(__VA_ARGS__)                  \
                    : fn<4, 8>(__VA_ARGS__))
 
-int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv) {
-    if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7)) return YAT_EINVAL;
-    if ((uint64_t)B * N * ldq * 2 > 0x7fffffffull || (uint64_t)B * T * ldkv * 2 > 0x7fffffffull) return YAT_EINVAL;
+// kv_rows: rows of the K / V matrices (B * T in the padded layout, the packed row count otherwise)
+int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv, int64_t kv_rows) {
+    if (B <= 0 || N <= 0 || T <= 0 || H <= 0 || dh <= 0 || dh > 128 || (dh & 7) || (ldq & 7) || (ldkv & 7) || kv_rows <= 0)
+        return YAT_EINVAL;
+    if ((uint64_t)B * N * ldq * 2 > 0x7fffffffull || (uint64_t)kv_rows * ldkv * 2 > 0x7fffffffull) return YAT_EINVAL;
     return YAT_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
-                 int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream) {
-    if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 3) || !q || !k || !v || !key_bias || !out) return YAT_EINVAL;
+int sdpa_fwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                  int ldkv, const int* kv_off, int64_t kv_rows, const float* key_bias, const int* kv_len, void* out, int ldo,
+                  float* lse, yat_stream_t stream) {
+    if (check_common(B, N, T, H, dh, ldq, ldkv, kv_rows) || (ldo & 3) || !q || !k || !v || !key_bias || !out) return YAT_EINVAL;
+    if (kv_off && !kv_len) return YAT_EINVAL;          // packed keys: every image says how many rows it owns (all >= 1)
     SdpaP p{};
     p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
-    p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = lse;
-    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
+    p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = lse; p.kv_off = kv_off;
+    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)kv_rows * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
     // XCD-contiguous order only for long uniform key loops (self-attention): with ragged kv_len the images with long
     // captions would pile up on one XCD (measured: T = 300 cross-attention 81 -> 104 us; N = T = 4096 1175 -> 1117 us)
     static const int xcd_env = getenv("YAT_SDPA_XCD") ? atoi(getenv("YAT_SDPA_XCD")) : -1;
@@ -700,21 +709,22 @@ int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     return YAT_SDPA_DISPATCH(launch_fwd, dh, p, B, wide, (hipStream_t)stream);
 }
 
-int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
-                 int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
-                 const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,
-                 int n_work, int parts, yat_stream_t stream) {
-    if (check_common(B, N, T, H, dh, ldq, ldkv) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddkv & 3) || !q || !k || !v ||
-        !key_bias || !out || !dout || !lse || !delta || !dq || !dk || !dv)
+int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                  int ldkv, const int* kv_off, int64_t kv_rows, const float* key_bias, const int* kv_len, const void* out,
+                  int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv,
+                  int lddkv, const int* work_list, int n_work, int parts, yat_stream_t stream) {
+    if (check_common(B, N, T, H, dh, ldq, ldkv, kv_rows) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddkv & 3) || !q || !k ||
+        !v || !key_bias || !out || !dout || !lse || !delta || !dq || !dk || !dv)
         return YAT_EINVAL;
     if ((uint64_t)B * N * lddo * 2 > 0x7fffffffull) return YAT_EINVAL;
+    if (kv_off && !kv_len) return YAT_EINVAL;
     SdpaP p{};
     p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
-    p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = (float*)lse;
+    p.bias = key_bias; p.kv_len = kv_len; p.out = (bf16_t*)out; p.ldo = ldo; p.lse = (float*)lse; p.kv_off = kv_off;
     p.dout = (const bf16_t*)dout; p.lddo = lddo; p.delta = delta; p.dq = (bf16_t*)dq; p.lddq = lddq;
     p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lddkv = lddkv;
-    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)B * T * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
+    p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)kv_rows * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
     p.bias_bytes = (uint64_t)B * T * 4;
     p.stat_bytes = (uint64_t)B * H * N * 4;
     static const int xcd_env = getenv("YAT_SDPA_XCD") ? atoi(getenv("YAT_SDPA_XCD")) : -1;
@@ -741,6 +751,38 @@ int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q,
     if (wide_kv_env >= 0) wide_kv = wide_kv_env;
     if (p.work) wide_kv = 0;
     return YAT_SDPA_DISPATCH(launch_dkv, dh, p, B, wide_kv, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                 int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream) {
+    return sdpa_fwd_impl(B, N, T, H, dh, scale, q, ldq, k, v, ldkv, nullptr, (int64_t)B * T, key_bias, kv_len, out, ldo, lse,
+                         stream);
+}
+int yat_sdpa_fwd_packed(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                        int ldkv, const int* kv_row_offsets, int kv_rows, const float* key_bias, const int* kv_len, void* out,
+                        int ldo, float* lse, yat_stream_t stream) {
+    if (!kv_row_offsets) return YAT_EINVAL;
+    return sdpa_fwd_impl(B, N, T, H, dh, scale, q, ldq, k, v, ldkv, kv_row_offsets, kv_rows, key_bias, kv_len, out, ldo, lse,
+                         stream);
+}
+int yat_sdpa_bwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                 int ldkv, const float* key_bias, const int* kv_len, const void* out, int ldo, const void* dout, int lddo,
+                 const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv, int lddkv, const int* work_list,
+                 int n_work, int parts, yat_stream_t stream) {
+    return sdpa_bwd_impl(B, N, T, H, dh, scale, q, ldq, k, v, ldkv, nullptr, (int64_t)B * T, key_bias, kv_len, out, ldo, dout,
+                         lddo, lse, delta, dq, lddq, dk, dv, lddkv, work_list, n_work, parts, stream);
+}
+int yat_sdpa_bwd_packed(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
+                        int ldkv, const int* kv_row_offsets, int kv_rows, const float* key_bias, const int* kv_len,
+                        const void* out, int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                        void* dk, void* dv, int lddkv, const int* work_list, int n_work, int parts, yat_stream_t stream) {
+    if (!kv_row_offsets) return YAT_EINVAL;
+    return sdpa_bwd_impl(B, N, T, H, dh, scale, q, ldq, k, v, ldkv, kv_row_offsets, kv_rows, key_bias, kv_len, out, ldo, dout,
+                         lddo, lse, delta, dq, lddq, dk, dv, lddkv, work_list, n_work, parts, stream);
 }
 
 }  // extern "C"

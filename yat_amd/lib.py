@@ -68,6 +68,8 @@ SIGNATURES = {
     "yat_linear_attn_bwd": (I, [I, I, I, P, I, I, I, P, I, P, I, P, P, P]),
     "yat_sdpa_fwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, P]),
     "yat_sdpa_bwd": (I, [I, I, I, I, I, F, P, I, P, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P, I, I, P]),
+    "yat_sdpa_fwd_packed": (I, [I, I, I, I, I, F, P, I, P, P, I, P, I, P, P, P, I, P, P]),
+    "yat_sdpa_bwd_packed": (I, [I, I, I, I, I, F, P, I, P, P, I, P, I, P, P, P, I, P, I, P, P, P, I, P, P, I, P, I, I, P]),
     "yat_dwconv_glu_bwd_workspace_bytes": (U64, [I, I, I, I]),
     "yat_dwconv_glu_fwd": (I, [I, I, I, I, P, P, P, P, P, P]),
     "yat_dwconv_glu_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, I, P, P, P]),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "yat_transpose_bf16": (I, [I, I, I, P, P, P]),
     "yat_timestep_embed_fwd": (I, [I, I, P, P, P]),
     "yat_pad_mask": (I, [I, I, I, P, P, P, P, P, P, P]),
+    "yat_pack_mask": (I, [I, I, I, I, P, P, P, P, P, P, P]),
     "yat_flow_mix": (I, [I, I64, P, P, P, P, P, P]),
     "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
     "yat_lokr_rows": (I, [I64, I, I, I, P, P, P, P]),

@@ -449,9 +449,17 @@ def linear_attn_bwd(qkv2d, B, N, H, k_off, v_off, dout, dqkv, workspace, state=N
     return dqkv
 
 
-def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse):
-    """k2d / v2d may be column slices of one fused [B*T, 2*H*dh] projection (same row stride)."""
+def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse, kv_off=None):
+    """k2d / v2d may be column slices of one fused [B*T, 2*H*dh] projection (same row stride).  ``kv_off`` (device int32, one
+    row offset per image): packed keys -- k2d / v2d are the whole [rows, .] matrices without padding rows
+    (include/yat_hip.h: yat_sdpa_fwd_packed)."""
     assert k2d.stride(0) == v2d.stride(0)
+    if kv_off is not None:
+        rc = _lib().yat_sdpa_fwd_packed(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
+                                        _p(kv_off), k2d.shape[0], _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(lse),
+                                        _stream())
+        _l.check(rc, "yat_sdpa_fwd_packed")
+        return out
     rc = _lib().yat_sdpa_fwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                              _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(lse), _stream())
     _l.check(rc, "yat_sdpa_fwd")
@@ -465,9 +473,19 @@ def kv_work_list(lens, T, device):
 
 
 def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv, work=None,
-             parts=3):
-    """parts: 1 = dQ + delta, 2 = dK/dV (after part 1, possibly on another stream), 3 = both."""
+             parts=3, kv_off=None):
+    """parts: 1 = dQ + delta, 2 = dK/dV (after part 1, possibly on another stream), 3 = both.  ``kv_off``: packed keys, as in
+    ``sdpa_fwd`` (dk / dv share the packed row layout; rows outside the images' ranges are left alone)."""
     assert k2d.stride(0) == v2d.stride(0) and dk.stride(0) == dv.stride(0)
+    if kv_off is not None:
+        rc = _lib().yat_sdpa_bwd_packed(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
+                                        _p(kv_off), k2d.shape[0], _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout),
+                                        dout.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0),
+                                        _p(work), 0 if work is None else work.shape[0], parts, _stream())
+        if RECORDER is not None and work is not None:
+            RECORDER.mark_dynamic("n_work", 27)
+        _l.check(rc, "yat_sdpa_bwd_packed")
+        return
     rc = _lib().yat_sdpa_bwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                              _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
                              _p(delta), _p(dq), dq.stride(0), _p(dk), _p(dv), dk.stride(0), _p(work),
@@ -586,6 +604,14 @@ def pad_mask(src_cat, offsets_i32, B, T, Cdim, dst, mask_i64, key_bias_f32, kv_l
     rc = _lib().yat_pad_mask(B, T, Cdim, _p(src_cat), _p(offsets_i32), _p(dst), _p(mask_i64), _p(key_bias_f32),
                              _p(kv_len_i32), _stream())
     _l.check(rc, "yat_pad_mask")
+
+
+def pack_mask(src_cat, offsets_i32, B, T, Cdim, dst_packed, mask_i64, key_bias_f32, kv_len_i32):
+    """The text rows WITHOUT padding rows: dst_packed [rows_padded, C] = the source rows, then zero rows; mask / key bias /
+    kv_len as ``pad_mask`` writes them (include/yat_hip.h: yat_pack_mask)."""
+    rc = _lib().yat_pack_mask(B, T, Cdim, dst_packed.shape[0], _p(src_cat), _p(offsets_i32), _p(dst_packed), _p(mask_i64),
+                              _p(key_bias_f32), _p(kv_len_i32), _stream())
+    _l.check(rc, "yat_pack_mask")
 
 
 def flow_mix(x, noise, sigma_bf16, noisy=None, target=None):

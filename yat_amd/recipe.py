@@ -11,6 +11,8 @@ buffer, ONE H2D copy and one ``yat_pad_mask`` launch; ``get_sigmas``' B device->
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -140,16 +142,41 @@ class SanaRecipe:
         loss = _MseLoss.apply(pred, target, self._mse_ws)
         return (loss, pred, target) if return_pred else loss
 
-    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out, kv_work=None, gscale=1.0):
+    # ---- packed text rows (no padding rows through the text-side GEMMs; SanaTransformer2DModelHIP.forward_impl)
+    TEXT_ROW_PAD = 256          # the packed matrix ends in fewer than this many zero rows (one GEMM tile of rows)
+
+    def packs_text(self, lens):
+        """May this batch take the packed text layout?  The model must accept it, no adapter may be wrapped around it (their
+        per-target buffers follow the padded shapes), and every prompt needs a row (a prompt of length 0 attends uniformly to
+        the padding rows in the reference -- only the padded layout has them).  ``YAT_TEXT_PACK=0`` switches it off."""
+        if os.environ.get("YAT_TEXT_PACK", "1") == "0" or not getattr(self.model, "packed_text", False):
+            return False
+        return getattr(self.model, "adapters", None) is None and min(lens) >= 1
+
+    def packed_rows(self, rows):
+        return -(-rows // self.TEXT_ROW_PAD) * self.TEXT_ROW_PAD
+
+    def packed_enc(self, B, T, C, rows):
+        """[packed_rows(rows), C] view of one persistent buffer sized for B * T rows (its address never moves)."""
+        cap = self.packed_rows(B * T)
+        buf = getattr(self, "_packed_buf", None)
+        if buf is None or buf.shape != (cap, C):
+            buf = self._packed_buf = torch.empty(cap, C, dtype=BF16, device=self.dev)
+        return buf[:self.packed_rows(rows)]
+
+    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, sigmas, loss_out, kv_work=None, gscale=1.0,
+                          kv_off=None):
         """Graph-friendly straight-line step on device-resident inputs: forward, loss+dL/dpred, backward.
-        Used by bench.py and the trainer fast path (no autograd objects, no allocation besides pred)."""
+        Used by bench.py and the trainer fast path (no autograd objects, no allocation besides pred).
+        ``kv_off``: ``enc`` is the packed text matrix (``ops.pack_mask``), see ``forward_impl``."""
         bias, kvl = mask_bias_kvl
         noisy, target = ops.flow_mix(latents, noise, sigmas, self._noisy(latents), self._target(latents))
         dev_path = hasattr(self.model, "forward_device")
+        packed = {} if kv_off is None else {"kv_off": kv_off}
         if dev_path:
-            pred = self.model.forward_device(noisy, enc, timesteps, bias, kvl, kv_work=kv_work)
+            pred = self.model.forward_device(noisy, enc, timesteps, bias, kvl, kv_work=kv_work, **packed)
         else:
-            pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
+            pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work, **packed)
         dpred = self._dpred(pred)
         ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws, gscale=gscale)
         if dev_path:
@@ -209,10 +236,15 @@ class SanaRecipe:
                                    torch.empty(B, dtype=torch.int32, device=self.dev),
                                    torch.zeros(1, dtype=torch.float32, device=self.dev))
         enc, mask, bias, kvl, loss_out = fixed
-        ops.pad_mask(dseg(o_emb, 2 * rows * C, BF16).view(rows, C), dseg(o_off, 4 * (B + 1), torch.int32), B, T, C, enc, mask,
-                     bias, kvl)                                                                                          # :168-180
+        src_d, off_d, kv_off = dseg(o_emb, 2 * rows * C, BF16).view(rows, C), dseg(o_off, 4 * (B + 1), torch.int32), None
+        if self.packs_text(lens):
+            enc, kv_off = self.packed_enc(B, T, C, rows), off_d[:B]
+            ops.pack_mask(src_d, off_d, B, T, C, enc, mask, bias, kvl)                                                   # :168-180,
+        else:                                                                                    # minus the padding rows
+            ops.pad_mask(src_d, off_d, B, T, C, enc, mask, bias, kvl)                                                    # :168-180
         self.train_step_device(lat_d, enc, (bias, kvl), noise_d, dseg(o_t, 4 * B, torch.float32), dseg(o_sig, 2 * B, BF16),
-                               loss_out, kv_work=dseg(o_work, 8 * len(pairs), torch.int32).view(len(pairs), 2), gscale=gscale)
+                               loss_out, kv_work=dseg(o_work, 8 * len(pairs), torch.int32).view(len(pairs), 2), gscale=gscale,
+                               kv_off=kv_off)
         return loss_out[0].clone()
 
     def _scratch(self, name, like):

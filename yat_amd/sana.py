@@ -182,14 +182,19 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         return (self.side_wgrad, self.keep_glu_u, self.fwd_chains, self.group_big_wgrad, self.group_small_wgrad,
                 self.defer_wgrad, self.grouped_wgrad, self.training)
 
-    def forward_device(self, latents, enc, timestep, key_bias, kv_len, kv_work=None):
+    packed_text = True         # forward_device / forward_impl accept the text rows without padding (``kv_off``)
+
+    def forward_device(self, latents, enc, timestep, key_bias, kv_len, kv_work=None, kv_off=None):
         """``forward_impl`` on device-resident inputs in persistent buffers, replayed from a launch plan when this (shapes,
-        addresses, schedule) combination has run before.  The prediction is an arena buffer: consume it before the next call."""
+        addresses, schedule) combination has run before.  The prediction is an arena buffer: consume it before the next call.
+        ``kv_off`` (device int32 row offsets, one per image): ``enc`` is the packed [rows, C] text matrix -- the prompts'
+        rows back to back, then fewer than 256 zero rows (see ``forward_impl``); the plan key then carries the row count."""
         pev = self.param_events
         key = (latents.data_ptr(), tuple(latents.shape), enc.data_ptr(), tuple(enc.shape), timestep.data_ptr(),
-               key_bias.data_ptr(), kv_len.data_ptr(), None if pev is None else id(pev[0]), self._schedule_flags())
+               key_bias.data_ptr(), kv_len.data_ptr(), None if kv_off is None else kv_off.data_ptr(),
+               None if pev is None else id(pev[0]), self._schedule_flags())
         out = self.planned("fwd", key, lambda: self.forward_impl(latents, enc, timestep, None, key_bias=key_bias,
-                                                                 kv_len=kv_len, kv_work=kv_work))
+                                                                 kv_len=kv_len, kv_work=kv_work, kv_off=kv_off))
         self.param_events = None          # consumed by the forward (recorded or replayed)
         self._saved.kv_work = kv_work
         return out
@@ -204,14 +209,24 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         self.planned("bwd", key, lambda: self.backward_impl(dpred))
 
     # ------------------------------------------------------------------ forward
-    def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None, kv_work=None):
+    def forward_impl(self, latents, enc, timestep, mask=None, key_bias=None, kv_len=None, kv_work=None, kv_off=None):
+        """``kv_off`` None: ``enc`` is the reference's padded [B, T, C] batch (train_sana.py:168-180).  Otherwise ``enc`` is the
+        PACKED text matrix [Mt, C]: image b's prompt occupies rows [kv_off[b], kv_off[b] + kv_len[b]) (kv_len >= 1), rows past
+        the last prompt are zero and there are fewer than 256 of them; ``key_bias`` [B, T] / ``kv_len`` as before.  The
+        padding rows the reference carries through the caption projection and every block's K / V projection never reach a
+        result -- their keys get the -10000 bias, probability exactly 0, gradient exactly 0 -- so the text side runs on the
+        real rows only: same prediction bit for bit, text-side GEMMs over ~Sum(len) instead of B * 512 rows."""
         cfg, P = self.cfg, self.P
         D, Hc, H1, H2, dh2 = cfg.inner_dim, cfg.ffn_hidden, cfg.num_attention_heads, cfg.num_cross_attention_heads, \
             cfg.cross_attention_head_dim
         B, Cin, h, w = latents.shape
         N, M = h * w, B * h * w
-        T = enc.shape[1]
-        Mt = B * T
+        packed = kv_off is not None
+        if packed and (key_bias is None or kv_len is None or enc.dim() != 2):
+            raise ValueError("packed text: enc [rows, C] with key_bias [B, T], kv_len [B] and kv_off [B]")
+        T = key_bias.shape[1] if packed else enc.shape[1]
+        Mt = enc.shape[0] if packed else B * T
+        Mt_cap = max(B * T, Mt)                    # text-side buffers are sized once, for the padded layout
         Cout = cfg.out_channels
         dev = self.dev
         latents = latents.to(device=dev, dtype=BF16).contiguous()
@@ -227,9 +242,14 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 key_bias = ((1 - mdev.to(BF16)) * -10000.0).float().contiguous()
                 idx = torch.arange(1, T + 1, device=dev, dtype=torch.int32)
                 kv_len = (mdev.to(torch.int32) * idx).amax(dim=1).to(torch.int32).contiguous()
-        S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, key_bias=key_bias, kv_len=kv_len, kv_work=kv_work,
-                            enc2d=enc2d, blocks=[])
+        S = SimpleNamespace(B=B, h=h, w=w, N=N, M=M, T=T, Mt=Mt, Mt_cap=Mt_cap, key_bias=key_bias, kv_len=kv_len,
+                            kv_work=kv_work, kv_off=kv_off, enc2d=enc2d, blocks=[])
         buf = self._buf
+
+        def tbuf(name, cols, dtype=BF16):
+            """text-side activation [Mt, cols]: the first rows of a buffer sized for the padded layout, so a batch with more
+            text rows finds it at the same address (recorded launch plans hold addresses)"""
+            return buf(name, (Mt_cap, cols), dtype)[:Mt] if cols else buf(name, (Mt_cap,), dtype)[:Mt]
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None      # per-bucket events of an AdamW update still in flight
@@ -253,13 +273,13 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         # stream until the first cross-attention: it runs on the second stream, filling CUs the single-round GEMMs of
         # the main chain leave idle.
         def text_branch():
-            S.zc1 = buf("cap_z1", (Mt, D))
+            S.zc1 = tbuf("cap_z1", D)
             S.c1 = lin(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
-                                  out=buf("cap_c1", (Mt, D)), activation="gelu_tanh", aux_out=S.zc1)
+                                  out=tbuf("cap_c1", D), activation="gelu_tanh", aux_out=S.zc1)
             S.c2 = lin(S.c1, P["caption_projection.linear_2.weight"], P["caption_projection.linear_2.bias"],
-                                  out=buf("cap_c2", (Mt, D)))
-            S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, buf("cap_n", (Mt, D)),
-                                                 buf("cap_rstd", (Mt,), torch.float32))
+                                  out=tbuf("cap_c2", D))
+            S.encn, S.enc_rstd = ops.rmsnorm_fwd(S.c2, P["caption_norm.weight"], 1e-5, tbuf("cap_n", D),
+                                                 tbuf("cap_rstd", 0, torch.float32))
             S.kv2, S.kv_ready = [], []
             cur = torch.cuda.current_stream()
             for i in range(cfg.num_layers):
@@ -267,7 +287,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 params_ready(i + 1, cur)
                 wkv, _ = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
                 bkv, _ = self._fused(pre + "attn2.to_k.bias", 2 * D)
-                S.kv2.append(lin(S.encn, wkv, bkv, out=buf(f"b{i}.kv2", (Mt, 2 * D))))
+                S.kv2.append(lin(S.encn, wkv, bkv, out=tbuf(f"b{i}.kv2", 2 * D)))
                 if side is not None:
                     S.kv_ready.append(self._ev_record(cur))
 
@@ -358,9 +378,9 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 lin(A.x1[rs], P[pre + "attn2.to_q.weight"], P[pre + "attn2.to_q.bias"], out=A.q2[rs])
                 if side is not None:
                     self._ev_wait(stream, S.kv_ready[i])
-                kv = A.kv2[ts]
+                kv = A.kv2 if packed else A.kv2[ts]          # packed: the whole matrix + this chain's row offsets
                 ops.sdpa_fwd(A.q2[rs], kv[:, :D], kv[:, D:], nb, N, T, H2, dh2, scale2, key_bias[bs], kv_len[bs], A.o2[rs],
-                             A.lse[bs])
+                             A.lse[bs], kv_off=kv_off[bs] if packed else None)
                 lin(A.o2[rs], P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"], out=A.x2[rs],
                                residual=A.x1[rs])
                 ops.ln_modulate_fwd(A.x2[rs], mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, A.h2[rs],
@@ -413,8 +433,12 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         Cout, Cin = cfg.out_channels, cfg.in_channels
         acc = self.accumulate_grads
         buf = self._buf
+        packed, Mt_cap = S.kv_off is not None, S.Mt_cap
+
+        def tbuf(name, cols, dtype=BF16):
+            return buf(name, (Mt_cap, cols), dtype)[:Mt]
         f32, u8 = torch.float32, torch.uint8
-        ws_col = buf("ws_col", (int(ops._lib().yat_colsum_workspace_bytes(max(M, Mt), max(2 * Hc, 6 * D, 3 * D))),), u8)
+        ws_col = buf("ws_col", (int(ops._lib().yat_colsum_workspace_bytes(max(M, Mt_cap), max(2 * Hc, 6 * D, 3 * D))),), u8)
         ws_ln = buf("ws_ln", (ops.ln_bwd_workspace_bytes(M, D, N),), u8)
         ws_gate = buf("ws_gate", (int(ops._lib().yat_gate_bwd_workspace_bytes(M, D, N)),), u8)
         ws_dw = buf("ws_dw", (ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc),), u8)
@@ -486,7 +510,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         dx = ops.ln_modulate_bwd(S.x_last, S.meanf, S.rstdf, S.modf.view(B, 2 * D)[:, D:2 * D], 2 * D, N, dhf, None, dxa,
                                  dmodf2d[:, 0:D], dmodf2d[:, D:2 * D], 2 * D, ws_ln)
         ops.modulation_bwd(dmodf, G["scale_shift_table"], demb, 0, accumulate_table=acc)
-        denc = buf("denc", (Mt, D))
+        denc = tbuf("denc", D)
         # ---- blocks, last to first.  A block's seven weight gradients are deferred to its end and go out as ONE grouped
         # GEMM launch on the side stream (~1240 full-K 256x256 tiles = 4.85 rounds of the 256 CUs, instead of seven
         # launches of 81..396 tiles, three of them split-K); the gradient buffers they read alternate between two sets
@@ -566,14 +590,23 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             emit(dx2, A.o2, G[pre + "attn2.to_out.0.weight"], G[pre + "attn2.to_out.0.bias"], group=True)
             do2 = dgrad(dx2, P[pre + "attn2.to_out.0.weight"], out=buf(f"do2.{par}", (M, D)))
             dq2 = buf(f"dq2.{par}", (M, D))
-            dkv2 = buf(f"dkv2.{par}", (Mt, 2 * D))
+            dkv2 = tbuf(f"dkv2.{par}", 2 * D)
             delta = buf(f"delta.{par}", (B, H2, N), f32)
             sd = (A.q2, A.kv2[:, :D], A.kv2[:, D:], B, N, T, H2, dh2, scale2, S.key_bias, S.kv_len, A.o2, do2, A.lse, delta,
                   dq2, dkv2[:, :D], dkv2[:, D:])
+
+            def dkv_part(parts, sd=sd, dkv2=dkv2):
+                if packed:
+                    # the zero rows behind the last prompt (< 256 of them) belong to no image: dK/dV leaves them alone, the
+                    # text-side GEMMs read them -- zero the last 256 rows first (the real ones among them are rewritten)
+                    ops.zero_(dkv2[max(0, Mt - 256):])
+                ops.sdpa_bwd(*sd, work=S.kv_work, parts=parts, kv_off=S.kv_off)
             # cross-attention backward: dQ (+delta) on the chain, dK/dV -- read only by the text-side gradients -- behind it
-            ops.sdpa_bwd(*sd, work=S.kv_work, parts=1 if side is not None else 3)
             if side is not None:
-                off_chain(lambda sd=sd: ops.sdpa_bwd(*sd, work=S.kv_work, parts=2))
+                ops.sdpa_bwd(*sd, work=S.kv_work, parts=1, kv_off=S.kv_off)
+                off_chain(lambda dkv_part=dkv_part: dkv_part(2))
+            else:
+                dkv_part(3)
             emit(dq2, A.x1, G[pre + "attn2.to_q.weight"], G[pre + "attn2.to_q.bias"], group=True)
             dx1 = dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
@@ -662,8 +695,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             side = None
         wgrad(dx, S.x_tok, "patch_embed.proj.weight", (D, Cin), "patch_embed.proj.bias")
         # caption branch
-        dc2 = buf("dc2", (Mt, D))
-        ws_rms = buf("ws_rms", (int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(Mt, D)),), u8)
+        dc2 = tbuf("dc2", D)
+        ws_rms = buf("ws_rms", (int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(Mt_cap, D)),), u8)
         ops.rmsnorm_bwd(S.c2, P["caption_norm.weight"], S.enc_rstd, denc, dc2, G["caption_norm.weight"], ws_rms,
                         accumulate_dw=acc)
         wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D), "caption_projection.linear_2.bias")
