@@ -199,7 +199,7 @@ def run_from_shards(args, rank, world, local_rank):
         cfg = trainer.model.cfg
         # text rows computed per image: the prompts' own lengths (uniform 20..300 in the synthetic shards, mean 160) when
         # the recipe packs the text rows, the reference's 512 otherwise
-        trows = 160.0 if (os.environ.get("YAT_TEXT_PACK", "1") != "0" and not (args.lokr or args.lora)) else 512
+        trows = 160.0 if os.environ.get("YAT_TEXT_PACK", "1") != "0" else 512
         flops = B * sum(train_flops_per_image(cfg, h * w, trows) for h, w in BUCKETS) / len(BUCKETS)
         print(json.dumps({
             "metric": "images/sec (whole node) SANA-1.6B 1024px bf16 training step", "value": world * B * args.steps / elapsed,
@@ -333,7 +333,7 @@ def main():
 
     def stage_text(b):
         """pad + mask (train_sana.py:168-180): packed text rows (no padding rows through the text-side GEMMs, see
-        SanaRecipe.packs_text / SanaTransformer2DModelHIP.forward_impl) unless YAT_TEXT_PACK=0 or an adapter is wrapped"""
+        SanaRecipe.packs_text / SanaTransformer2DModelHIP.forward_impl) unless YAT_TEXT_PACK=0"""
         if recipe.packs_text(b["lens"]):
             enc_b = recipe.packed_enc(B, T, Cc, b["rows"])
             ops.pack_mask(b["src"], b["offsets"], B, T, Cc, enc_b, mask, bias, kvl)

@@ -146,12 +146,13 @@ class SanaRecipe:
     TEXT_ROW_PAD = 256          # the packed matrix ends in fewer than this many zero rows (one GEMM tile of rows)
 
     def packs_text(self, lens):
-        """May this batch take the packed text layout?  The model must accept it, no adapter may be wrapped around it (their
-        per-target buffers follow the padded shapes), and every prompt needs a row (a prompt of length 0 attends uniformly to
-        the padding rows in the reference -- only the padded layout has them).  ``YAT_TEXT_PACK=0`` switches it off."""
+        """May this batch take the packed text layout?  The model must accept it and every prompt needs a row (a prompt of
+        length 0 attends uniformly to the padding rows in the reference -- only the padded layout has them).  Adapters ride
+        along: their products follow the row count of whatever activation they are handed.  ``YAT_TEXT_PACK=0`` switches it
+        off."""
         if os.environ.get("YAT_TEXT_PACK", "1") == "0" or not getattr(self.model, "packed_text", False):
             return False
-        return getattr(self.model, "adapters", None) is None and min(lens) >= 1
+        return min(lens) >= 1
 
     def packed_rows(self, rows):
         return -(-rows // self.TEXT_ROW_PAD) * self.TEXT_ROW_PAD
