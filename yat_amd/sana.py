@@ -545,14 +545,17 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 if ad is not None:        # frozen base: adapter gradients only, launched by the dgrad() of the same dy
                     pending_ad.append((dy_, x_, gw_))
                     return
-                if self.defer_wgrad or side is None:
-                    deferred.append((dy_, x_, gw_))
+                if self.defer_wgrad:
+                    deferred.append((dy_, x_, gw_, bias))
+                    return
+                if group is True and self.group_small_wgrad:      # (also without a side stream: one launch instead of three
+                    small.append((dy_, x_, gw_, bias))            #  split-K ones -- the serialized pass runs the step's kernels)
+                    return
+                if side is None:
+                    deferred.append((dy_, x_, gw_, bias))
                     return
                 if group == "big" and self.group_big_wgrad:
                     big.append((dy_, x_, gw_, bias))
-                    return
-                if group is True and self.group_small_wgrad:
-                    small.append((dy_, x_, gw_, bias))
                     return
 
                 def run():
@@ -663,13 +666,13 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 if deferred:
                     if self.grouped_wgrad:
                         # largest K first: the short tiles (text side, K = B*T) fill the tail
-                        ops.wgrad_grouped(sorted(deferred, key=lambda it: -it[0].shape[0]), accumulate=acc)
+                        ops.wgrad_grouped(sorted([it[:3] for it in deferred], key=lambda it: -it[0].shape[0]), accumulate=acc)
                     else:
-                        for dy_, x_, gw_ in deferred:
+                        for dy_, x_, gw_, _ in deferred:
                             ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
-                    ops.colsum(dx2, G[pre + "attn2.to_out.0.bias"], ws_col, accumulate=acc)
-                    ops.colsum(dq2, G[pre + "attn2.to_q.bias"], ws_col, accumulate=acc)
-                    ops.colsum(dkv2, gbkv, ws_col, accumulate=acc)
+                    for dy_, _, _, bias_ in deferred:             # attn2.to_out / to_q (unless grouped above) / to_k|to_v
+                        if bias_ is not None:
+                            ops.colsum(dy_, bias_, ws_col, accumulate=acc)
                 # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
                 dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
 
