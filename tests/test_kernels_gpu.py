@@ -114,6 +114,38 @@ def test_gemm_tn_wgrad(ops, M, N, K):
     close(dw, (rb(ref) + rb(ref)).to(BF), f"gemm_tn_acc {M}x{N}x{K}")
 
 
+def test_gemm_skinny_long_k(ops):
+    """Skinny outputs with a long reduction take the K-split path of the 256-row kernel (csrc/gemm.hip: `skinny`): the
+    embedders' M = B rows (time_embed.linear forward / dgrad at SANA width) and the 32-channel patch-embedding / output-head
+    weight gradients over 8192 tokens -- all three layouts, with the epilogues those calls carry."""
+    B, D = 8, 2240
+    x, w, bias = rnd(B, D, seed=1), rnd(6 * D, D, scale=D ** -0.5, seed=2), rnd(6 * D, seed=3)
+    y = ops.linear_fwd(x, w, bias)                                                   # nn 8 x 13440 x 2240
+    close(y, (x.float() @ w.float().T + bias.float()).to(BF), "skinny fwd 8x13440x2240")     # one rounding, like torch's addmm
+    z = torch.empty(B, D, dtype=BF, device=DEV)
+    w2, b2 = rnd(D, D, scale=D ** -0.5, seed=4), rnd(D, seed=5)
+    e = ops.linear_fwd(x, w2, b2, activation="silu", aux_out=z)                      # nn 8 x 2240 x 2240 + bias + SiLU + aux
+    zr = (x.float() @ w2.float().T + b2.float()).to(BF)
+    close(z, zr, "skinny fwd pre-activation")
+    close(e, torch.nn.functional.silu(zr.float()).to(BF), "skinny fwd SiLU")
+    dy = rnd(B, 6 * D, seed=6)
+    dx = ops.linear_dgrad(dy, w)                                                     # nt 8 x 2240 x 13440
+    close(dx, (dy.float() @ w.float()).to(BF), "skinny dgrad 8x2240x13440")
+    M, C = 8192, 32
+    g, t = rnd(M, D, scale=M ** -0.5, seed=7), rnd(M, C, seed=8)
+    dw = torch.empty(D, C, dtype=BF, device=DEV)
+    ops.linear_wgrad(g, t, dw)                                                       # tt 2240 x 32 x 8192
+    ref = g.float().T @ t.float()
+    close(dw, ref.to(BF), "skinny wgrad 2240x32x8192")
+    ops.linear_wgrad(g, t, dw, accumulate=True)
+    close(dw, (rb(ref) + rb(ref)).to(BF), "skinny wgrad accumulate")
+    g2, t2 = rnd(M, C, scale=M ** -0.5, seed=9), rnd(M, D, seed=10)
+    dw2, db2 = torch.empty(C, D, dtype=BF, device=DEV), torch.empty(C, dtype=BF, device=DEV)
+    ops.linear_wgrad(g2, t2, dw2, bias_grad=db2)                                     # tt 32 x 2240 x 8192 + bias gradient
+    close(dw2, (g2.float().T @ t2.float()).to(BF), "skinny wgrad 32x2240x8192")
+    close(db2, g2.float().sum(0).to(BF), "skinny wgrad bias gradient", tol=4e-3, ulps=3.0)
+
+
 def test_gemm_grouped_wgrad(ops):
     """yat_gemm_grouped_bf16: several dW = dy^T x of different shapes (ragged tiles, different K) in one launch are
     bit-identical to the same problems launched one by one on the 256x256 tile, plain and accumulating."""

@@ -304,10 +304,18 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         // (N >= 256: one 256/320-wide column tile is fine when K is long enough to split -- the [out, in_m*r] weight
         //  gradients of the factored LoKr path are 2240 x 320 x 32768: 9 tiles, split 28 ways)
         static const int min_n256 = getenv("YAT_GEMM_MIN_N256") ? atoi(getenv("YAT_GEMM_MIN_N256")) : 256;
-        if (M >= 1024 && (N >= 512 || (N >= min_n256 && K >= 2048) || (N >= 256 && K >= 8192)) && K >= 256) {
+        const bool big = M >= 1024 && (N >= 512 || (N >= min_n256 && K >= 2048) || (N >= 256 && K >= 8192)) && K >= 256;
+        // Skinny outputs with a long reduction -- the embedders' M = B rows (time_embed.linear dgrad: 8 x 2240 x 13440), the
+        // patch-embedding / output-head weight gradients (32 channels x 2240 x 8192 tokens): on the 128 x 128 kernel they are
+        // 18 workgroups walking 128..210 k-tiles each (150..250 us with the chip idle, at the head of the forward and the tail
+        // of the backward); split along K on the 256-row kernel (mostly zero-filled tile, but the launch is bound by reading
+        // the weight) they are ~7 tiles x 16..26 slices.  Only with a split: unsplit, the small kernel is the better one.
+        static const bool skinny_on = !(getenv("YAT_GEMM_SKINNY") && !atoi(getenv("YAT_GEMM_SKINNY")));
+        const bool skinny = skinny_on && !big && K >= 2048 && M >= 8 && N >= 32;
+        if (big || skinny) {
             double best = est_time_128(M, N, K);
             for (int v = 4; v <= 5; ++v)
-                for (int s = 1; s <= max_ksplit; s = pow2_only ? s * 2 : s + 1) {
+                for (int s = skinny ? 2 : 1; s <= max_ksplit; s = pow2_only ? s * 2 : s + 1) {
                     // any factor, not only powers of two: what matters is tiles x s against the 256 CUs (75 tiles x 3 = 225
                     // fills one round; x 2 leaves 106 CUs idle, x 4 spills into a second round)
                     if (s > 1 && p.pre_add) continue;
