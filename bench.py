@@ -201,7 +201,7 @@ def run_from_shards(args, rank, world, local_rank):
         # the recipe packs the text rows, the reference's 512 otherwise
         trows = 160.0 if os.environ.get("YAT_TEXT_PACK", "1") != "0" else 512
         flops = B * sum(train_flops_per_image(cfg, h * w, trows) for h, w in BUCKETS) / len(BUCKETS)
-        print(json.dumps({
+        emit_json({
             "metric": "images/sec (whole node) SANA-1.6B 1024px bf16 training step", "value": world * B * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -212,7 +212,7 @@ def run_from_shards(args, rank, world, local_rank):
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": 1024, "parallelism": f"dp{world}",
                        "num_layers": cfg.num_layers, "params": trainer.model.numel_flat},
             "loss": loss_val, "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-            "mfma_util_step": flops / (elapsed / args.steps) / (PEAK_BF16_TFLOPS * 1e12)}))
+            "mfma_util_step": flops / (elapsed / args.steps) / (PEAK_BF16_TFLOPS * 1e12)})
     import shutil
     if world > 1:
         dist.barrier()
@@ -220,7 +220,24 @@ def run_from_shards(args, rank, world, local_rank):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def emit_json(obj):
+    """The ONE line on the real stdout (see ``main``: fd 1 is pointed at stderr for everything else)."""
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
+_JSON_OUT = None
+
+
 def main():
+    # stdout carries exactly one JSON line.  Libraries do not know that: RCCL prints its version block on stdout when the
+    # first communicator is built (seen with a forced one-rank group), which would land in front of the line the driver
+    # parses.  Keep a private handle on the real stdout for the JSON line and point fd 1 at stderr for everyone else.
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -371,10 +388,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The step runs on a high-priority stream: the side streams (weight gradients, AdamW) keep priority 0, so the
-    # dependent chain gets the CUs first whenever a long weight-gradient workgroup retires.
-    if os.environ.get("YAT_HP_MAIN", "0") != "0":          # measured: no gain (99.9 vs 100.4 ms), off by default
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+    # The step runs on a stream of the compute-stream set (high priority level, one hardware queue each) rather than on the
+    # default stream, which shares its hardware queue with whatever else the process creates -- with a process group around
+    # that was the weight-gradient and optimizer streams, and the step lost 16 ms ("hardware queues").
+    from yat_amd.flat import compute_stream, isolate_streams
+    if os.environ.get("YAT_HP_MAIN", "1") != "0" and isolate_streams():      # (only with a process group around)
+        hp = compute_stream(dev)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     log("inputs resident; warm-up")
     for i in range(args.warmup):
         step(i)
@@ -546,7 +567,7 @@ def main():
             except Exception as e:  # the baseline is a reported side number; never let it sink the bench line
                 res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": usable_cores(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(res))
+        emit_json(res)
     if world > 1:
         dist.destroy_process_group()
 

@@ -110,6 +110,30 @@ class HipAccelerator:
             dist.barrier()
 
 
+@contextlib.contextmanager
+def _step_stream(dev):
+    """Run the step loop on a stream of the compute-stream set (yat_amd/flat.py ``compute_stream``) instead of the default
+    stream.  The HIP runtime multiplexes streams onto a handful of hardware queues per priority level, and two streams that
+    land on one hardware queue run their kernels strictly one after the other: with the process group's and the copy
+    engine's streams around, the default stream shared a queue with the weight-gradient and optimizer streams and the step
+    lost 16 ms ("hardware queues").  In a data-parallel job the compute streams are therefore the only
+    users of the high-priority level -- four streams, four queues; without a process group nothing changes
+    (``flat.isolate_streams``).  ``YAT_HP_MAIN=0`` keeps the default stream."""
+    from ..flat import compute_stream, isolate_streams
+    if torch.device(dev).type != "cuda" or os.environ.get("YAT_HP_MAIN", "1") == "0" or not isolate_streams():
+        yield
+        return
+    prev = torch.cuda.current_stream(dev)
+    st = compute_stream(dev)
+    st.wait_stream(prev)
+    torch.cuda.set_stream(st)
+    try:
+        yield
+    finally:
+        prev.wait_stream(st)
+        torch.cuda.set_stream(prev)
+
+
 class Model:
     def __init__(self, params, accelerator: HipAccelerator | None = None):
         # NCCL_P2P_DISABLE / NCCL_IB_DISABLE of the reference (:27-28) are deliberately NOT set: xGMI needs P2P.
@@ -297,6 +321,10 @@ class Model:
         p = self.params
         self.initialize()
         dev = self.accelerator.device
+        with _step_stream(dev):
+            return self._run(p, dev, max_steps, on_step)
+
+    def _run(self, p, dev, max_steps, on_step):
         avg_loss = torch.zeros((), device=dev)
         self.accelerator.wait_for_everyone()
         if self.empty_embeddings is None and p.train_unconditional_prob > 0:       # :306-308

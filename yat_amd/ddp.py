@@ -117,7 +117,9 @@ class HipDDP:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if rccl:
+                if rccl and os.environ.get("YAT_DDP_DRYRUN", "0") != "0":
+                    pass      # diagnostic: the whole machinery (hooks, events, streams) without the collective itself
+                elif rccl:
                     self._works.append(dist.all_reduce(chunk, op=op, group=self.pg, async_op=True))
                 else:       # one-GPU rehearsal over gloo (device tensors staged through the host): sum, then the mean
                     dist.all_reduce(chunk, op=op, group=self.pg)

@@ -23,6 +23,29 @@ class _Node(nn.Module):
     """Anonymous container so parameter names can carry the diffusers dotted paths."""
 
 
+def isolate_streams():
+    """Should the step's compute streams live on the high-priority level?  Only when a process group exists (data-parallel
+    job, or the forced one-rank rehearsal): that is when the streams of the process group and of the copy engine crowd the
+    normal level's hardware queues.  Alone, the step's four streams get a hardware queue each at the normal level anyway,
+    and the trainer fed from shards was measured SLOWER with high-priority streams (84 -> 107 ms).
+    ``YAT_STREAM_PRIORITY`` = 0 | -1 overrides."""
+    env = os.environ.get("YAT_STREAM_PRIORITY")
+    if env is not None:
+        return int(env) != 0
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def compute_stream(device):
+    """A HIP stream for the step's compute (dependent chain, second forward chain, weight-gradient stream, optimizer stream).
+    The HIP runtime multiplexes streams onto a few hardware queues PER PRIORITY LEVEL, and two streams on one hardware queue
+    run their kernels strictly one after the other.  In a data-parallel job the normal level is shared with every stream
+    torch, the process group and the copy engine create -- the default stream, the weight-gradient stream and the optimizer
+    stream were found on ONE hardware queue, 16 ms per step lost -- so there the four compute streams move to the high level,
+    whose only users they are: four streams, four queues ("hardware queues")."""
+    return torch.cuda.Stream(device=device, priority=-1 if isolate_streams() else 0)
+
+
 class FlatParamModule(nn.Module):
     def _alloc_flat(self, specs, device):
         """``specs``: [(diffusers key, shape)] in forward-execution order."""
@@ -203,10 +226,10 @@ class FlatParamModule(nn.Module):
 
     def _chain_stream(self, c):
         if c not in self._chains:
-            self._chains[c] = torch.cuda.Stream(device=self.flat_param.device)
+            self._chains[c] = compute_stream(self.flat_param.device)
         return self._chains[c]
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat_param.device)
+            self._side = compute_stream(self.flat_param.device)
         return self._side

@@ -87,7 +87,8 @@ class FlatAdamW:
             return
         m.join_pending_update()
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=m.flat_param.device)
+            from .flat import compute_stream
+            self._stream = compute_stream(m.flat_param.device)
         main = torch.cuda.current_stream()
         self._stream.wait_stream(main)
         # one persistent event per bucket, re-recorded every step: the next forward's waits are then the same calls on
