@@ -274,9 +274,10 @@ def test_launch_plan_replay_is_bit_identical():
     (l_a, p_a, replays, nplans), (l_b, p_b, r_b, n_b) = runs
     print(f"[plans] {nplans} plans recorded, {replays} replays; losses {l_a.tolist()}")
     assert r_b == 0 and n_b == 0
-    # step 0 records without optimizer events, steps 1-2 record the steady-state plans of the two buckets (fwd + bwd each);
-    # with the text rows packed (the default) a plan is also keyed by the packed row count: 256 or 512 rows here
-    assert replays >= 4 and nplans <= 2 + 2 * 2 * 2
+    # step 0 records without optimizer events, steps 1-2 record the steady-state plans of the two buckets (fwd + bwd each).
+    # The text rows are packed (the default) and their count -- 256 or 512 rows here, changing from step to step -- is a
+    # dynamic integer of the plan (ops.text_rows), not part of its key: the replays below patch it.
+    assert replays >= 2 * 4 and nplans <= 8
     assert torch.equal(l_a, l_b) and torch.equal(p_a, p_b)
 
 

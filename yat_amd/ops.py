@@ -6,6 +6,7 @@ that entry point replaces.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 
@@ -61,12 +62,36 @@ class Recorder:
             return fn(*args)
         return call
 
-    def mark_dynamic(self, name, arg_index):
-        """The call just recorded takes a per-step integer at ``arg_index``."""
-        self.dynamic.setdefault(name, []).append((len(self.entries) - 1, arg_index))
+    def mark_dynamic(self, name, arg_index, mul=1, add=0):
+        """The call just recorded takes a per-step integer at ``arg_index``: value(name) * mul + add."""
+        self.dynamic.setdefault(name, []).append((len(self.entries) - 1, arg_index, mul, add))
 
 
 RECORDER = None
+
+# Packed text rows (yat_amd/sana.py forward_impl, kv_off): the number of text rows changes from batch to batch, and a launch
+# plan must not be keyed by it (every new (bucket, row count) pair would be a fresh recording).  Inside ``with
+# text_rows(n):`` the wrappers below mark the argument that carries the row count -- M of a forward / dgrad GEMM, K of a
+# weight gradient, the row count of a norm / column sum / packed attention, the address of the last rows -- as the plan's
+# dynamic integer "text_rows"; a replay patches them from ``plan_dynamic["text_rows"]``.  Scopes hold text-side calls only.
+TEXT_ROWS = None
+
+
+@contextlib.contextmanager
+def text_rows(n):
+    global TEXT_ROWS
+    prev, TEXT_ROWS = TEXT_ROWS, n
+    try:
+        yield
+    finally:
+        TEXT_ROWS = prev
+
+
+def _dyn_rows(arg_index, value, mul=1, add=0):
+    if RECORDER is not None and TEXT_ROWS is not None:
+        if value != TEXT_ROWS * mul + add:
+            raise RuntimeError("text_rows scope around a call whose row count is not the text row count")
+        RECORDER.mark_dynamic("text_rows", arg_index, mul, add)
 
 
 def _lib():
@@ -99,8 +124,9 @@ def gemm_concurrency(streams: int):
 
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
          activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
-         glu_u=None, pre_add=None, dact_z=None, a_rowsum=None, a_rowsum_accumulate=False):
-    """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts."""
+         glu_u=None, pre_add=None, dact_z=None, a_rowsum=None, a_rowsum_accumulate=False, dyn=None):
+    """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts.  ``dyn`` ("M" | "K"): inside a
+    ``text_rows`` scope, the dimension that is the text row count."""
     _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add, dact_z, a_rowsum)
     lda = lda if lda is not None else (M if a_t else K)
     ldb = ldb if ldb is not None else (N if b_t else K)
@@ -120,6 +146,8 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
     ws = _gemm_ws(out.device)
     rc = _lib().yat_gemm_bf16_ex(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
                                  C.byref(ep) if ep is not None else None, variant, _p(ws), ws.numel(), _stream())
+    if dyn is not None and TEXT_ROWS is not None:
+        _dyn_rows(2 if dyn == "M" else 4, M if dyn == "M" else K)
     if timer is not None:
         e1.record()
         nbytes = 2.0 * (M * K + K * N + M * N * (1 + (residual is not None) + (aux_out is not None) +
@@ -135,7 +163,7 @@ def linear_fwd(x2d, w, bias=None, out=None, **ep):
     M, K = x2d.shape
     N = w.shape[0]
     out = out if out is not None else torch.empty(M, N, dtype=BF16, device=x2d.device)
-    return gemm(x2d, w, out, M=M, N=N, K=K, bias=bias, **ep)
+    return gemm(x2d, w, out, M=M, N=N, K=K, bias=bias, dyn="M", **ep)
 
 
 def linear_dgrad(dy2d, w, out=None, **ep):
@@ -143,7 +171,7 @@ def linear_dgrad(dy2d, w, out=None, **ep):
     M, N = dy2d.shape
     K = w.shape[1]
     out = out if out is not None else torch.empty(M, K, dtype=BF16, device=dy2d.device)
-    return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, **ep)
+    return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, dyn="M", **ep)
 
 
 def linear_dgrad_glu(dy2d, w, u, du):
@@ -179,7 +207,8 @@ def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=Non
     # unsplit makes the weight-gradient stream the critical path (PixArt 228 -> 244 ms when it was fused unconditionally)
     fused = bias_grad is not None and FUSE_BIAS_GRAD and ((N + 255) // 256) * ((K + 255) // 256) >= 96
     r = gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=dy2d.stride(0), ldb=K, ldc=K,
-             residual=out if accumulate else None, a_rowsum=bias_grad if fused else None, a_rowsum_accumulate=accumulate)
+             residual=out if accumulate else None, a_rowsum=bias_grad if fused else None, a_rowsum_accumulate=accumulate,
+             dyn="K")
     if bias_grad is not None and not fused:
         if colsum_ws is None:                                   # (the models pass their arena buffer)
             colsum_ws = torch.empty(int(_lib().yat_colsum_workspace_bytes(M, N)), dtype=torch.uint8, device=dy2d.device)
@@ -357,6 +386,7 @@ def colsum(x2d, out, workspace, accumulate=False):
     """yat_colsum_bf16: out[c] (+)= sum_r x[r,c]."""
     rows, cols = x2d.shape
     rc = _lib().yat_colsum_bf16(rows, cols, _p(x2d), x2d.stride(0), _p(out), int(accumulate), _p(workspace), _stream())
+    _dyn_rows(0, rows)
     _l.check(rc, "yat_colsum_bf16")
     return out
 
@@ -410,6 +440,7 @@ def rmsnorm_fwd(x2d, w, eps, y=None, rstd=None):
     y = y if y is not None else torch.empty_like(x2d)
     rstd = rstd if rstd is not None else torch.empty(M, dtype=torch.float32, device=x2d.device)
     rc = _lib().yat_rmsnorm_fwd(M, D, eps, _p(x2d), _p(w), _p(y), _p(rstd), _stream())
+    _dyn_rows(0, M)
     _l.check(rc, "yat_rmsnorm_fwd")
     return y, rstd
 
@@ -418,6 +449,7 @@ def rmsnorm_bwd(x2d, w, rstd, dy, dx, dw, workspace, accumulate_dw=False):
     M, D = x2d.shape
     rc = _lib().yat_rmsnorm_bwd(M, D, _p(x2d), _p(w), _p(rstd), _p(dy), _p(dx), _p(dw), int(accumulate_dw),
                                 _p(workspace), _stream())
+    _dyn_rows(0, M)
     _l.check(rc, "yat_rmsnorm_bwd")
 
 
@@ -458,6 +490,7 @@ def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse, k
         rc = _lib().yat_sdpa_fwd_packed(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                                         _p(kv_off), k2d.shape[0], _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(lse),
                                         _stream())
+        _dyn_rows(12, k2d.shape[0])
         _l.check(rc, "yat_sdpa_fwd_packed")
         return out
     rc = _lib().yat_sdpa_fwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
@@ -484,6 +517,7 @@ def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, 
                                         _p(work), 0 if work is None else work.shape[0], parts, _stream())
         if RECORDER is not None and work is not None:
             RECORDER.mark_dynamic("n_work", 27)
+        _dyn_rows(12, k2d.shape[0])
         _l.check(rc, "yat_sdpa_bwd_packed")
         return
     rc = _lib().yat_sdpa_bwd(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
@@ -561,7 +595,10 @@ def act_fwd(x, act, y=None):
 
 def act_bwd(x, dy, act, dx=None):
     dx = dx if dx is not None else torch.empty_like(x)
-    _l.check(_lib().yat_act_bwd(x.numel(), ACT[act], _p(x), _p(dy), _p(dx), _stream()), "yat_act_bwd")
+    rc = _lib().yat_act_bwd(x.numel(), ACT[act], _p(x), _p(dy), _p(dx), _stream())
+    if TEXT_ROWS is not None:
+        _dyn_rows(0, x.numel(), mul=x.numel() // x.shape[0])
+    _l.check(rc, "yat_act_bwd")
     return dx
 
 
@@ -571,6 +608,19 @@ def zero_(t):
         raise ValueError("zero_: contiguous tensors only")
     _l.check(_lib().yat_memset_zero(_p(t), t.numel() * t.element_size(), _stream()), "yat_memset_zero")
     return t
+
+
+def zero_last_rows(x2d, n):
+    """Zero the last ``n`` rows of a contiguous [rows, cols] matrix (inside a ``text_rows`` scope the address follows the row
+    count: a launch plan replays it for another number of rows)."""
+    rows = x2d.shape[0]
+    if not x2d.is_contiguous() or rows < n:
+        raise ValueError("zero_last_rows: contiguous matrix with at least n rows")
+    row_bytes = x2d.shape[1] * x2d.element_size()
+    ptr = x2d.data_ptr() + (rows - n) * row_bytes
+    rc = _lib().yat_memset_zero(C.c_void_p(ptr), n * row_bytes, _stream())
+    _dyn_rows(0, ptr, mul=row_bytes, add=x2d.data_ptr() - n * row_bytes)
+    _l.check(rc, "yat_memset_zero")
 
 
 def add_bf16(a, b, out=None):

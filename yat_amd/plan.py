@@ -105,15 +105,15 @@ class LaunchPlan:
                 pending.append((op, vals))
         flush()
         for name, slots in dynamic.items():
-            self.dynamic[name] = [(where[e][0], where[e][1], a) for e, a in slots]
+            self.dynamic[name] = [(where[e][0], where[e][1], a, mul, add) for e, a, mul, add in slots]
         self.n_entries = len(entries)
         self._fail = C.c_int(0)
 
     def replay(self, dynamic_values):
         for name, slots in self.dynamic.items():
             v = int(dynamic_values[name])
-            for arr, pos, a in slots:
-                arr[pos].a[a].i = v
+            for arr, pos, a, mul, add in slots:
+                arr[pos].a[a].i = v * mul + add
         lib = _l.load()
         for seg in self.segments:
             if seg[0] == "c":

@@ -27,6 +27,7 @@ gradient buffer (``p.grad`` are views of it).
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from dataclasses import dataclass, field, asdict
@@ -190,7 +191,11 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         ``kv_off`` (device int32 row offsets, one per image): ``enc`` is the packed [rows, C] text matrix -- the prompts'
         rows back to back, then fewer than 256 zero rows (see ``forward_impl``); the plan key then carries the row count."""
         pev = self.param_events
-        key = (latents.data_ptr(), tuple(latents.shape), enc.data_ptr(), tuple(enc.shape), timestep.data_ptr(),
+        # (packed text: the row count is a dynamic integer of the plan -- ops.text_rows -- not part of its key)
+        enc_shape = tuple(enc.shape) if kv_off is None else ("packed",) + tuple(enc.shape[1:])
+        if kv_off is not None:
+            self._text_rows = self.plan_dynamic["text_rows"] = int(enc.shape[0])
+        key = (latents.data_ptr(), tuple(latents.shape), enc.data_ptr(), enc_shape, timestep.data_ptr(),
                key_bias.data_ptr(), kv_len.data_ptr(), None if kv_off is None else kv_off.data_ptr(),
                None if pev is None else id(pev[0]), self._schedule_flags())
         out = self.planned("fwd", key, lambda: self.forward_impl(latents, enc, timestep, None, key_bias=key_bias,
@@ -204,6 +209,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         work = S.kv_work
         if work is not None:
             self.plan_dynamic["n_work"] = int(work.shape[0])
+        if S.kv_off is not None:
+            self.plan_dynamic["text_rows"] = self._text_rows          # this batch's, not the recorded one's
         key = (id(S), dpred.data_ptr(), self.accumulate_grads, id(self.grad_ready), None if work is None else work.data_ptr(),
                self._schedule_flags())
         self.planned("bwd", key, lambda: self.backward_impl(dpred))
@@ -222,8 +229,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         B, Cin, h, w = latents.shape
         N, M = h * w, B * h * w
         packed = kv_off is not None
-        if packed and (key_bias is None or kv_len is None or enc.dim() != 2):
-            raise ValueError("packed text: enc [rows, C] with key_bias [B, T], kv_len [B] and kv_off [B]")
+        if packed and (key_bias is None or kv_len is None or enc.dim() != 2 or enc.shape[0] % 256 or not enc.shape[0]):
+            raise ValueError("packed text: enc [rows, C] (rows a multiple of 256) with key_bias [B, T], kv_len [B], kv_off [B]")
         T = key_bias.shape[1] if packed else enc.shape[1]
         Mt = enc.shape[0] if packed else B * T
         Mt_cap = max(B * T, Mt)                    # text-side buffers are sized once, for the padded layout
@@ -272,7 +279,13 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         # The text branch (caption projection, RMSNorm, every block's K/V projection) does not depend on the latent
         # stream until the first cross-attention: it runs on the second stream, filling CUs the single-round GEMMs of
         # the main chain leave idle.
+        text_scope = (lambda: ops.text_rows(Mt)) if packed else contextlib.nullcontext     # see ops.text_rows
+
         def text_branch():
+            with text_scope():
+                text_branch_()
+
+        def text_branch_():
             S.zc1 = tbuf("cap_z1", D)
             S.c1 = lin(enc2d, P["caption_projection.linear_1.weight"], P["caption_projection.linear_1.bias"],
                                   out=tbuf("cap_c1", D), activation="gelu_tanh", aux_out=S.zc1)
@@ -379,8 +392,9 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 if side is not None:
                     self._ev_wait(stream, S.kv_ready[i])
                 kv = A.kv2 if packed else A.kv2[ts]          # packed: the whole matrix + this chain's row offsets
-                ops.sdpa_fwd(A.q2[rs], kv[:, :D], kv[:, D:], nb, N, T, H2, dh2, scale2, key_bias[bs], kv_len[bs], A.o2[rs],
-                             A.lse[bs], kv_off=kv_off[bs] if packed else None)
+                with text_scope():
+                    ops.sdpa_fwd(A.q2[rs], kv[:, :D], kv[:, D:], nb, N, T, H2, dh2, scale2, key_bias[bs], kv_len[bs],
+                                 A.o2[rs], A.lse[bs], kv_off=kv_off[bs] if packed else None)
                 lin(A.o2[rs], P[pre + "attn2.to_out.0.weight"], P[pre + "attn2.to_out.0.bias"], out=A.x2[rs],
                                residual=A.x1[rs])
                 ops.ln_modulate_fwd(A.x2[rs], mod2d[:, 3 * D:4 * D], mod2d[:, 4 * D:5 * D], 6 * D, N, cfg.norm_eps, A.h2[rs],
@@ -437,6 +451,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
         def tbuf(name, cols, dtype=BF16):
             return buf(name, (Mt_cap, cols), dtype)[:Mt]
+
+        text_scope = (lambda: ops.text_rows(Mt)) if packed else contextlib.nullcontext     # see ops.text_rows
         f32, u8 = torch.float32, torch.uint8
         ws_col = buf("ws_col", (int(ops._lib().yat_colsum_workspace_bytes(max(M, Mt_cap), max(2 * Hc, 6 * D, 3 * D))),), u8)
         ws_ln = buf("ws_ln", (ops.ln_bwd_workspace_bytes(M, D, N),), u8)
@@ -541,25 +557,28 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
             big = []                                          # experiment: conv_inverted + conv_point + kv in one launch
 
-            def emit(dy_, x_, gw_, bias=None, group=False):
+            def emit(dy_, x_, gw_, bias=None, group=False, text=False):
+                """``text``: the reduction runs over the (packed) text rows -- never grouped, its K is the plan's dynamic
+                row count"""
                 if ad is not None:        # frozen base: adapter gradients only, launched by the dgrad() of the same dy
                     pending_ad.append((dy_, x_, gw_))
                     return
                 if self.defer_wgrad:
-                    deferred.append((dy_, x_, gw_, bias))
+                    deferred.append((dy_, x_, gw_, bias, text))
                     return
                 if group is True and self.group_small_wgrad:      # (also without a side stream: one launch instead of three
                     small.append((dy_, x_, gw_, bias))            #  split-K ones -- the serialized pass runs the step's kernels)
                     return
                 if side is None:
-                    deferred.append((dy_, x_, gw_, bias))
+                    deferred.append((dy_, x_, gw_, bias, text))
                     return
-                if group == "big" and self.group_big_wgrad:
+                if group == "big" and self.group_big_wgrad and not text:
                     big.append((dy_, x_, gw_, bias))
                     return
 
                 def run():
-                    ops.linear_wgrad(dy_, x_, gw_, accumulate=acc, bias_grad=bias, colsum_ws=ws_col)
+                    with (text_scope() if text else contextlib.nullcontext()):
+                        ops.linear_wgrad(dy_, x_, gw_, accumulate=acc, bias_grad=bias, colsum_ws=ws_col)
                 off_chain(run)
 
             # x3 = x2 + gate_mlp * lin3
@@ -599,14 +618,16 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                   dq2, dkv2[:, :D], dkv2[:, D:])
 
             def dkv_part(parts, sd=sd, dkv2=dkv2):
-                if packed:
-                    # the zero rows behind the last prompt (< 256 of them) belong to no image: dK/dV leaves them alone, the
-                    # text-side GEMMs read them -- zero the last 256 rows first (the real ones among them are rewritten)
-                    ops.zero_(dkv2[max(0, Mt - 256):])
-                ops.sdpa_bwd(*sd, work=S.kv_work, parts=parts, kv_off=S.kv_off)
+                with text_scope():
+                    if packed:
+                        # the zero rows behind the last prompt (< 256 of them) belong to no image: dK/dV leaves them alone,
+                        # the text-side GEMMs read them -- zero the last 256 rows first (the real ones among them are rewritten)
+                        ops.zero_last_rows(dkv2, 256)
+                    ops.sdpa_bwd(*sd, work=S.kv_work, parts=parts, kv_off=S.kv_off)
             # cross-attention backward: dQ (+delta) on the chain, dK/dV -- read only by the text-side gradients -- behind it
             if side is not None:
-                ops.sdpa_bwd(*sd, work=S.kv_work, parts=1, kv_off=S.kv_off)
+                with text_scope():
+                    ops.sdpa_bwd(*sd, work=S.kv_work, parts=1, kv_off=S.kv_off)
                 off_chain(lambda dkv_part=dkv_part: dkv_part(2))
             else:
                 dkv_part(3)
@@ -614,7 +635,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             dx1 = dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
-            emit(dkv2, S.encn, gkv, gbkv, group="big")
+            emit(dkv2, S.encn, gkv, gbkv, group="big", text=packed)
             if big:
                 def big_grads(big=big):
                     ops.wgrad_grouped(sorted([(a, b_, c) for a, b_, c, _ in big], key=lambda it: -it[0].shape[0]),
@@ -664,17 +685,21 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             def block_grads(deferred=deferred, dx2=dx2, dq2=dq2, dkv2=dkv2, wkv=wkv, gbkv=gbkv, pre=pre,
                             first=(i == cfg.num_layers - 1)):
                 if deferred:
-                    if self.grouped_wgrad:
+                    grouped = [it for it in deferred if not it[4]] if self.grouped_wgrad else []
+                    if grouped:
                         # largest K first: the short tiles (text side, K = B*T) fill the tail
-                        ops.wgrad_grouped(sorted([it[:3] for it in deferred], key=lambda it: -it[0].shape[0]), accumulate=acc)
-                    else:
-                        for dy_, x_, gw_, _ in deferred:
-                            ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
-                    for dy_, _, _, bias_ in deferred:             # attn2.to_out / to_q (unless grouped above) / to_k|to_v
+                        ops.wgrad_grouped(sorted([it[:3] for it in grouped], key=lambda it: -it[0].shape[0]), accumulate=acc)
+                    for dy_, x_, gw_, _, text_ in deferred:
+                        if not self.grouped_wgrad or text_:
+                            with (text_scope() if text_ else contextlib.nullcontext()):
+                                ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
+                    for dy_, _, _, bias_, text_ in deferred:      # attn2.to_out / to_q (unless grouped above) / to_k|to_v
                         if bias_ is not None:
-                            ops.colsum(dy_, bias_, ws_col, accumulate=acc)
+                            with (text_scope() if text_ else contextlib.nullcontext()):
+                                ops.colsum(dy_, bias_, ws_col, accumulate=acc)
                 # the text-side gradient chain (denc += dkv2 Wkv) only meets the main chain at the caption branch
-                dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
+                with text_scope():
+                    dgrad(dkv2, wkv, out=denc, residual=None if first else denc)
 
             if ad is not None:
                 flush_adapter_wgrads()        # anything queued whose dy had no dgrad() (none today; keeps the queue per block)
@@ -697,15 +722,17 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             self._wait_stream(main, side)
             side = None
         wgrad(dx, S.x_tok, "patch_embed.proj.weight", (D, Cin), "patch_embed.proj.bias")
-        # caption branch
+        # caption branch (every call in it runs over the text rows)
         dc2 = tbuf("dc2", D)
         ws_rms = buf("ws_rms", (int(ops._lib().yat_rmsnorm_bwd_workspace_bytes(Mt_cap, D)),), u8)
-        ops.rmsnorm_bwd(S.c2, P["caption_norm.weight"], S.enc_rstd, denc, dc2, G["caption_norm.weight"], ws_rms,
-                        accumulate_dw=acc)
-        wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D), "caption_projection.linear_2.bias")
-        dc1 = dgrad(dc2, P["caption_projection.linear_2.weight"], out=denc)
-        dzc1 = ops.act_bwd(S.zc1, dc1, "gelu_tanh", dc2)
-        wgrad(dzc1, S.enc2d, "caption_projection.linear_1.weight", (D, cfg.caption_channels), "caption_projection.linear_1.bias")
+        with text_scope():
+            ops.rmsnorm_bwd(S.c2, P["caption_norm.weight"], S.enc_rstd, denc, dc2, G["caption_norm.weight"], ws_rms,
+                            accumulate_dw=acc)
+            wgrad(dc2, S.c1, "caption_projection.linear_2.weight", (D, D), "caption_projection.linear_2.bias")
+            dc1 = dgrad(dc2, P["caption_projection.linear_2.weight"], out=denc)
+            dzc1 = ops.act_bwd(S.zc1, dc1, "gelu_tanh", dc2)
+            wgrad(dzc1, S.enc2d, "caption_projection.linear_1.weight", (D, cfg.caption_channels),
+                  "caption_projection.linear_1.bias")
         # timestep branch
         dtmod_b = ops.f32_to_bf16(dtmod, buf("dtmod_b", (B, 6 * D)))
         wgrad(dtmod_b, S.se, "time_embed.linear.weight", (6 * D, D), "time_embed.linear.bias")
