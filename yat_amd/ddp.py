@@ -90,6 +90,10 @@ class HipDDP:
             self.native = NativeComm.get(process_group)
         self._works = []
         self.bytes_reduced = 0
+        # YAT_DDP_COALESCE=k: k consecutive buckets (they complete in reverse order and are adjacent in the flat gradient
+        # buffer) go out as one collective -- fewer, larger messages; 1 = one per transformer block
+        self.coalesce = max(1, int(os.environ.get("YAT_DDP_COALESCE", "1")))
+        self._pending = None
         model.grad_ready = self.bucket_ready
 
     def broadcast_parameters(self, src=0):
@@ -104,6 +108,16 @@ class HipDDP:
         if (self.world == 1 and not self.force) or not self.sync:
             return
         lo, hi = self.model.bucket_bounds[i]
+        if self.coalesce > 1:
+            if self._pending is not None and self._pending[0] == hi:          # adjacent below the pending range: extend it
+                self._pending = (lo, self._pending[1], self._pending[2] + 1)
+            else:
+                self._pending = (lo, hi, 1) if self._pending is None else self._pending
+                if self._pending[0] != lo and self._pending[1] != hi:         # not adjacent (never with the models' order)
+                    raise RuntimeError("HipDDP: buckets completed out of order")
+            if self._pending[2] < self.coalesce and i != 0:
+                return
+            (lo, hi, _), self._pending = self._pending, None
         chunk = self.model.flat_grad[lo:hi]
         self.bytes_reduced += chunk.numel() * chunk.element_size()
         if self.native is not None:
