@@ -332,3 +332,26 @@ def optimize_ref(model, sched, latents, prompt_embeds, pooled, generator=None, d
     target = noise - latents
     loss = F.mse_loss(pred.to(noise.dtype), target)
     return loss, pred, target
+
+
+@torch.no_grad()
+def sample_latents_sd3_ref(model, sched, latents, prompt_embeds, pooled, negative_embeds, negative_pooled,
+                           num_inference_steps=20, guidance_scale=5.0, dtype=torch.bfloat16):
+    """[RECALL] StableDiffusion3Pipeline.__call__ denoising loop as train_sd35.py:129-142 calls it (guidance 5.0, 20 steps,
+    output_type='latent'): CFG batch (unconditional | conditional) of token embeddings and pooled projections, one
+    transformer call per step with the timestep expanded to the batch, Euler flow-match step in fp32, cast back.
+    ``model``: an SD3TransformerRef in ``dtype``; float32 gives the ground truth for the same initial latents.  Test
+    infrastructure (oracle/): never imported by the product path."""
+    from .recipe_ref import inference_schedule_ref
+    timesteps, sigmas = inference_schedule_ref(sched, num_inference_steps)
+    x = latents.to(dtype)
+    enc = torch.cat([negative_embeds, prompt_embeds]).to(dtype)
+    pool = torch.cat([negative_pooled, pooled]).to(dtype)
+    for i in range(num_inference_steps):
+        x_in = torch.cat([x, x])
+        t = timesteps[i].expand(x_in.shape[0])
+        v = model(x_in, enc, pool, t)
+        v_u, v_c = v.float().chunk(2)
+        v = (v_u + guidance_scale * (v_c - v_u)).to(dtype)
+        x = (x.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(dtype)
+    return x

@@ -176,6 +176,34 @@ def test_sd3_step_matches_oracle(B, Hl, Wl, T, kw):
     _compare_step(rcfg, ref_bf, ref_32, hip, B, Hl, Wl, T, f"tiny B={B} {Hl}x{Wl} T={T} L={rcfg.num_layers}")
 
 
+def test_sd3_validation_sampler_matches_oracle():
+    """CFG + flow-match Euler latent sampler over the MMDiT (the middle third of the reference's SD3.5 validate(),
+    train_sd35.py:129-142): HIP model vs the oracle in bf16 and fp32 from the same initial latents, a few steps on a tiny
+    configuration with the SD3.5 scheduler shift; same bar as the SANA sampler."""
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched
+    from oracle.sd3_ref import sample_latents_sd3_ref
+    from yat_amd.sampler import sample_latents_sd3
+    from yat_amd.scheduler import FlowMatchSchedule
+    rcfg, ref_bf, ref_32, hip = _setup({})
+    g = torch.Generator().manual_seed(21)
+    B, T, Hl, Wl = 2, 10, 12, 8
+    x0 = torch.randn(B, rcfg.in_channels, Hl, Wl, generator=g).to(BF)
+    enc, neg = (torch.randn(B, T, rcfg.joint_attention_dim, generator=g).to(BF) for _ in range(2))
+    pool, npool = (torch.randn(B, rcfg.pooled_projection_dim, generator=g).to(BF) for _ in range(2))
+    steps = 4
+    out = sample_latents_sd3(hip, enc, pool, neg, npool, Hl, Wl, num_inference_steps=steps, guidance_scale=5.0, latents=x0,
+                             schedule=FlowMatchSchedule(shift=3.0))
+    o_bf = sample_latents_sd3_ref(ref_bf, RefSched(shift=3.0), x0, enc, pool, neg, npool, steps, 5.0, BF)
+    o_32 = sample_latents_sd3_ref(ref_32, RefSched(shift=3.0), x0, enc, pool, neg, npool, steps, 5.0, torch.float32)
+    e_hip, e_ref = rel(out, o_32), rel(o_bf, o_32)
+    print(f"[parity] sd3 sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
+    assert torch.isfinite(out.float()).all() and out.shape == x0.shape
+    assert e_hip <= 1.3 * e_ref + 2e-3
+    # without guidance: one conditional pass per step, no negative branch
+    out1 = sample_latents_sd3(hip, enc, pool, None, None, Hl, Wl, num_inference_steps=2, guidance_scale=1.0, latents=x0)
+    assert torch.isfinite(out1.float()).all() and out1.shape == x0.shape
+
+
 def test_sd3_real_width_blocks_match_oracle():
     """SD3.5-Medium width (D = 1536 = 24 x 64, text width 4096, pooled 2048, T = 333 = 77 + 256 prompt tokens): one dual
     block + the context_pre_only block, 32 x 48 latents (384 image tokens per image, joint sequence 717)."""
@@ -243,6 +271,12 @@ def test_sd3_trainer_runs_from_shards(tmp_path, monkeypatch):
         "urls:", "  - unused", "local_shard_paths:", f"  - {path}", "num_shards: 1", "dataset_seed: 3", "batch_size: 4",
         "learning_rate: 1e-3", "steps: 3", "num_steps_per_validation: 2", "validation_prompts:", "  - x", "bfloat16: true",
         "aspect_ratio: 1024", ""]))
+    # cached validation embeddings (what pipe.encode_prompt returns, train_sd35.py:116-118): the validation pass samples
+    # latents from them (validate(): 20 Euler steps with CFG 5.0) at every validation step
+    torch.save([(torch.randn(1, 11, cfg.joint_attention_dim, generator=g).to(BF),
+                 torch.randn(1, 11, cfg.joint_attention_dim, generator=g).to(BF),
+                 torch.randn(1, cfg.pooled_projection_dim, generator=g).to(BF),
+                 torch.randn(1, cfg.pooled_projection_dim, generator=g).to(BF))], tmp_path / "validation_embeds.pt")
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("YAT_TENSORBOARD", "0")
     params = TrainingParameters()
@@ -256,6 +290,9 @@ def test_sd3_trainer_runs_from_shards(tmp_path, monkeypatch):
     assert not torch.equal(before, trainer.model.flat_param)
     ck = tmp_path / "models" / "2"
     assert (ck / "config.json").exists() and (ck / "diffusion_pytorch_model.safetensors").exists()
+    lat = torch.load(ck / "validation_latents.pt")
+    assert len(lat) == 1 and lat[0].shape == (1, cfg.in_channels, cfg.sample_size, cfg.sample_size)
+    assert torch.isfinite(lat[0].float()).all()
 
 
 @pytest.mark.parametrize("algo", ["lora", "lokr"])

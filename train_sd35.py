@@ -60,7 +60,32 @@ class SD35Trainer(Model):
         raise NotImplementedError("text encoding is outside the hot-path scope; train from cached-feature shards")
 
     def validate(self):
-        raise NotImplementedError("SD3.5 validation pipeline (three text encoders + VAE decode) is outside the hot-path scope")
+        """Middle third of train_sd35.py:94-162: 20-step flow-match Euler sampling with CFG 5.0 over the HIP MMDiT (:129-142),
+        generator seeded 42 (:110).  The three text encoders and the VAE are outside this build's scope, so the prompt
+        embeddings come from a cached file (``validation_embeds.pt`` next to the shards or in the cwd: a list of
+        (prompt_embeds [1,T,C], negative_prompt_embeds, pooled_prompt_embeds [1,P], negative_pooled_prompt_embeds) tuples as
+        ``pipe.encode_prompt`` returns them, :116-118) and the result is the latents (``output_type='latent'``), stored
+        under models/<step>/ with a three-channel preview for the logger in place of the decoded image (:154)."""
+        from yat_amd.sampler import sample_latents_sd3
+        cands = [os.path.join(os.path.dirname(p), "validation_embeds.pt") for p in (self.params.local_shard_paths or [])]
+        path = next((c for c in cands + ["validation_embeds.pt"] if os.path.isfile(c)), None)
+        if path is None:
+            raise NotImplementedError("no cached validation embeddings (text encoding is outside the hot-path scope)")
+        embeds = torch.load(path, map_location="cpu")
+        gen = torch.Generator().manual_seed(42)                                              # a CPU generator (:110)
+        side = self.model.cfg.sample_size
+        out = []
+        for pe, ne, pp, npp in embeds:
+            out.append(sample_latents_sd3(self.model, pe, pp, ne, npp, side, side, num_inference_steps=20, guidance_scale=5.0,
+                                          generator=gen, schedule=self.scheduler).cpu())
+        os.makedirs(f"models/{self.global_step}", exist_ok=True)
+        torch.save(out, f"models/{self.global_step}/validation_latents.pt")
+        if self.logger is not None:
+            for idx, lat in enumerate(out):
+                x = lat[0, :3].float()
+                x = (x - x.amin()) / (x.amax() - x.amin()).clamp_min(1e-6)
+                self.logger.add_image(f"validation_latents/{idx}", x, self.global_step)
+        return out
 
     def optimize(self, ratio, latents, embeddings, repa_tokens=None, generator: torch.Generator = None):
         """train_sd35.py:165-194 on the HIP path (yat_amd.recipe.SD3Recipe.optimize); global RNG streams as there."""

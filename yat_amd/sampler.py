@@ -60,3 +60,39 @@ def sample_latents(model, prompt_embeds, prompt_mask, negative_embeds, negative_
             v = (v_u + guidance_scale * (v_c - v_u)).to(BF16)       # the pipeline combines in the model dtype
         latents = (latents.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(BF16)
     return latents
+
+
+@torch.no_grad()
+def sample_latents_sd3(model, prompt_embeds, pooled, negative_embeds, negative_pooled, height, width, *,
+                       num_inference_steps=20, guidance_scale=5.0, generator=None, schedule: FlowMatchSchedule | None = None,
+                       latents=None):
+    """The middle third of the reference's SD3.5 ``validate()`` (train_sd35.py:129-142: ``self.pipe(prompt_embeds=...,
+    negative_prompt_embeds=..., pooled_prompt_embeds=..., negative_pooled_prompt_embeds=..., guidance_scale=5.0,
+    num_inference_steps=20, generator=generator, output_type='latent')``) over the HIP MMDiT [RECALL,
+    StableDiffusion3Pipeline.__call__]: the same classifier-free-guidance / flow-match Euler loop as ``sample_latents``, the
+    condition being (token embeddings [B, T, C], pooled projection [B, P]) pairs and no mask; the scheduler's static shift
+    (3.0 for SD3.5) comes with ``schedule``.  Returns latents [B, C_in, height, width] (bf16): ``output_type='latent'``
+    returns them as the loop leaves them (the VAE's scaling / shift belong to the decode)."""
+    sched = schedule or FlowMatchSchedule(shift=3.0)
+    dev = model.device
+    B = prompt_embeds.shape[0]
+    cin = model.cfg.in_channels
+    if latents is None:
+        if generator is not None and generator.device.type == "cuda":
+            latents = torch.randn(B, cin, height, width, generator=generator, device=dev, dtype=BF16)
+        else:
+            latents = torch.randn(B, cin, height, width, generator=generator, dtype=BF16).to(dev)
+    latents = latents.to(device=dev, dtype=BF16)
+    do_cfg = guidance_scale > 1.0
+    enc = (torch.cat([negative_embeds, prompt_embeds]) if do_cfg else prompt_embeds).to(device=dev, dtype=BF16)
+    pool = (torch.cat([negative_pooled, pooled]) if do_cfg else pooled).to(device=dev, dtype=BF16)
+    timesteps, sigmas = inference_schedule(sched, num_inference_steps)
+    for i in range(num_inference_steps):
+        x_in = torch.cat([latents, latents]) if do_cfg else latents
+        t = timesteps[i].expand(x_in.shape[0]).to(dev)
+        v = model(x_in, encoder_hidden_states=enc, pooled_projections=pool, timestep=t).sample
+        if do_cfg:
+            v_u, v_c = v.float().chunk(2)
+            v = (v_u + guidance_scale * (v_c - v_u)).to(BF16)       # the pipeline combines in the model dtype
+        latents = (latents.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(BF16)
+    return latents
