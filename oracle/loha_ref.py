@@ -6,8 +6,8 @@ The adapter arithmetic lives in the unpinned third-party ``peft`` (requirements.
 everything below is [RECALL peft/tuners/loha/layer.py] -- PARITY UNPINNED for this module:
 
 * Linear / 1x1 Conv2d (``use_effective_conv2d=False``) with weight [out, in]: ``hada_w1_a [out, r]``, ``hada_w1_b [r, in]``,
-  ``hada_w2_a [out, r]``, ``hada_w2_b [r, in]``; init (``init_weights=True``): w1_b, w1_a, w2_b kaiming_uniform(a=sqrt(5)),
-  w2_a zeros (so the initial delta is zero);
+  ``hada_w2_a [out, r]``, ``hada_w2_b [r, in]``; init (``init_weights=True``, ``LoHaLayer.reset_adapter_parameters``): w1_a, w1_b,
+  w2_a kaiming_uniform(a=sqrt(5)), w2_b zeros (so the initial delta is zero and w2_b receives the first gradients);
 * ``delta_w = HadaWeight.apply(w1a, w1b, w2a, w2b, scale)`` with scale = alpha / r:
   forward ``((w1a @ w1b) * (w2a @ w2b)) * scale``; the hand-written backward
   ``g = grad * scale; t = g * (w2a @ w2b); d_w1a = t @ w1b.T; d_w1b = w1a.T @ t; t = g * (w1a @ w1b); d_w2a = t @ w2b.T;
@@ -60,11 +60,11 @@ class LoHaWrapped(nn.Module):
         dt = base.weight.dtype
         self.hada_w1_a = nn.Parameter(torch.empty(out_dim, r, dtype=dt))
         self.hada_w1_b = nn.Parameter(torch.empty(r, in_dim, dtype=dt))
-        self.hada_w2_a = nn.Parameter(torch.zeros(out_dim, r, dtype=dt))
-        self.hada_w2_b = nn.Parameter(torch.empty(r, in_dim, dtype=dt))
-        nn.init.kaiming_uniform_(self.hada_w1_b, a=math.sqrt(5))
+        self.hada_w2_a = nn.Parameter(torch.empty(out_dim, r, dtype=dt))
+        self.hada_w2_b = nn.Parameter(torch.zeros(r, in_dim, dtype=dt))
         nn.init.kaiming_uniform_(self.hada_w1_a, a=math.sqrt(5))
-        nn.init.kaiming_uniform_(self.hada_w2_b, a=math.sqrt(5))
+        nn.init.kaiming_uniform_(self.hada_w1_b, a=math.sqrt(5))
+        nn.init.kaiming_uniform_(self.hada_w2_a, a=math.sqrt(5))
 
     def delta_weight(self):
         w = HadaWeight.apply(self.hada_w1_a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b, torch.tensor(self.scale))

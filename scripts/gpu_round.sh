@@ -10,7 +10,7 @@ rc=0
 for s in $STEPS; do
   case $s in
     tests)
-      timeout -k 10 600 python -m pytest tests -m gpu -q -s -p no:cacheprovider > gpurun_out/tests_gpu.log 2>&1; rc=$?
+      timeout -k 10 ${TEST_TIMEOUT:-900} python -m pytest ${TEST_ARGS:-tests} -m gpu -q -s -p no:cacheprovider > gpurun_out/tests_gpu.log 2>&1; rc=$?
       echo "exit=$rc" >> gpurun_out/tests_gpu.log; grep -E "passed|failed" gpurun_out/tests_gpu.log | tail -2 ;;
     benchsmall)
       timeout -k 10 180 python bench.py --layers 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_small.json 2> gpurun_out/bench_small.err; rc=$?

@@ -21,30 +21,109 @@ def _model():
     return SanaTransformer2DModelHIP(cfg, device=DEV).init_synthetic(3), cfg
 
 
-def _two_steps(transport):
+# Every model family of BASELINE's "DP = 8" configs puts its own `grad_ready` call sites under the data-parallel hook
+# (common/trainer.py:212-241,253: accelerator.prepare wraps whatever model -- or PEFT-wrapped model -- the recipe built):
+#   sana    config 2   yat_amd/sana.py     per-block hooks on the weight-gradient stream + embedders
+#   pixart  config 3   yat_amd/pixart.py   (same structure, its own call sites)
+#   sd3     config 4   yat_amd/sd3.py      MMDiT: hooks behind the modulation-gradient chain of each block
+#   lokr    config 5   yat_amd/lokr.py     one small bucket after project(), B = 32 per GPU
+#   lora               yat_amd/lora.py     (the reference's other adapter branch, :214-219)
+KINDS = ["sana", "pixart", "sd3", "lokr", "lora"]
+ADAPTER_TARGETS = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
+
+
+def _case(kind, seed=2):
+    """-> (base model, trained object (model or adapter set), step(i) -> loss with gradients in trained.flat_grad)."""
+    g = torch.Generator().manual_seed(seed)
+    if kind in ("sana", "lokr", "lora"):
+        from yat_amd.recipe import SanaRecipe
+        model, cfg = _model()
+        trained = model
+        B = 4
+        if kind == "lokr":
+            from yat_amd.lokr import LoKrAdapters
+            trained, B = LoKrAdapters(model, ADAPTER_TARGETS, r=2, alpha=4.0, module_dropout=0.0), 32      # config 5: B = 32
+        elif kind == "lora":
+            from yat_amd.lora import LoRAAdapters
+            trained, B = LoRAAdapters(model, ADAPTER_TARGETS, r=2, alpha=4.0), 32
+        if kind == "lokr":                   # adapters start as the identity: move the zero factor off it (w1 / lora_B)
+            for e in trained.entries:
+                w1, _, _ = trained._views(e, trained.flat_param)
+                w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+        elif kind == "lora":
+            for e in trained.entries:
+                _, bt = trained._views(e, trained.flat_param)
+                bt[:2].copy_((torch.randn(2, e["out"], generator=g) * 0.05).to(BF))
+        recipe = SanaRecipe(model, pad_to=32, device=DEV)
+        latents = (torch.randn(B, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+        embs = [torch.randn(int(L), cfg.caption_channels, generator=g).to(BF)
+                for L in torch.randint(1, 33, (B,), generator=g).tolist()]
+
+        def step(i):
+            loss = recipe.optimize(latents, embs, torch.Generator().manual_seed(10 + i))
+            loss.backward()
+            return loss
+        return model, trained, step
+    if kind == "pixart":
+        from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
+        from yat_amd.recipe import PixArtRecipe
+        cfg = PixArtConfig(num_attention_heads=2, attention_head_dim=24, in_channels=4, out_channels=8, num_layers=3,
+                           cross_attention_dim=48, sample_size=8, patch_size=2, caption_channels=64)
+        model = PixArtTransformer2DModelHIP(cfg, device=DEV).init_synthetic(3)
+        recipe = PixArtRecipe(model, pad_to=16, device=DEV)
+        latents = (torch.randn(4, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+        embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (5, 16, 9, 1)]
+
+        def step(i):
+            loss = recipe.optimize(latents, embs, torch.Generator().manual_seed(10 + i))
+            loss.backward()
+            return loss
+        return model, model, step
+    if kind == "sd3":
+        from yat_amd.recipe import SD3Recipe
+        from yat_amd.sd3 import SD3Config, SD3Transformer2DModelHIP
+        cfg = SD3Config(sample_size=16, patch_size=2, in_channels=8, out_channels=8, num_layers=3, attention_head_dim=64,
+                        num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128, pooled_projection_dim=64,
+                        pos_embed_max_size=24, dual_attention_layers=(0, 1))
+        model = SD3Transformer2DModelHIP(cfg, device=DEV).init_synthetic(3)
+        recipe = SD3Recipe(model, device=DEV)
+        latents = (torch.randn(4, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+        emb = (torch.randn(4, 10, cfg.joint_attention_dim, generator=g).to(BF),
+               torch.randn(4, cfg.pooled_projection_dim, generator=g).to(BF))
+
+        def step(i):
+            loss = recipe.optimize(latents, emb, torch.Generator().manual_seed(10 + i))
+            loss.backward()
+            return loss
+        return model, model, step
+    raise ValueError(kind)
+
+
+def _two_steps(transport, kind="sana"):
     from yat_amd.ddp import HipDDP
     from yat_amd.optim import FlatAdamW
-    from yat_amd.recipe import SanaRecipe
-    model, cfg = _model()
-    ddp = HipDDP(model, force=True, transport=transport) if transport else None
+    model, trained, step = _case(kind)
+    fired = []
+    ddp = HipDDP(trained, force=True, transport=transport) if transport else None
     if ddp:
         ddp.broadcast_parameters()
-    opt = FlatAdamW(model, lr=1e-3, weight_decay=0.01, overlap_update=True)
-    recipe = SanaRecipe(model, pad_to=32, device=DEV)
-    g = torch.Generator().manual_seed(2)
-    latents = (torch.randn(4, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
-    embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (5, 32, 17, 9)]
+        hook = trained.grad_ready
+        trained.grad_ready = lambda i: (fired.append(i), hook(i))[1]          # which call sites fired under the group
+    opt = FlatAdamW(trained, lr=1e-3, weight_decay=0.01, overlap_update=True)
     grads = []
     for s in range(2):
-        loss = recipe.optimize(latents, embs, torch.Generator().manual_seed(10 + s))
-        loss.backward()
+        step(s)
         if ddp:
             ddp.wait()
-        grads.append(model.flat_grad.clone())
+        grads.append(trained.flat_grad.clone())
         opt.step()
-    model.join_pending_update()
+    trained.join_pending_update()
     torch.cuda.synchronize()
-    return grads, model.flat_param.clone(), (ddp.bytes_reduced if ddp else 0), model.numel_flat
+    assert torch.isfinite(grads[0].float()).all() and grads[0].float().abs().max().item() > 0
+    if ddp:
+        assert sorted(set(fired)) == list(range(len(trained.bucket_bounds))), (kind, fired)     # every bucket's hook fired
+        assert len(fired) == 2 * len(trained.bucket_bounds)
+    return grads, trained.flat_param.clone(), (ddp.bytes_reduced if ddp else 0), trained.numel_flat
 
 
 @pytest.fixture(scope="module")
@@ -61,10 +140,27 @@ def one_rank_group():
         dist.destroy_process_group()
 
 
-def test_forced_ddp_torch_transport_is_bit_identical(one_rank_group):
-    g0, p0, _, n = _two_steps(None)
-    g1, p1, reduced, _ = _two_steps("torch")
+@pytest.mark.parametrize("kind", KINDS)
+def test_forced_ddp_torch_transport_is_bit_identical(one_rank_group, kind):
+    g0, p0, _, n = _two_steps(None, kind)
+    g1, p1, reduced, _ = _two_steps("torch", kind)
     assert reduced == 2 * 2 * n, (reduced, n)                     # every bucket of both steps went through RCCL
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("kind", KINDS[1:])
+def test_forced_ddp_native_transport_all_families(kind):
+    """The library's own communicator under the hooks of PixArt-Sigma, the MMDiT and the adapter sets (configs 3 - 5)."""
+    from yat_amd.ddp import NativeComm
+    g0, p0, _, n = _two_steps(None, kind)
+    try:
+        g1, p1, reduced, _ = _two_steps("native", kind)
+    finally:
+        if NativeComm._instance is not None:
+            NativeComm.get().destroy()
+    assert reduced == 2 * 2 * n, (reduced, n)
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
     assert torch.equal(p0, p1)
@@ -164,4 +260,63 @@ def test_world2_over_gloo_matches_two_single_rank_backwards(tmp_path):
     mean = (local[0] + local[1]) / 2
     err = ((r0["grads"][0].float() - mean).norm() / mean.norm()).item()
     print(f"[parity] world-2 mean gradient vs the two single-rank gradients: rel_l2={err:.3e}")
+    assert err <= 6e-3
+
+
+def _world2_adapter_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      YAT_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yat_amd.ddp import HipDDP
+    from yat_amd.optim import FlatAdamW
+    model, trained, step = _case("lokr", seed=20 + rank)      # every rank its own batch AND its own adapter draw ...
+    ddp = HipDDP(trained)
+    ddp.broadcast_parameters()                                # ... which rank 0's must overwrite (trainer.py:253)
+    start = trained.flat_param.clone().cpu()
+    opt = FlatAdamW(trained, lr=1e-3, weight_decay=0.01, overlap_update=True)
+    grads = []
+    for s in range(2):
+        step(s)
+        ddp.wait()
+        torch.cuda.synchronize()
+        grads.append(trained.flat_grad.clone().cpu())
+        opt.step()
+    trained.join_pending_update()
+    torch.cuda.synchronize()
+    torch.save(dict(grads=grads, start=start, param=trained.flat_param.cpu(), reduced=ddp.bytes_reduced),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_world2_over_gloo_adapter_step(tmp_path):
+    """BASELINE config 5's data-parallel clause with a real second rank: a LoKr adapter set (B = 32 per rank) under HipDDP,
+    two processes on this GPU over gloo.  The adapter parameters are rank 0's after the broadcast, the single small bucket is
+    reduced once per step (after ``project()``), both ranks hold the same gradient -- the mean of the two single-rank
+    gradients, recomputed here from the broadcast parameters -- and the same parameters after the optimizer."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_world2_adapter_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    assert torch.equal(r0["start"], r1["start"]), "broadcast did not overwrite rank 1's adapter parameters"
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b), "ranks disagree on the reduced adapter gradient"
+    assert torch.equal(r0["param"], r1["param"]) and not torch.equal(r0["param"], r0["start"])
+    assert r0["reduced"] == 2 * 2 * r0["start"].numel()        # one bucket of numel bf16 elements per step
+    local = []
+    for rank in (0, 1):
+        _, trained, step = _case("lokr", seed=20 + rank)
+        with torch.no_grad():
+            trained.flat_param.copy_(r0["start"].to(DEV))
+        step(0)
+        torch.cuda.synchronize()
+        local.append(trained.flat_grad.float().cpu())
+    mean = (local[0] + local[1]) / 2
+    err = ((r0["grads"][0].float() - mean).norm() / mean.norm()).item()
+    print(f"[parity] world-2 LoKr adapter gradient vs the mean of the two single-rank gradients: rel_l2={err:.3e}")
     assert err <= 6e-3

@@ -42,10 +42,18 @@ def full_models():
     return hip, ref_bf
 
 
-# ONE bucket in the suite (the CPU oracle's two passes over 1.6 B parameters are ~90 s of host time per case): the non-square
-# 24 x 42 bucket with two images of different text length.  The square 32 x 32 bucket ran in every earlier log of the round
-# (profiles/r02_a .. r02_o *_tests_gpu.log; numbers in DESIGN.md section 2) and is one edit away: add (32, 32, (300, 41)).
-@pytest.mark.parametrize("h,w,lens", [(24, 42, (41, 233))])
+# Both bench buckets that differ in kind: the square 32 x 32 one and the non-square 24 x 42 one, two images of different text
+# length each (the CPU oracle's two passes over 1.6 B parameters are ~100 s of host time per case).
+#
+# The HIP side runs the path the benchmark and the trainer run -- ``SanaRecipe.optimize_device``: one packed H2D, PACKED text
+# rows, launch plans on, two forward chains -- TWICE, so that what is compared with the oracle is a REPLAYED plan; then the
+# padded autograd path (``recipe.optimize`` + ``loss.backward()``, what ``model(...)`` callers get) on the same inputs, held to
+# the device path: loss / prediction / image-side gradients bit-identical, text-side weight gradients (sums over text rows
+# cut into different K tiles) within 2e-3.
+TEXT_SIDE = ("caption_projection", "caption_norm", "attn2.to_k", "attn2.to_v")
+
+
+@pytest.mark.parametrize("h,w,lens", [(32, 32, (300, 41)), (24, 42, (41, 233))])
 def test_full_depth_step_matches_oracle(full_models, h, w, lens):
     from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
     from yat_amd.recipe import SanaRecipe
@@ -58,13 +66,37 @@ def test_full_depth_step_matches_oracle(full_models, h, w, lens):
     tap_blocks = (0, 4, 9, 19)
 
     recipe = SanaRecipe(hip, pad_to=512, device=DEV)
-    loss, pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
-    taps_h = {i: hip._saved.blocks[i].x3.detach().clone().view(nb, h * w, -1) for i in tap_blocks}
-    loss.backward()
+    assert hip.use_plans and recipe.packs_text(list(lens)) and hip.fwd_chains == 2
+    replays0 = getattr(hip, "plan_replays", 0)
+    for _ in range(2):                                      # the second call replays the recorded forward / backward plans
+        loss = recipe.optimize_device(latents, embs, torch.Generator())
     torch.cuda.synchronize()
-    grads_h = hip.flat_grad.detach().float().cpu()
+    assert hip.plan_replays - replays0 == 2 and hip._saved.kv_off is not None
+    assert hip._saved.Mt == recipe.packed_rows(sum(lens)) < nb * 512
+    pred = hip._buf("pred", (nb, cfg.out_channels, h * w)).clone().view(nb, cfg.out_channels, h, w)
+    taps_h = {i: hip._saved.blocks[i].x3.detach().clone().view(nb, h * w, -1) for i in tap_blocks}
+    grads_dev = hip.flat_grad.detach().clone()
+    grads_h = grads_dev.float().cpu()
     assert torch.isfinite(grads_h).all()
     offs, numel = hip._offset, dict(zip(hip._offset, hip._seg_numel))
+
+    # the padded autograd path on the same inputs and draws
+    loss_p, pred_p, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
+    loss_p.backward()
+    torch.cuda.synchronize()
+    assert hip._saved.kv_off is None
+    assert torch.equal(loss_p.detach(), loss) and torch.equal(pred_p.detach(), pred)
+    worst = 0.0
+    for k in hip.P:
+        a, b = grads_dev[offs[k]:offs[k] + numel[k]], hip.flat_grad[offs[k]:offs[k] + numel[k]]
+        if any(t in k for t in TEXT_SIDE):
+            r = ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+            worst = max(worst, r)
+            assert r <= 2e-3, (k, r)
+        else:
+            assert torch.equal(a, b), k
+    print(f"[parity] full depth {h}x{w}: device path (packed text, replayed plans) vs padded autograd path: loss / prediction / "
+          f"image-side gradients bit-identical, text-side weight gradients within {worst:.2e}")
 
     def oracle(model, dtype):
         t0 = time.time()
@@ -87,6 +119,7 @@ def test_full_depth_step_matches_oracle(full_models, h, w, lens):
     del ref_32
 
     l_h = loss.item()
+    print(f"[parity] full depth {h}x{w}: HIP results below are the device path's (optimize_device: packed text, plans replayed)")
     print(f"[parity] full depth {h}x{w}: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
     for i in tap_blocks:
         e_h, e_b = rel(taps_h[i], taps_t[i]), rel(taps_b[i], taps_t[i])
@@ -109,3 +142,70 @@ def test_full_depth_step_matches_oracle(full_models, h, w, lens):
             e1, e2 = (grads_h[lo:hi] - g_t[lo:hi]).norm().item() / d, (g_b[lo:hi] - g_t[lo:hi]).norm().item() / d
             print(f"[parity] full depth {h}x{w}: grads bucket {bi:2d}: hip={e1:.3e} oracle_bf16={e2:.3e}")
             assert e1 <= 1.5 * e2 + 2e-3, (bi, e1, e2)
+
+
+# ---- the bench step at its own width and batch, on every bench bucket, without the oracle: what bench.py times is
+# ``train_step_device`` with packed text rows, replayed launch plans and two forward chains at D = 2240, B = 8 on the buckets
+# 32x32 / 16x64 / 24x42 / 44x22 with prompts of 20..300 tokens (train_sana.py:163-219).  The oracle pins the padded path (tiny
+# configs, one real-width block, the full-depth test above at B = 2); here the packed / planned step is held to the padded /
+# unplanned one AT the bench's shapes: loss, prediction and every image-side gradient bit-identical, the text-side weight
+# gradients (a sum over text rows cut into different K tiles) within 2e-3; plans on vs off bit-identical everywhere.
+BENCH_BUCKETS = [(32, 32), (16, 64), (24, 42), (44, 22)]
+
+
+@pytest.fixture(scope="module")
+def wide_model():
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    hip = SanaTransformer2DModelHIP(SanaConfig(num_layers=2), device=DEV).init_synthetic(3)
+    with torch.no_grad():
+        for name, p in hip.P.items():
+            if name.endswith("scale_shift_table") and p.shape[0] == 6:
+                p.add_(0.5)
+    return hip
+
+
+@pytest.mark.parametrize("h,w", BENCH_BUCKETS)
+def test_full_width_bench_step_packed_and_planned(wide_model, h, w, monkeypatch):
+    from yat_amd.recipe import SanaRecipe
+    hip = wide_model
+    cfg = hip.cfg
+    B = 8
+    g = torch.Generator().manual_seed(1234 + h)
+    lens = torch.randint(20, 301, (B,), generator=g).tolist()                 # bench.py's prompt lengths
+    latents = (torch.randn(B, cfg.in_channels, h, w, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in lens]
+    offs, numel = hip._offset, dict(zip(hip._offset, hip._seg_numel))
+
+    def run(pack, plans, calls):
+        monkeypatch.setenv("YAT_TEXT_PACK", pack)
+        hip.use_plans = plans
+        recipe = SanaRecipe(hip, pad_to=512, device=DEV)
+        r0 = getattr(hip, "plan_replays", 0)
+        for _ in range(calls):
+            loss = recipe.optimize_device(latents, embs, torch.Generator())
+        torch.cuda.synchronize()
+        assert (hip._saved.kv_off is not None) == (pack == "1")
+        if plans:
+            assert hip.plan_replays - r0 >= 2 * (calls - 1)                   # the compared result is a replay
+        return (loss.clone(), hip._buf("pred", (B, cfg.out_channels, h * w)).clone(), hip.flat_grad.clone(), hip._saved.Mt)
+
+    try:
+        l1, p1, g1, mt = run("1", True, 3)          # the bench's configuration, replayed twice
+        l2, p2, g2, _ = run("1", False, 1)          # same, every launch re-derived in Python
+        l0, p0, g0, mt0 = run("0", True, 2)         # the reference's padded layout
+    finally:
+        hip.use_plans = True
+    assert mt < mt0 == B * 512 and torch.isfinite(g1.float()).all() and torch.isfinite(l1)
+    assert torch.equal(l1, l2) and torch.equal(p1, p2) and torch.equal(g1, g2), "launch plans on vs off differ"
+    assert torch.equal(l1, l0) and torch.equal(p1, p0)
+    worst = 0.0
+    for k in hip.P:
+        a, b = g1[offs[k]:offs[k] + numel[k]], g0[offs[k]:offs[k] + numel[k]]
+        if any(t in k for t in TEXT_SIDE):
+            r = ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+            worst = max(worst, r)
+            assert r <= 2e-3, (k, r)
+        else:
+            assert torch.equal(a, b), k
+    print(f"[parity] bench step D=2240 B=8 {h}x{w} ({sum(lens)} text rows -> {mt} packed of {mt0}): plans on == off bit for bit; "
+          f"packed == padded bit for bit in loss / prediction / image-side gradients, text-side weight gradients {worst:.2e}")

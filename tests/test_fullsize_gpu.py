@@ -229,3 +229,97 @@ def test_pixart_self_attention_full_size(ops):
         as_good_as(out, obf, o32, f"pixart_sdpa_fwd N={Np}")
         for name, sl in (("dq", slice(0, Dp)), ("dk", slice(Dp, 2 * Dp)), ("dv", slice(2 * Dp, 3 * Dp))):
             as_good_as(dqkv[:, sl], gbf[:, sl], g32[:, sl], f"pixart_sdpa_{name} N={Np}")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 (SD3.5-Medium at 1024 px) at its own token counts: joint attention over 4096 image + 333 text tokens,
+# 24 heads x 64 (train_sd35.py:165-194 -> JointAttnProcessor2_0 [RECALL]); the head-dim instantiation <2, 4>, the
+# 128 / 192-query workgroups, the XCD-contiguous order and the dense dK/dV grid only run at these sizes.
+SD_B, SD_N, SD_T, SD_H, SD_DH = 2, 4096, 333, 24, 64
+
+
+@pytest.mark.parametrize("L,tag", [(SD_N + SD_T, "joint 4096+333"), (SD_N, "image-only second attention 4096")])
+def test_sd35_attention_full_size(ops, L, tag):
+    """The joint attention (L = 4429) and the dual blocks' image-only attention (L = 4096) exactly as yat_amd/sd3.py launches
+    them -- q | k | v = column blocks of the [B*L, 3D] joint buffer, zero bias, kv_len = L -- forward, dQ, dK, dV against torch
+    (fp32 truth, torch's own bf16 kernel as the yardstick) on two images."""
+    Bs, Hs, dh = SD_B, SD_H, SD_DH
+    Ds = Hs * dh
+    scale = 1 / math.sqrt(dh)
+    qkv = grnd(Bs * L, 3 * Ds, seed=41)
+    dout = grnd(Bs * L, Ds, scale=0.1, seed=42)
+    out, lse = torch.empty(Bs * L, Ds, dtype=BF, device=DEV), torch.empty(Bs, Hs, L, device=DEV)
+    zero = torch.zeros(Bs, L, device=DEV)
+    full = torch.full((Bs,), L, dtype=torch.int32, device=DEV)
+    q, k, v = qkv[:, :Ds], qkv[:, Ds:2 * Ds], qkv[:, 2 * Ds:]
+    ops.sdpa_fwd(q, k, v, Bs, L, L, Hs, dh, scale, zero, full, out, lse)
+    dqkv = torch.full_like(qkv, float("nan"))
+    ops.sdpa_bwd(q, k, v, Bs, L, L, Hs, dh, scale, zero, full, out, dout, lse, torch.empty(Bs, Hs, L, device=DEV),
+                 dqkv[:, :Ds], dqkv[:, Ds:2 * Ds], dqkv[:, 2 * Ds:])
+    assert torch.isfinite(dqkv.float()).all() and torch.isfinite(lse).all()
+
+    def torch_path(dt):
+        t = qkv.to(dt).clone().requires_grad_(True)
+        heads = lambda x: x.reshape(Bs, L, Hs, dh).transpose(1, 2)
+        o = F.scaled_dot_product_attention(heads(t[:, :Ds]), heads(t[:, Ds:2 * Ds]), heads(t[:, 2 * Ds:]))
+        o = o.transpose(1, 2).reshape(Bs * L, Ds)
+        o.backward(dout.to(dt))
+        return o.detach(), t.grad
+    o32, g32 = torch_path(torch.float32)
+    obf, gbf = torch_path(BF)
+    as_good_as(out, obf, o32, f"sd35_sdpa_fwd {tag}")
+    for name, sl in (("dq", slice(0, Ds)), ("dk", slice(Ds, 2 * Ds)), ("dv", slice(2 * Ds, 3 * Ds))):
+        as_good_as(dqkv[:, sl], gbf[:, sl], g32[:, sl], f"sd35_sdpa_{name} {tag}")
+    # a second run is bit-identical (no atomics, fixed reduction order)
+    out2, lse2, dqkv2 = torch.empty_like(out), torch.empty_like(lse), torch.empty_like(qkv)
+    ops.sdpa_fwd(q, k, v, Bs, L, L, Hs, dh, scale, zero, full, out2, lse2)
+    ops.sdpa_bwd(q, k, v, Bs, L, L, Hs, dh, scale, zero, full, out2, dout, lse2, torch.empty(Bs, Hs, L, device=DEV),
+                 dqkv2[:, :Ds], dqkv2[:, Ds:2 * Ds], dqkv2[:, 2 * Ds:])
+    assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(dqkv, dqkv2)
+
+
+def test_sd35_qknorm_concat_full_rows(ops):
+    """``yat_qknorm_concat_fwd/bwd`` at B x 4429 rows (B = 8, the bench's batch): per-head RMSNorm of q | k of both streams +
+    the row concatenation of JointAttnProcessor2_0 [RECALL], forward bit-exact against the bf16 restatement, backward against
+    fp32 autograd of the same function (evaluated on the GPU: 163 M elements)."""
+    Bq, N_, T_, H_, dh = 8, SD_N, SD_T, SD_H, SD_DH
+    Dq, L, eps = H_ * dh, SD_N + SD_T, 1e-6
+    qkv_i, qkv_t = grnd(Bq * N_, 3 * Dq, seed=51), grnd(Bq * T_, 3 * Dq, seed=52)
+    ws = [(1.0 + 0.2 * torch.randn(dh, generator=torch.Generator().manual_seed(60 + j))).to(BF).to(DEV) for j in range(4)]
+    joint = torch.empty(Bq * L, 3 * Dq, dtype=BF, device=DEV)
+    rstd = torch.empty(Bq * L, 2 * H_, dtype=torch.float32, device=DEV)
+    ops.qknorm_concat_fwd(qkv_i, qkv_t, Bq, N_, T_, H_, dh, eps, ws[0], ws[1], ws[2], ws[3], joint, rstd)
+
+    def rms(x, w, dt):
+        y = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps)
+        if dt == BF:
+            y = y.to(BF)
+        return (y * w.to(dt)).to(dt)
+
+    def ref(dt):
+        xi = qkv_i.to(dt).view(Bq, N_, 3, H_, dh).requires_grad_(True)
+        xt = qkv_t.to(dt).view(Bq, T_, 3, H_, dh).requires_grad_(True)
+        w = [t.to(dt).requires_grad_(True) for t in ws]
+        qq = torch.cat([rms(xi[:, :, 0], w[0], dt), rms(xt[:, :, 0], w[2], dt)], 1)
+        kk = torch.cat([rms(xi[:, :, 1], w[1], dt), rms(xt[:, :, 1], w[3], dt)], 1)
+        vv = torch.cat([xi[:, :, 2], xt[:, :, 2]], 1)
+        return torch.stack([qq, kk, vv], dim=2).reshape(Bq * L, 3 * Dq), (xi, xt), w
+    with torch.no_grad():
+        o_bf, _, _ = ref(BF)
+    assert torch.equal(joint, o_bf), "forward is not bit-identical to the bf16 restatement"
+    del o_bf
+    dj = grnd(Bq * L, 3 * Dq, seed=55)
+    o32, parts, w32 = ref(torch.float32)
+    o32.backward(dj.float())
+    del o32
+    dqi, dqt = torch.empty_like(qkv_i), torch.empty_like(qkv_t)
+    dws = [torch.zeros(dh, dtype=BF, device=DEV) for _ in range(4)]
+    wsb = torch.empty(ops.qknorm_concat_bwd_workspace_bytes(Bq, N_, T_, dh), dtype=torch.uint8, device=DEV)
+    ops.qknorm_concat_bwd(qkv_i, qkv_t, Bq, N_, T_, H_, dh, ws[0], ws[1], ws[2], ws[3], rstd, dj, dqi, dqt, dws[0], dws[1],
+                          dws[2], dws[3], wsb)
+    e_i = rel(dqi, parts[0].grad.reshape(Bq * N_, 3 * Dq))
+    e_t = rel(dqt, parts[1].grad.reshape(Bq * T_, 3 * Dq))
+    e_w = [rel(dws[j], w32[j].grad) for j in range(4)]
+    print(f"[parity] qknorm_concat B={Bq} N={N_} T={T_} H={H_} dh={dh} ({Bq * L} rows): fwd bit-exact; d_img {e_i:.3e} "
+          f"d_txt {e_t:.3e} d_w {max(e_w):.3e}")
+    assert e_i <= 4e-3 and e_t <= 4e-3 and max(e_w) <= 8e-3

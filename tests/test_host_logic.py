@@ -151,3 +151,25 @@ def test_flop_accounting_matches_survey():
     from yat_amd.sana import SanaConfig
     f = bench.train_flops_per_image(SanaConfig(), 1024, 512)
     assert abs(f / 9.285e12 - 1) < 2e-3                 # 9.285 TFLOP / image
+
+
+def test_empty_embedding_layout_is_checked_per_recipe():
+    """CFG dropout (common/trainer.py:306-308,319-323) substitutes ``empty_embeddings[0]`` per sample: SANA / PixArt expect a
+    list with one [L, C] tensor, SD3.5 a (prompt [T, C], pooled [P]) pair -- a file in the wrong layout is refused by name
+    instead of being sliced by rows."""
+    import pytest
+    from train_sd35 import SD35Trainer
+    from yat_amd.common.trainer import Model
+    t = torch.randn(5, 8)
+    assert Model.check_empty_embeddings(None, t, "f.pt")[0] is t
+    assert Model.check_empty_embeddings(None, [t], "f.pt")[0] is t
+    with pytest.raises(ValueError, match="f.pt"):
+        Model.check_empty_embeddings(None, {"x": 1}, "f.pt")
+    pair = (torch.randn(333, 16), torch.randn(1, 32))
+    for given in (pair, [pair], (pair[0][None], pair[1])):
+        got = SD35Trainer.check_empty_embeddings(None, given, "e.pt")
+        assert len(got) == 1 and got[0][0].shape == (333, 16) and got[0][1].shape == (32,)
+    with pytest.raises(ValueError, match="e.pt"):
+        SD35Trainer.check_empty_embeddings(None, t, "e.pt")
+    with pytest.raises(ValueError, match="e.pt"):
+        SD35Trainer.check_empty_embeddings(None, [t], "e.pt")

@@ -58,9 +58,9 @@ def test_loha_training_step_matches_oracle():
     hip.load_state_dict(ref_bf.state_dict())
     ad = LoHaAdapters(hip, TARGETS, r=2, alpha=4.0)
     g = torch.Generator().manual_seed(7)
-    for e in ad.entries:                                    # meaningful adapters: w2_a away from its zero init
-        w2a = ad._views(e, ad.flat_param)[2]
-        w2a[:, :ad.r].copy_((torch.randn(e["out"], ad.r, generator=g) * 0.3).to(BF))
+    for e in ad.entries:                                    # meaningful adapters: w2_b away from its zero init
+        w2b = ad._views(e, ad.flat_param)[3]
+        w2b[:ad.r].copy_((torch.randn(ad.r, e["inn"], generator=g) * 0.3).to(BF))
     wrapped = apply_loha(ref_bf, TARGETS, r=2, alpha=4.0)
     assert sorted(wrapped) == sorted(e["module"] for e in ad.entries)
     sd = ad.state_dict()
@@ -131,8 +131,8 @@ def test_loha_module_dropout_drops_the_adapter():
     _, base_pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
     ad = LoHaAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=1.0 - 1e-9)
     for e in ad.entries:
-        w2a = ad._views(e, ad.flat_param)[2]
-        w2a[:, :2].copy_((torch.randn(e["out"], 2, generator=g) * 0.3).to(BF))
+        w2b = ad._views(e, ad.flat_param)[3]
+        w2b[:2].copy_((torch.randn(2, e["inn"], generator=g) * 0.3).to(BF))
     loss, pred, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True)
     loss.backward()
     torch.cuda.synchronize()

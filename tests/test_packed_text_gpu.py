@@ -132,3 +132,45 @@ def test_packed_step_matches_padded_step(B, h, w, lens, pad_to, layers, modified
             assert torch.equal(g0[k], g1[k]), k
     print(f"[parity] packed vs padded step: loss / prediction / image-side gradients bit-identical; "
           f"text-side weight gradients within {worst:.2e} rel L2")
+
+
+def test_accumulation_with_changing_packed_rows_and_plans(monkeypatch):
+    """Gradient accumulation x packed text x launch plans (common/trainer.py:317,343-346: ``accelerator.accumulate``): the
+    second micro-step REPLAYS the forward plan (recorded for the first micro-step's row count) and then RECORDS its backward
+    plan, because ``accumulate_grads`` flipped.  The recorded backward must run over this batch's text rows, not over the
+    rows of the batch the forward was recorded with: flat gradients with plans on are bit-equal to plans off, over two
+    accumulation windows whose four batches all have different packed row counts (more rows and fewer rows than recorded)."""
+    from oracle.sana_ref import SanaConfig as RefCfg
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    rcfg = RefCfg.tiny(num_layers=2)
+    kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
+    B, h, w, pad_to = 2, 6, 10, 512
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for lens in ([100, 90], [300, 310], [400, 500], [20, 30]):        # packed rows 256, 768, 1024, 256 (of 1024 padded)
+        lat = (torch.randn(B, rcfg.in_channels, h, w, generator=g) * 0.5).to(BF)
+        batches.append((lat, [torch.randn(L, rcfg.caption_channels, generator=g).to(BF) for L in lens]))
+    res = {}
+    for plans in ("1", "0"):
+        monkeypatch.setenv("YAT_LAUNCH_PLANS", plans)
+        hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV).init_synthetic(4)
+        assert hip.use_plans == (plans == "1")
+        recipe = SanaRecipe(hip, pad_to=pad_to, device=DEV)
+        grads, losses = [], []
+        for i, (lat, embs) in enumerate(batches):
+            hip.accumulate_grads = bool(i & 1)                         # windows of two micro-steps
+            losses.append(recipe.optimize_device(lat, embs, torch.Generator().manual_seed(70 + i), gscale=0.5).clone())
+            assert hip._saved.kv_off is not None and hip._saved.Mt == recipe.packed_rows(sum(e.shape[0] for e in embs))
+            if i & 1:
+                torch.cuda.synchronize()
+                grads.append(hip.flat_grad.clone())
+        if plans == "1":
+            assert getattr(hip, "plan_replays", 0) >= 5                # fwd x3, bwd x2 replayed
+        res[plans] = (losses, grads)
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert torch.equal(a, b)
+    for wi, (a, b) in enumerate(zip(res["1"][1], res["0"][1])):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b), f"window {wi}: {(a != b).sum().item()} gradient elements differ between plans on / off"
+    print("[parity] accumulation x packed rows x plans: flat gradients of both windows bit-equal with plans on / off")

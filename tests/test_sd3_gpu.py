@@ -211,6 +211,34 @@ def test_sd3_real_width_blocks_match_oracle():
     _compare_step(rcfg, ref_bf, ref_32, hip, 2, 32, 48, 333, "real width", check_adamw=False)
 
 
+def test_sd3_real_width_blocks_at_1024px_token_count():
+    """BASELINE config 4 at its own sequence length: SD3.5-Medium width, one dual block + the context_pre_only block, 128 x 128
+    latents = 4096 image tokens, T = 333 -> joint sequence 4429 (train_sd35.py:165-194).  B = 1 against the CPU oracle in bf16
+    and fp32 (same criteria as every step test), then B = 2 twice: finite everywhere and run-to-run bit-identical (streams,
+    fixed-order reductions at 8858 joint rows)."""
+    from yat_amd.recipe import SD3Recipe
+    rcfg, ref_bf, ref_32, hip = _setup(dict(_full=True, num_layers=2, dual_attention_layers=(0,)))
+    _compare_step(rcfg, ref_bf, ref_32, hip, 1, 128, 128, 333, "real width, 128x128 latents (L = 4429)", check_adamw=False)
+    del ref_bf, ref_32
+    g = torch.Generator().manual_seed(9)
+    latents = (torch.randn(2, rcfg.in_channels, 128, 128, generator=g) * 0.5).to(BF)
+    emb = (torch.randn(2, 333, rcfg.joint_attention_dim, generator=g).to(BF), torch.randn(2, rcfg.pooled_projection_dim, generator=g).to(BF))
+    recipe = SD3Recipe(hip, device=DEV)
+
+    def run():
+        loss, pred, _ = recipe.optimize(latents, emb, torch.Generator().manual_seed(5), return_pred=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), pred.detach().clone(), hip.flat_grad.clone()
+    a, b = run(), run()
+    assert hip._saved.L == 4429 and hip._saved.M == 2 * 4096
+    for x in a:
+        assert torch.isfinite(x.float()).all()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "two runs of the same step differ: stream race or non-deterministic reduction"
+    print(f"[parity] sd3 real width, B=2, 128x128 latents (L = 4429): loss {a[0].item():.6f}, finite, run-to-run bit-identical")
+
+
 def test_sd3_checkpoint_roundtrip_and_determinism(tmp_path):
     from yat_amd.sd3 import SD3Transformer2DModelHIP
     from yat_amd.recipe import SD3Recipe

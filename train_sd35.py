@@ -59,6 +59,21 @@ class SD35Trainer(Model):
     def extract_embeddings(self, captions):
         raise NotImplementedError("text encoding is outside the hot-path scope; train from cached-feature shards")
 
+    def check_empty_embeddings(self, emb, path):
+        """SD3.5's per-sample embedding is a ``(prompt_embeds [T, C], pooled [P])`` pair (``SD3Recipe.stack_embeddings``), so
+        ``empty_embeds.pt`` holds that pair for the empty prompt -- as the pair itself or as a list with the pair (what
+        ``extract_embeddings([''])`` returns, :76-92).  A bare tensor (the SANA / PixArt layout) is an error here: CFG
+        dropout would slice it by rows."""
+        if isinstance(emb, (list, tuple)) and len(emb) == 1 and isinstance(emb[0], (list, tuple)):
+            emb = emb[0]
+        ok = (isinstance(emb, (list, tuple)) and len(emb) == 2 and all(torch.is_tensor(t) for t in emb)
+              and emb[0].ndim in (2, 3) and emb[1].numel() == emb[1].shape[-1])
+        if not ok:
+            raise ValueError(f"{path}: SD3.5 needs the empty prompt's (prompt_embeds [T, C], pooled [P]) pair, got "
+                             f"{type(emb).__name__}" + (f" of shape {tuple(emb.shape)}" if torch.is_tensor(emb) else ""))
+        prompt = emb[0] if emb[0].ndim == 2 else emb[0][0]
+        return [(prompt, emb[1].reshape(-1))]
+
     def validate(self):
         """Middle third of train_sd35.py:94-162: 20-step flow-match Euler sampling with CFG 5.0 over the HIP MMDiT (:129-142),
         generator seeded 42 (:110).  The three text encoders and the VAE are outside this build's scope, so the prompt

@@ -225,8 +225,15 @@ class Model:
                 "extract_embeddings(['']): a list with one [L, C] tensor) next to the shards or in the working directory "
                 f"(looked in: {cands + ['empty_embeds.pt']})")
         emb = torch.load(path, map_location="cpu")
+        return self.check_empty_embeddings(emb, path)
+
+    def check_empty_embeddings(self, emb, path):
+        """SANA / PixArt layout: a list with one ``[L, C]`` tensor (a bare tensor is wrapped).  Recipes with another
+        per-sample embedding layout override this (SD3.5: a ``(prompt [T, C], pooled [P])`` pair, train_sd35.py)."""
         if torch.is_tensor(emb):
             emb = [emb if emb.ndim == 2 else emb[0]]
+        if not (isinstance(emb, (list, tuple)) and len(emb) >= 1 and torch.is_tensor(emb[0]) and emb[0].ndim == 2):
+            raise ValueError(f"{path}: expected extract_embeddings(['']) = a list with one [L, C] tensor")
         return emb
 
     def save_model(self):

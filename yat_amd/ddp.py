@@ -33,6 +33,14 @@ class NativeComm:
     def get(cls, process_group=None):
         if cls._instance is None:
             cls._instance = cls(process_group)
+            cls._instance._group = process_group
+        elif cls._instance._group is not process_group and (
+                dist.is_initialized() and (dist.get_rank(process_group), dist.get_world_size(process_group))
+                != (cls._instance.rank, cls._instance.world) and dist.get_world_size(process_group) > 1):
+            # the library owns ONE communicator (csrc/comm.hip): a second HipDDP over another set of ranks would silently
+            # reduce over the first group's ranks
+            raise RuntimeError("NativeComm was built for another process group (rank "
+                               f"{cls._instance.rank} of {cls._instance.world}); the C-ABI transport holds one communicator")
         return cls._instance
 
     def __init__(self, process_group=None):

@@ -5,7 +5,8 @@ Arithmetic [RECALL peft/tuners/loha/layer.py -- parity unpinned, see oracle/loha
 Linear / 1x1 Conv with weight W [out, in] (``use_effective_conv2d=False``):
     delta_w = ((hada_w1_a @ hada_w1_b) * (hada_w2_a @ hada_w2_b)) * (alpha / r)        (HadaWeight.forward, bf16 op by op)
     result  = base_layer(x) + F.linear(x, delta_w);  the adapter is dropped for a call when rand(1) <= module_dropout
-with w1_a, w1_b, w2_b kaiming-uniform(a=sqrt(5)) and w2_a zeros (``init_weights=True``), and HadaWeight's hand-written
+with w1_a, w1_b, w2_a kaiming-uniform(a=sqrt(5)) and w2_b zeros (``init_weights=True``: LoHaLayer.reset_adapter_parameters
+zeroes hada_w2_b -- the factor that receives the first gradients is therefore w2_b), and HadaWeight's hand-written
 backward: g = d_delta * scale; t1 = g * (w2a w2b); d_w1a = t1 w1b^T; d_w1b = w1a^T t1; t2 = g * (w1a w1b); d_w2a = t2 w2b^T;
 d_w2b = w2a^T t2.
 
@@ -102,12 +103,13 @@ class LoHaAdapters:
         return hit
 
     def reset_parameters(self):
-        """peft init_weights=True: hada_w1_a, hada_w1_b, hada_w2_b kaiming_uniform(a=sqrt(5)) on the CPU then cast, w2_a zeros."""
+        """peft init_weights=True (LoHaLayer.reset_adapter_parameters [RECALL]): hada_w1_a, hada_w1_b, hada_w2_a
+        kaiming_uniform(a=sqrt(5)) in that order (on the CPU, then cast), hada_w2_b zeros."""
         self.flat_param.zero_()
         r = self.r
         for e in self.entries:
-            w1a, w1b, _, w2b = self._views(e, self.flat_param)
-            for t, shape in ((w1b[:r], (r, e["inn"])), (w1a[:, :r], (e["out"], r)), (w2b[:r], (r, e["inn"]))):
+            w1a, w1b, w2a, _ = self._views(e, self.flat_param)
+            for t, shape in ((w1a[:, :r], (e["out"], r)), (w1b[:r], (r, e["inn"])), (w2a[:, :r], (e["out"], r))):
                 init = torch.empty(shape, dtype=torch.float32)
                 torch.nn.init.kaiming_uniform_(init, a=math.sqrt(5))
                 t.copy_(init.to(BF16))

@@ -202,7 +202,28 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                                                                  kv_len=kv_len, kv_work=kv_work, kv_off=kv_off))
         self.param_events = None          # consumed by the forward (recorded or replayed)
         self._saved.kv_work = kv_work
+        if kv_off is not None and self._saved.Mt != int(enc.shape[0]):
+            # a REPLAYED forward hands back the saved state of the step that was recorded: its text-side views are cut for
+            # that batch's row count.  A backward that is recorded now (first micro-step with another accumulate flag, a new
+            # gradient hook, ...) must see THIS batch's rows, or it would sum stale rows into the text-side gradients.
+            self._retarget_text(self._saved, enc)
         return out
+
+    def _retarget_text(self, S, enc):
+        """Re-cut the text-side views of a saved forward for the packed row count of ``enc`` (same addresses: the buffers
+        are sized for the padded layout once, ``Mt_cap``)."""
+        Mt, D, f32 = int(enc.shape[0]), self.cfg.inner_dim, torch.float32
+        if Mt > S.Mt_cap:
+            raise RuntimeError("packed text rows exceed the capacity the forward was recorded with")
+
+        def tb(name, cols, dtype=BF16):
+            return (self._buf(name, (S.Mt_cap, cols), dtype) if cols else self._buf(name, (S.Mt_cap,), dtype))[:Mt]
+        S.Mt, S.enc2d = Mt, enc.view(Mt, -1)
+        S.zc1, S.c1, S.c2, S.encn = tb("cap_z1", D), tb("cap_c1", D), tb("cap_c2", D), tb("cap_n", D)
+        S.enc_rstd = tb("cap_rstd", 0, f32)
+        S.kv2 = [tb(f"b{i}.kv2", 2 * D) for i in range(self.cfg.num_layers)]
+        for A, kv in zip(S.blocks, S.kv2):
+            A.kv2 = kv
 
     def backward_device(self, dpred):
         S = self._saved
@@ -233,7 +254,9 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             raise ValueError("packed text: enc [rows, C] (rows a multiple of 256) with key_bias [B, T], kv_len [B], kv_off [B]")
         T = key_bias.shape[1] if packed else enc.shape[1]
         Mt = enc.shape[0] if packed else B * T
-        Mt_cap = max(B * T, Mt)                    # text-side buffers are sized once, for the padded layout
+        # text-side buffers are sized once, for the padded layout (rounded up to whole row tiles: the most a packed batch
+        # of this bucket can bring, so a replayed plan never meets a longer matrix than its buffers)
+        Mt_cap = max(-(-(B * T) // 256) * 256 if packed else B * T, Mt)
         Cout = cfg.out_channels
         dev = self.dev
         latents = latents.to(device=dev, dtype=BF16).contiguous()
