@@ -18,6 +18,11 @@ The JSON line carries, besides the driver's contract:
                 launch stream; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
   mfma_util_step  whole-step figure: algorithmic training FLOPs (6 x MAC, SURVEY.md 8d: 9.285 TFLOP/image at
                 N=1024,T=512) x img/s/GPU / 2.5e15.
+  comm          (N > 1, or YAT_DDP_FORCE=1 on one GPU) the data-parallel exchange: transport, buckets and bytes reduced per
+                step, per-bucket collective time from HIP events on the communication stream, the step with the collective
+                switched off on the same inputs (exposed time = the difference), how long the optimizer waited, overlap
+                fraction, the RCCL channel cap in force (--rccl-channels N sets NCCL_MAX_NCHANNELS); with --lokr / --lora the
+                latency of the adapter set's single small all-reduce.
   cpu_baseline  the CPU oracle (torch restatement of the reference path; diffusers is absent offline) timed on this
                 box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -257,6 +262,11 @@ def main():
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the serialized GEMM-timing pass")
+    ap.add_argument("--rccl-channels", type=int, default=0, metavar="N",
+                    help="cap RCCL at N channels (NCCL_MAX_NCHANNELS=N before the communicator is built): fewer channels = "
+                         "fewer persistent collective workgroups competing with the GEMM tiles for CUs, at lower link "
+                         "bandwidth; 0 = RCCL's default.  The value in force is reported in the `comm` object")
+    ap.add_argument("--comm-steps", type=int, default=6, help="steps of each pass of the data-parallel diagnostics")
     ap.add_argument("--phases", default=None, metavar="FILE",
                     help="after the timed region, time the phases of 6 steps with HIP events and write them to FILE")
     args = ap.parse_args()
@@ -280,6 +290,10 @@ def main():
     # YAT_DDP_FORCE=1: run the whole data-parallel machinery (RCCL group, bucket hooks on the side stream, comm stream,
     # optimizer wait) even with ONE rank -- the only way to exercise that code path on a single-GPU box.
     force_ddp = os.environ.get("YAT_DDP_FORCE", "0") != "0"
+    if args.rccl_channels > 0:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
+        if int(os.environ.get("NCCL_MIN_NCHANNELS", "0") or 0) > args.rccl_channels:
+            os.environ["NCCL_MIN_NCHANNELS"] = str(args.rccl_channels)
     if world > 1 or force_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -430,6 +444,76 @@ def main():
     log(f"host enqueue of one step onto an idle GPU: {min(host_ms):.1f} ms (per bucket: {', '.join(f'{v:.1f}' for v in host_ms)}; "
         f"launch plans {'on' if model.use_plans else 'off'})")
 
+    # ---- data-parallel diagnostics (after the timed region; SURVEY 8(d) C4 / C5: "report overlap fraction", "report all-reduce
+    # latency for the ~MB-scale gradient set"; replaces what Accelerate's DDP hides behind common/trainer.py:253,344).  Three
+    # passes of --comm-steps steps on the same buckets: the step as timed; the step with the collective itself switched off
+    # (hooks, events, streams, the optimizer's wait all still there): the difference is what the collective costs the step,
+    # overlap and CU interference included; and a pass with HIP events around every bucket's collective on the communication
+    # stream and around the compute stream's wait for it.  Every rank runs them (collectives), rank 0 reports.
+    comm = None
+    if ddp is not None:
+        K = max(2, args.comm_steps)
+        base = args.warmup + args.steps + len(BUCKETS)
+        base += (-base) % len(BUCKETS)                     # every pass starts on the same bucket
+
+        def timed_pass():
+            barrier()
+            tp = time.perf_counter()
+            for i in range(K):
+                step(base + i)
+            barrier()
+            dt = time.perf_counter() - tp
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = tt.item()
+            return 1e3 * dt / K
+        step(base)                                         # (plans of this bucket order are recorded by now; one settle step)
+        ms_live = timed_pass()
+        ddp.dryrun = True
+        ms_dry = timed_pass()
+        ddp.dryrun = False
+        if world > 1:
+            ddp.broadcast_parameters()                     # the dry steps did not average: bring the replicas back together
+        ddp.timing, ddp.timed_buckets, ddp.timed_waits = True, [], []
+        b0, n0 = ddp.bytes_reduced, ddp.buckets_reduced
+        ms_timing = timed_pass()
+        ddp.timing = False
+        torch.cuda.synchronize()
+        durs = sorted(e0.elapsed_time(e1) for _, _, e0, e1 in ddp.timed_buckets)
+        sizes = [nb for _, nb, _, _ in ddp.timed_buckets]
+        waits = [w0.elapsed_time(w1) for w0, w1 in ddp.timed_waits]
+        comm_ms = sum(durs) / K
+        exposed = max(0.0, ms_live - ms_dry)
+        big = [(nb, e0.elapsed_time(e1)) for _, nb, e0, e1 in ddp.timed_buckets if nb >= (32 << 20)]
+        comm = {
+            "world": world, "forced_one_rank": bool(force_ddp and world == 1),
+            "transport": "native (yat_comm_* behind the C ABI)" if ddp.native is not None else f"torch.distributed ({backend})",
+            "buckets_per_step": (ddp.buckets_reduced - n0) / K, "bytes_per_step": (ddp.bytes_reduced - b0) / K,
+            "bucket_mb_min_max": [min(sizes) / 2 ** 20, max(sizes) / 2 ** 20] if sizes else None,
+            "bucket_us_min_median_max": [1e3 * durs[0], 1e3 * durs[len(durs) // 2], 1e3 * durs[-1]] if durs else None,
+            "comm_stream_ms_per_step": comm_ms,
+            # per-rank algorithm bandwidth of the large buckets (bytes / time) and the bus bandwidth a ring moves for it
+            "algbw_gbps_large_buckets": (sum(nb for nb, _ in big) / (1e-3 * sum(t for _, t in big)) / 1e9) if big else None,
+            "busbw_factor": 2.0 * (world - 1) / world,
+            "step_ms": ms_live, "step_ms_collective_off": ms_dry, "step_ms_timing_pass": ms_timing,
+            "exposed_ms_per_step": exposed,
+            "optimizer_wait_ms_per_step": sum(waits) / max(1, len(waits)),
+            "overlap_frac": (1.0 - min(1.0, exposed / comm_ms)) if comm_ms > 0 else None,
+            "rccl_channels": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")},
+            "coalesce": ddp.coalesce, "steps_per_pass": K,
+            "note": ("exposed = step - step with the collective switched off (same inputs, same hooks / events / streams); "
+                     "overlap_frac = 1 - exposed / summed comm-stream time; optimizer_wait = how long the compute stream sat "
+                     "in HipDDP.wait() before clip + AdamW" + ("; ONE rank: RCCL runs its one-rank copy kernel, the link "
+                     "figures mean nothing -- the line is a rehearsal of the reporting" if world == 1 else "")),
+        }
+        if args.lokr or args.lora:
+            # BASELINE config 5: ONE small bucket (the adapter set's flat gradient), latency-bound
+            comm["adapter_allreduce_latency_us"] = 1e3 * durs[len(durs) // 2] if durs else None
+            comm["adapter_bucket_bytes"] = sizes[0] if sizes else None
+        log(f"data-parallel diagnostics: step {ms_live:.2f} ms, collective off {ms_dry:.2f} ms, comm stream {comm_ms:.2f} ms/step "
+            f"-> overlap {comm['overlap_frac']}")
+
     # ---- optional phase probe (after the timed region; nothing of it runs otherwise): GPU timestamps of the step's phases
     # from a handful of HIP events per step -- unlike a profiler's kernel trace it does not slow the host's enqueue, so the
     # streams overlap as they do in the timed region.
@@ -515,6 +599,8 @@ def main():
             "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),
             "algorithmic_tflop_per_step": flops / args.steps / 1e12,
         }
+        if comm is not None:
+            res["comm"] = comm
         if timer:
             gf = sum(t[0] for t in timer)
             gms = sum(t[1].elapsed_time(t[2]) for t in timer)

@@ -10,7 +10,9 @@
  * `stream` is a hipStream_t passed as void*; every call only enqueues work (no sync, no
  * allocation, graph-capturable) and returns 0 on success, a negative yat error for bad arguments
  * or a positive hipError_t from the launch.  The library keeps no global mutable state except the
- * RCCL communicator of the communication section at the end.
+ * RCCL communicator of the communication section at the end, and reads no environment variable: the
+ * YAT_* tuning switches named in the sources exist only in builds made with -DYAT_TUNING
+ * (scripts/build_variant.py), in the product library each is its constant default.
  */
 #ifndef YAT_HIP_H
 #define YAT_HIP_H
@@ -70,13 +72,6 @@ typedef struct yat_gemm_epilogue {
 
 uint64_t yat_gemm_epilogue_size(void);   /* sizeof(yat_gemm_epilogue) in this build of the library */
 
-/* Host hint for the tile-shape / split-K policy of the entry points below (variant 0): how many independent streams of
- * GEMMs the caller keeps in flight (1 = each GEMM has the chip to itself, the default; the training step declares 2: two
- * forward chains, dgrad beside wgrad).  With more than one, a launch is charged its CU-time (but at least 3/8 of the
- * chip) instead of whole rounds, so it is not split or narrowed to fill a round its neighbour would have filled.  Process-wide, read at launch time; 1..8.  No reference counterpart (torch
- * picks its GEMM algorithms per call, unaware of the caller's streams).                                                      */
-int yat_gemm_set_concurrency(int streams);
-
 /* C[M,N] = epilogue(A_op * B_op).  a_t=0: A is [M,K] (k contiguous); a_t=1: A is [K,M].
  * b_t=0: B is [N,K] (k contiguous, nn.Linear weight layout); b_t=1: B is [K,N].
  * (0,0) forward y = x W^T; (0,1) dgrad dx = dy W; (1,1) wgrad dW = dy^T x; (1,0) x^T W^T.
@@ -84,9 +79,17 @@ int yat_gemm_set_concurrency(int streams);
 int yat_gemm_bf16(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                   void* C, int ldc, const yat_gemm_epilogue* ep, yat_stream_t stream);
 
-/* Same, with an optional split-K workspace and an explicit tile variant for tests / tuning.
- * variant: 0 = automatic policy, 1 = 128x128 tile, 4 = 256x256 tile, 5 = 256x320 tile (two staggered wave groups,
- * gemm256.hip); 100*s + v forces split-K factor s (2 or 4) on variant v (4 or 5).
+/* Same, with an optional split-K workspace and a per-call POLICY WORD `variant` = v + 100*s + 10000*c:
+ *   v  tile variant: 0 = automatic policy, 1 = 128x128 tile, 4 = 256x256 tile, 5 = 256x320 tile (two staggered wave
+ *      groups, gemm256.hip);
+ *   s  0 = the policy decides; 1..32 forces that split-K factor on variant 4 or 5 (tests / tuning);
+ *   c  host hint for the automatic policy: how many independent streams of GEMMs the caller keeps in flight while this
+ *      launch runs (0 or 1 = the launch has the chip to itself; the training step passes 2: two forward chains, dgrad
+ *      beside wgrad; at most 8).  With more than one, a launch is charged its CU-time (but at least 3/8 of the chip)
+ *      instead of whole rounds, so it is not split or narrowed to fill a round its neighbour would have filled.  The hint
+ *      travels with the call -- the library keeps no policy state -- and changes tile / split choice only, i.e. the
+ *      summation order of the result, never its meaning.  No reference counterpart (torch picks its GEMM algorithms per
+ *      call, unaware of the caller's streams).
  * workspace (fp32, >= ksplit*M*N*4 bytes) lets the policy split K for shapes that leave CUs idle (small outputs with a
  * long reduction: weight gradients); with workspace == NULL K is never split. */
 int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const void* A, int lda, const void* B, int ldb,

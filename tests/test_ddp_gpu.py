@@ -320,3 +320,38 @@ def test_world2_over_gloo_adapter_step(tmp_path):
     err = ((r0["grads"][0].float() - mean).norm() / mean.norm()).item()
     print(f"[parity] world-2 LoKr adapter gradient vs the mean of the two single-rank gradients: rel_l2={err:.3e}")
     assert err <= 6e-3
+
+
+@pytest.mark.parametrize("transport", ["torch", "native"])
+def test_ddp_diagnostic_modes_do_not_change_results(one_rank_group, transport):
+    """bench.py's `comm` object is measured with HipDDP.timing (HIP events around every bucket's collective and around the
+    optimizer's wait) and HipDDP.dryrun (everything but the collective): under a one-rank group both must leave gradients and
+    parameters bit-identical to the plain step, time every bucket once per step and clear their bookkeeping."""
+    from yat_amd.ddp import HipDDP, NativeComm
+    from yat_amd.optim import FlatAdamW
+    g0, p0, _, n = _two_steps(None, "sana")
+    model, trained, step = _case("sana")
+    ddp = HipDDP(trained, force=True, transport=transport)
+    try:
+        ddp.broadcast_parameters()
+        opt = FlatAdamW(trained, lr=1e-3, weight_decay=0.01, overlap_update=True)
+        grads = []
+        for s, (timing, dry) in enumerate([(True, False), (False, True)]):
+            ddp.timing, ddp.dryrun = timing, dry
+            step(s)
+            ddp.wait()
+            grads.append(trained.flat_grad.clone())
+            opt.step()
+        trained.join_pending_update()
+        torch.cuda.synchronize()
+        nb = len(trained.bucket_bounds)
+        assert len(ddp.timed_buckets) == nb and len(ddp.timed_waits) == 1
+        assert sum(b for _, b, _, _ in ddp.timed_buckets) == 2 * n
+        assert all(e0.elapsed_time(e1) >= 0.0 for _, _, e0, e1 in ddp.timed_buckets)
+        assert ddp.timed_waits[0][0].elapsed_time(ddp.timed_waits[0][1]) >= 0.0
+        for a, b in zip(g0, grads):
+            assert torch.equal(a, b)
+        assert torch.equal(p0, trained.flat_param)
+    finally:
+        if NativeComm._instance is not None:
+            NativeComm.get().destroy()

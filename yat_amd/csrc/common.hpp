@@ -15,6 +15,18 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #include "../../include/yat_hip.h"      // status codes (YAT_OK, YAT_EINVAL, ...) and the entry-point prototypes
 #define YAT_LDS __attribute__((address_space(3)))
 
+// Tuning switches.  The product library reads NO environment variable and keeps no mutable policy state (include/yat_hip.h,
+// "ABI rules"): every YAT_TUNE_* site below is the constant default there.  A tuning build (-DYAT_TUNING, made by
+// scripts/build_variant.py for same-box A/B runs through YAT_HIP_LIB) reads the named variable once instead.
+#include <stdlib.h>
+#ifdef YAT_TUNING
+#define YAT_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define YAT_TUNE_F64(name, dflt) (getenv(name) ? atof(getenv(name)) : (dflt))
+#else
+#define YAT_TUNE_INT(name, dflt) (dflt)
+#define YAT_TUNE_F64(name, dflt) (dflt)
+#endif
+
 #define YAT_CHECK_LAUNCH()                                  \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

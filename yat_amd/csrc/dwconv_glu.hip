@@ -205,7 +205,7 @@ using namespace v32w3;      // pass 2 below shares this variant's staging helper
 template <int MODE>
 int launch_tile_best(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t* wdw, const bf16_t* bdw, const bf16_t* dy,
                      bf16_t* out, bf16_t* u_out, hipStream_t stream) {
-    static const int force = getenv("YAT_DW_VARIANT") ? atoi(getenv("YAT_DW_VARIANT")) : 0;     // 1: v32w3, 2: v64w3, 3: v64w2
+    static const int force = YAT_TUNE_INT("YAT_DW_VARIANT", 0);     // 1: v32w3, 2: v64w3, 3: v64w2
     int v = MODE == 0 ? (w > 48 ? 3 : 2) : 1;
     if (force) v = force;
     if (v == 3 && v64w2::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream) == 0) return 0;
@@ -557,7 +557,7 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     int threads2 = 256;
     // pass 2 variants: 64 channels per tile with s, z straight from global (128-byte pixel slices everywhere; 1), or the
     // 32-channel kernel with all three operands tiled in LDS (2); YAT_DW_BWD2=2 forces the latter
-    static const int bwd2_force = getenv("YAT_DW_BWD2") ? atoi(getenv("YAT_DW_BWD2")) : 0;
+    static const int bwd2_force = YAT_TUNE_INT("YAT_DW_BWD2", 0);
     // measured (B = 8, Hc = 5600, us, 32-channel all-LDS kernel -> 64-channel global-s/z kernel): 32x32 237 -> 172,
     // 44x22 228 -> 211, but 24x42 199 -> 216 and 16x64 228 -> 246: narrow rows only
     int nparts = (bwd2_force == 2 || (bwd2_force == 0 && w > 32)) ? 0 : v64w3::launch_bwd2_gs(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)z, du,

@@ -166,27 +166,25 @@ double est_time_128(int M, int N, int K) {
     const double rounds = ceil(tiles / 512.0);
     return rounds * 2.0 * (2.0 * 128 * 128 * (double)K) / 3.4e12;
 }
-int g_gemm_streams = 1;      // host hint: independent GEMM streams sharing the chip
-
-double est_time_256(int M, int N, int K, int BNv, int ksplit) {
+// ``streams``: the caller's per-call hint (policy word of yat_gemm_bf16_ex): independent GEMM streams sharing the chip
+double est_time_256(int M, int N, int K, int BNv, int ksplit, int streams) {
     const double tiles = (double)((M + 255) / 256) * ((N + BNv - 1) / BNv) * ksplit;
     // A GEMM of the training step seldom has the chip to itself (weight gradients on the side stream beside the dgrad chain, two
     // forward chains), and a whole-round model then picks wrongly: it splits K (slab traffic + a reduce kernel) or takes the
     // narrower tile to fill a last round that the neighbouring stream would have filled anyway.  The host says how many
-    // independent GEMM streams it keeps in flight (yat_gemm_set_concurrency).  One: whole rounds, the choice that is fastest
+    // independent GEMM streams it keeps in flight (per call, in the policy word of yat_gemm_bf16_ex).  One: whole rounds, the choice that is fastest
     // for the launch alone.  More: the launch is charged its CU-time (tiles / 256 rounds) but at least 0.375 of the chip, so K
     // is still split until ~96 workgroups exist (a 25-tile K = 32768 weight gradient left unsplit is cheap in CU-time and
     // 0.75 ms long: the side stream becomes the critical path).  Measured in the step on one box, every bench
     // (scripts/gpu_policy_sweep.sh): whole rounds -> this: SANA 88.3 -> 86.0 ms, PixArt 235 -> 232, LoKr B=32 354 -> 352;
     // floor 0.25 loses PixArt (260), no floor loses LoKr (431) and PixArt (315); planning for a 128-CU share with whole
     // rounds of THAT (the obvious model) keeps half the gain (87.4).  YAT_GEMM_ROUND_W / _FLOOR: the sweep's knobs.
-    static const char* rw_env = getenv("YAT_GEMM_ROUND_W");
+    static const double round_w = YAT_TUNE_F64("YAT_GEMM_ROUND_W", -1.0);
     double rounds;
-    if (rw_env) {
-        static const double round_w = atof(rw_env);
-        static const double round_floor = getenv("YAT_GEMM_ROUND_FLOOR") ? atof(getenv("YAT_GEMM_ROUND_FLOOR")) : 0.375;
+    if (round_w >= 0.0) {
+        static const double round_floor = YAT_TUNE_F64("YAT_GEMM_ROUND_FLOOR", 0.375);
         rounds = round_w * ceil(tiles / 256.0) + (1.0 - round_w) * fmax(tiles / 256.0, round_floor);
-    } else if (g_gemm_streams <= 1) {
+    } else if (streams <= 1) {
         rounds = ceil(tiles / 256.0);                        // alone on the chip: whole rounds
     } else {
         rounds = fmax(tiles / 256.0, 0.375);                 // sharing it: CU-time, but spread over >= 96 CUs
@@ -248,13 +246,6 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
 
 extern "C" uint64_t yat_gemm_epilogue_size(void) { return sizeof(yat_gemm_epilogue); }
 
-extern "C" int yat_gemm_set_concurrency(int streams) {
-    static const int forced = getenv("YAT_GEMM_CONCURRENCY") ? atoi(getenv("YAT_GEMM_CONCURRENCY")) : 0;
-    if (streams < 1 || streams > 8) return YAT_EINVAL;
-    g_gemm_streams = forced >= 1 && forced <= 8 ? forced : streams;
-    return YAT_OK;
-}
-
 int yat_gemm256_grouped_launch(int a_t, int b_t, int ngroups, const GemmP* probs, hipStream_t stream);
 
 extern "C" int yat_gemm_grouped_bf16(int a_t, int b_t, int count, const yat_gemm_problem* problems, yat_stream_t stream) {
@@ -273,8 +264,17 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
                                 void* C, int ldc, const yat_gemm_epilogue* ep, int variant, void* workspace,
                                 uint64_t workspace_bytes, yat_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    int ksplit = 1;
-    if (variant >= 100) { ksplit = variant / 100; variant %= 100; }     // tests / tuning: 100*ksplit + variant
+    // policy word: tile variant + 100 * forced K split (tests / tuning) + 10000 * independent GEMM streams the caller keeps
+    // in flight (0 / 1: this launch has the chip to itself) -- per call, so the library holds no policy state
+    int ksplit = 1, streams = 1;
+    if (variant < 0) return YAT_EINVAL;
+    if (variant >= 10000) { streams = variant / 10000; variant %= 10000; }
+    if (streams > 8) return YAT_EINVAL;
+    {
+        static const int forced = YAT_TUNE_INT("YAT_GEMM_CONCURRENCY", 0);
+        if (forced >= 1 && forced <= 8) streams = forced;
+    }
+    if (variant >= 100) { ksplit = variant / 100; variant %= 100; }
     if (variant != 0 && variant != 1 && variant != 4 && variant != 5 && variant != 6) return YAT_EINVAL;
     if (ksplit < 1 || ksplit > 32) return YAT_EINVAL;
     GemmP p;
@@ -287,30 +287,30 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     if (p.pre_add && (a_t || b_t || p.glu_u)) return YAT_EINVAL;       // adapter addend: forward layout only
     if (p.dact_z) {                             // activation-backward epilogue: 256-row kernel, dgrad layout only
         if (ksplit != 1 || variant == 1 || a_t || !b_t) return YAT_EINVAL;
-        if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
+        if (variant == 0) variant = est_time_256(M, N, K, 320, 1, streams) < est_time_256(M, N, K, 256, 1, streams) ? 5 : 4;
     }
     if (p.glu_u) {                              // GLU-backward epilogue lives in the 256-row kernel only
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
-        if (variant == 0) variant = est_time_256(M, N, K, 320, 1) < est_time_256(M, N, K, 256, 1) ? 5 : 4;
+        if (variant == 0) variant = est_time_256(M, N, K, 320, 1, streams) < est_time_256(M, N, K, 256, 1, streams) ? 5 : 4;
     }
     if (p.rowsum) {                             // bias gradient fused into the weight gradient: 256 x 256 tile (the 320-wide
         if (ksplit != 1 || (variant != 0 && variant != 4)) return YAT_EINVAL;   // one has no registers for the extra
         variant = 4;                            // accumulators), whole K in one workgroup
     }
-    static const int max_ksplit = getenv("YAT_GEMM_MAX_KSPLIT") ? atoi(getenv("YAT_GEMM_MAX_KSPLIT")) : 32;
-    static const bool pow2_only = getenv("YAT_GEMM_KSPLIT_POW2") && atoi(getenv("YAT_GEMM_KSPLIT_POW2"));
+    static const int max_ksplit = YAT_TUNE_INT("YAT_GEMM_MAX_KSPLIT", 32);
+    static const bool pow2_only = YAT_TUNE_INT("YAT_GEMM_KSPLIT_POW2", 0) != 0;
     if (variant == 0) {
         variant = 1;
         // (N >= 256: one 256/320-wide column tile is fine when K is long enough to split -- the [out, in_m*r] weight
         //  gradients of the factored LoKr path are 2240 x 320 x 32768: 9 tiles, split 28 ways)
-        static const int min_n256 = getenv("YAT_GEMM_MIN_N256") ? atoi(getenv("YAT_GEMM_MIN_N256")) : 256;
+        static const int min_n256 = YAT_TUNE_INT("YAT_GEMM_MIN_N256", 256);
         const bool big = M >= 1024 && (N >= 512 || (N >= min_n256 && K >= 2048) || (N >= 256 && K >= 8192)) && K >= 256;
         // Skinny outputs with a long reduction -- the embedders' M = B rows (time_embed.linear dgrad: 8 x 2240 x 13440), the
         // patch-embedding / output-head weight gradients (32 channels x 2240 x 8192 tokens): on the 128 x 128 kernel they are
         // 18 workgroups walking 128..210 k-tiles each (150..250 us with the chip idle, at the head of the forward and the tail
         // of the backward); split along K on the 256-row kernel (mostly zero-filled tile, but the launch is bound by reading
         // the weight) they are ~7 tiles x 16..26 slices.  Only with a split: unsplit, the small kernel is the better one.
-        static const bool skinny_on = !(getenv("YAT_GEMM_SKINNY") && !atoi(getenv("YAT_GEMM_SKINNY")));
+        static const bool skinny_on = YAT_TUNE_INT("YAT_GEMM_SKINNY", 1) != 0;
         const bool skinny = skinny_on && !big && K >= 2048 && M >= 8 && N >= 32;
         if (big || skinny) {
             double best = est_time_128(M, N, K);
@@ -320,7 +320,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
                     // fills one round; x 2 leaves 106 CUs idle, x 4 spills into a second round)
                     if (s > 1 && p.pre_add) continue;
                     if (s > 1 && (!workspace || !wide_ok || (uint64_t)s * M * N * 4 > workspace_bytes || K / s < 512)) continue;
-                    const double t = est_time_256(M, N, K, v == 4 ? 256 : 320, s);
+                    const double t = est_time_256(M, N, K, v == 4 ? 256 : 320, s, streams);
                     if (t < best) { best = t; variant = v; ksplit = s; }
                 }
         }

@@ -697,10 +697,10 @@ int sdpa_fwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)kv_rows * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
     // XCD-contiguous order only for long uniform key loops (self-attention): with ragged kv_len the images with long
     // captions would pile up on one XCD (measured: T = 300 cross-attention 81 -> 104 us; N = T = 4096 1175 -> 1117 us)
-    static const int xcd_env = getenv("YAT_SDPA_XCD") ? atoi(getenv("YAT_SDPA_XCD")) : -1;
+    static const int xcd_env = YAT_TUNE_INT("YAT_SDPA_XCD", -1);
     p.xcd_remap = xcd_env >= 0 ? xcd_env : (T >= 1024);
     // 128-query workgroups once there are enough of them to fill the chip twice over (PixArt-Sigma: N = 4096)
-    static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
+    static const int wide_env = YAT_TUNE_INT("YAT_SDPA_WIDE", -1);
     // ... and 192-query ones (three sub-tiles per wave: K / V fragments feed three MFMAs, 236 registers) while the head dim
     // leaves room for them at two waves per SIMD (dh <= 80): 1.26 -> 1.17 ms at N = T = 4096, dh 72
     int wide = (int64_t)((N + 127) / 128) * H * B >= 1024;
@@ -727,10 +727,10 @@ int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)kv_rows * ldkv * 2; p.do_bytes = (uint64_t)B * N * lddo * 2;
     p.bias_bytes = (uint64_t)B * T * 4;
     p.stat_bytes = (uint64_t)B * H * N * 4;
-    static const int xcd_env = getenv("YAT_SDPA_XCD") ? atoi(getenv("YAT_SDPA_XCD")) : -1;
+    static const int xcd_env = YAT_TUNE_INT("YAT_SDPA_XCD", -1);
     p.xcd_remap = xcd_env >= 0 ? xcd_env : (T >= 1024);
     if (parts < 1 || parts > 3) return YAT_EINVAL;
-    static const int wide_env = getenv("YAT_SDPA_WIDE") ? atoi(getenv("YAT_SDPA_WIDE")) : -1;
+    static const int wide_env = YAT_TUNE_INT("YAT_SDPA_WIDE", -1);
     if (parts & 1) {                               // dQ, and delta = rowsum(dO * O) which the dK/dV part reads
         // (three sub-tiles per wave with the key tile walked in halves fit -- 254 registers at dh 72 -- but measured only
         //  -2.4 % at N = T = 4096 and +5 % on the T = 300 cross-attention: not instantiated)
@@ -746,7 +746,7 @@ int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     // walked in two 32-row halves): every Q / dO fragment read from LDS feeds two MFMAs -- 1.83 -> 1.42 ms at N = T = 4096,
     // dh 72.  (Same shape with all four 16-query tiles in flight: 330 registers, one wave per SIMD, 3.19 vs 2.37 ms; code 1 =
     // 8 waves x 16 keys: 1.97 vs 1.80 ms.  Both stay reachable through YAT_SDPA_WIDE_KV.)
-    static const int wide_kv_env = getenv("YAT_SDPA_WIDE_KV") ? atoi(getenv("YAT_SDPA_WIDE_KV")) : -1;
+    static const int wide_kv_env = YAT_TUNE_INT("YAT_SDPA_WIDE_KV", -1);
     int wide_kv = (dh <= 80 && (int64_t)((T + 127) / 128) * H * B >= 1024) ? 2 : 0;
     if (wide_kv_env >= 0) wide_kv = wide_kv_env;
     if (p.work) wide_kv = 0;

@@ -98,6 +98,15 @@ class HipDDP:
             self.native = NativeComm.get(process_group)
         self._works = []
         self.bytes_reduced = 0
+        # diagnostics (bench.py's `comm` object; off in the timed region).  ``dryrun``: the whole machinery -- hooks, events,
+        # streams, the optimizer's wait -- without the collective itself (step time with vs without = what the collective
+        # costs the step, overlap and interference included).  ``timing``: HIP events around every bucket's collective on
+        # the communication stream and around the compute stream's wait for it.
+        self.dryrun = os.environ.get("YAT_DDP_DRYRUN", "0") != "0"
+        self.timing = False
+        self.timed_buckets = []          # (bucket index, bytes, start event, end event) per collective
+        self.timed_waits = []            # (before, after) events of the compute stream's wait in ``wait()``
+        self.buckets_reduced = 0
         # YAT_DDP_COALESCE=k: k consecutive buckets (they complete in reverse order and are adjacent in the flat gradient
         # buffer) go out as one collective -- fewer, larger messages; 1 = one per transformer block
         self.coalesce = max(1, int(os.environ.get("YAT_DDP_COALESCE", "1")))
@@ -128,20 +137,46 @@ class HipDDP:
             (lo, hi, _), self._pending = self._pending, None
         chunk = self.model.flat_grad[lo:hi]
         self.bytes_reduced += chunk.numel() * chunk.element_size()
+        self.buckets_reduced += 1
+        rccl = self.on_gpu and (self.native is not None or dist.get_backend(self.pg) == "nccl")
+        if self.on_gpu and (self.timing or (self.dryrun and rccl)):
+            # diagnostic form, both transports: the producer's event and the communication stream's wait for it are issued
+            # here, so that the start event sits between that wait and the collective (inside the library / process group
+            # the two are one call) and the end event behind the collective's completion on the communication stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                e0 = e1 = None
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
+                if self.dryrun and rccl:
+                    pass
+                elif self.native is not None:
+                    self.native.allreduce_async(chunk, i, self.comm_stream, self.comm_stream)    # (runs ON that stream)
+                elif rccl:
+                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM, group=self.pg,
+                                    async_op=True).wait()          # the communication stream waits; the host does not
+                else:
+                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
+                    if self.average:
+                        chunk.div_(self.world)
+                if self.timing:
+                    e1.record(self.comm_stream)
+                    self.timed_buckets.append((i, chunk.numel() * chunk.element_size(), e0, e1))
+            return
         if self.native is not None:
             # event on the stream that finished the bucket -> all-reduce on the communication stream, all inside the library
             self.native.allreduce_async(chunk, i, torch.cuda.current_stream(), self.comm_stream)
             return
-        rccl = self.on_gpu and dist.get_backend(self.pg) == "nccl"
         op = dist.ReduceOp.AVG if (self.average and rccl) else dist.ReduceOp.SUM
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if rccl and os.environ.get("YAT_DDP_DRYRUN", "0") != "0":
-                    pass      # diagnostic: the whole machinery (hooks, events, streams) without the collective itself
-                elif rccl:
+                if rccl:
                     self._works.append(dist.all_reduce(chunk, op=op, group=self.pg, async_op=True))
                 else:       # one-GPU rehearsal over gloo (device tensors staged through the host): sum, then the mean
                     dist.all_reduce(chunk, op=op, group=self.pg)
@@ -153,6 +188,19 @@ class HipDDP:
 
     def wait(self):
         """Called before the optimizer: the compute stream waits for every outstanding bucket."""
+        if self.on_gpu and (self.timing or self.dryrun):
+            cur = torch.cuda.current_stream()
+            if self.timing:
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record(cur)
+            cur.wait_stream(self.comm_stream)
+            if self.native is not None and not self.dryrun:
+                self.native.wait(cur)                        # (clears the library's per-bucket pending flags)
+            if self.timing:
+                w1.record(cur)
+                self.timed_waits.append((w0, w1))
+            self._works.clear()
+            return
         if self.native is not None:
             self.native.wait(torch.cuda.current_stream())
         elif self.on_gpu:

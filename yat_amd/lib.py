@@ -46,7 +46,6 @@ class GemmProblem(C.Structure):
 SIGNATURES = {
     "yat_version": (I, []),
     "yat_gemm_epilogue_size": (U64, []),
-    "yat_gemm_set_concurrency": (I, [I]),
     "yat_gemm_bf16": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), P]),
     "yat_gemm_bf16_ex": (I, [I, I, I, I, I, P, I, P, I, P, I, C.POINTER(GemmEpilogue), I, P, U64, P]),
     "yat_gemm_grouped_bf16": (I, [I, I, I, C.POINTER(GemmProblem), P]),

@@ -117,9 +117,17 @@ def _chk_bf16(*ts):
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
+GEMM_STREAMS = 1
+
+
 def gemm_concurrency(streams: int):
-    """yat_gemm_set_concurrency: how many independent GEMM streams the caller keeps in flight (recorded in launch plans)."""
-    _l.check(_lib().yat_gemm_set_concurrency(int(streams)), "yat_gemm_set_concurrency")
+    """How many independent GEMM streams the caller keeps in flight from here on: host-side state of THIS module, handed to
+    the library per call in the policy word of yat_gemm_bf16_ex (include/yat_hip.h) -- the library itself holds no policy
+    state; a recorded launch plan carries the word of every call as recorded."""
+    global GEMM_STREAMS
+    if not 1 <= int(streams) <= 8:
+        raise ValueError("gemm_concurrency: 1..8 streams")
+    GEMM_STREAMS = int(streams)
 
 
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
@@ -145,7 +153,8 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
         e0.record()
     ws = _gemm_ws(out.device)
     rc = _lib().yat_gemm_bf16_ex(int(a_t), int(b_t), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc,
-                                 C.byref(ep) if ep is not None else None, variant, _p(ws), ws.numel(), _stream())
+                                 C.byref(ep) if ep is not None else None,
+                                 variant + (10000 * GEMM_STREAMS if GEMM_STREAMS > 1 else 0), _p(ws), ws.numel(), _stream())
     if dyn is not None and TEXT_ROWS is not None:
         _dyn_rows(2 if dyn == "M" else 4, M if dyn == "M" else K)
     if timer is not None:
