@@ -86,13 +86,18 @@ def main():
     noise_gen = torch.Generator(device=dev).manual_seed(99)
     ts_gen = torch.Generator().manual_seed(77)
 
+    t_dev = torch.empty(B, dtype=torch.float32, device=dev)        # persistent: the step's launch plan holds their addresses
+    a_dev, c_dev = (torch.empty(B, dtype=torch.bfloat16, device=dev) for _ in range(2))
+
     def step(i):
         b = batches[i % len(batches)]
         ops.pad_mask(b["src"], b["offsets"], B, T, Cc, enc, mask, bias, kvl)                        # :158-168
         noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)   # :170
         t, a, c = recipe.scheduler.sample(B, ts_gen)                                                 # :172-174
-        recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t.to(dev, non_blocking=True), a.to(dev, non_blocking=True),
-                                 c.to(dev, non_blocking=True), loss_dev, kv_work=b["work"])          # :176-184 + backward
+        t_dev.copy_(t, non_blocking=True)                 # int64 timestep -> the float the embedder takes (exact)
+        a_dev.copy_(a, non_blocking=True)
+        c_dev.copy_(c, non_blocking=True)
+        recipe.train_step_device(b["lat"], enc, (bias, kvl), noise, t_dev, a_dev, c_dev, loss_dev, kv_work=b["work"])   # :176-184 + bwd
         opt.step()
         return (b["Hl"] // cfg.patch_size) * (b["Wl"] // cfg.patch_size)
 
@@ -111,6 +116,16 @@ def main():
     elapsed = time.perf_counter() - t0
     loss_val = loss_dev.item()
     log(f"{elapsed:.3f}s for {args.steps} steps (host enqueue {1e3 * issue / args.steps:.1f} ms/step), loss={loss_val:.4f}")
+    # host cost of one step: enqueue onto an idle GPU, every bucket's launch plan already recorded
+    host_ms = []
+    for i in range(len(BUCKETS)):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step(args.warmup + args.steps + i)
+        host_ms.append(1e3 * (time.perf_counter() - th))
+    torch.cuda.synchronize()
+    log(f"host enqueue of one step onto an idle GPU: {min(host_ms):.1f} ms (per bucket: {', '.join(f'{v:.1f}' for v in host_ms)}; "
+        f"launch plans {'on' if model.use_plans else 'off'}, {getattr(model, 'plan_replays', 0)} replays)")
 
     # serialized pass for the per-launch GEMM figure
     saved = (model.side_wgrad, opt.overlap_update, model.fwd_chains)
@@ -137,6 +152,7 @@ def main():
                                f"bf16, {'LoRA rank %d on a frozen base' % args.lora if args.lora else 'full fine-tune'}, cached latents/T5 embeds, aspect buckets {BUCKETS} round-robin, T=300, "
                                "DDPM eps-prediction, AdamW+clip", "per_gpu_batch": B, "seq_len": 4096, "params": model.numel_flat},
         "loss": loss_val, "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+        "host_enqueue_ms_per_step": min(host_ms),
         "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),
         "algorithmic_tflop_per_step": flops / args.steps / 1e12,
         "roofline": {"bound": "mfma", "kernel": "gemm256_kernel / gemm_bf16_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,

@@ -78,12 +78,16 @@ def main():
     noise_gen = torch.Generator(device=dev).manual_seed(99)
     ts_gen = torch.Generator().manual_seed(77)
 
+    t_dev = torch.empty(B, dtype=torch.float32, device=dev)        # persistent: the step's launch plan holds their addresses
+    sig_dev = torch.empty(B, dtype=torch.bfloat16, device=dev)
+
     def step(i):
         b = batches[i % len(batches)]
         noise = torch.randn(b["lat"].shape, generator=noise_gen, device=dev, dtype=torch.bfloat16)   # :180
         _, t, sig = recipe.scheduler.sample(B, ts_gen)                                               # :182-184
-        recipe.train_step_device(b["lat"], b["prompt"], b["pooled"], noise, t.to(dev, non_blocking=True),
-                                 sig.to(dev, non_blocking=True), loss_dev)                           # :185-193 + backward
+        t_dev.copy_(t, non_blocking=True)
+        sig_dev.copy_(sig, non_blocking=True)
+        recipe.train_step_device(b["lat"], b["prompt"], b["pooled"], noise, t_dev, sig_dev, loss_dev)   # :185-193 + backward
         opt.step()
         return (b["Hl"] // cfg.patch_size) * (b["Wl"] // cfg.patch_size)
 
@@ -102,10 +106,20 @@ def main():
     elapsed = time.perf_counter() - t0
     loss_val = loss_dev.item()
     log(f"{elapsed:.3f}s for {args.steps} steps (host enqueue {1e3 * issue / args.steps:.1f} ms/step), loss={loss_val:.4f}")
+    # host cost of one step: enqueue onto an idle GPU, every bucket's launch plan already recorded
+    host_ms = []
+    for i in range(len(BUCKETS)):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step(args.warmup + args.steps + i)
+        host_ms.append(1e3 * (time.perf_counter() - th))
+    torch.cuda.synchronize()
+    log(f"host enqueue of one step onto an idle GPU: {min(host_ms):.1f} ms (per bucket: {', '.join(f'{v:.1f}' for v in host_ms)}; "
+        f"launch plans {'on' if model.use_plans else 'off'}, {getattr(model, 'plan_replays', 0)} replays)")
 
     # serialized pass for the per-launch GEMM figure
-    saved = (model.side_wgrad, opt.overlap_update)
-    model.side_wgrad, opt.overlap_update = False, False
+    saved = (model.side_wgrad, opt.overlap_update, model.fwd_chains)
+    model.side_wgrad, opt.overlap_update, model.fwd_chains = False, False, 1
     step(0)
     torch.cuda.synchronize()
     timer = []
@@ -114,7 +128,7 @@ def main():
         step(1 + i)
     torch.cuda.synchronize()
     ops.GEMM_TIMER = None
-    model.side_wgrad, opt.overlap_update = saved
+    model.side_wgrad, opt.overlap_update, model.fwd_chains = saved
 
     gf = sum(t[0] for t in timer)
     gms = sum(t[1].elapsed_time(t[2]) for t in timer)
@@ -129,6 +143,7 @@ def main():
                                f"embeds / pooled projections, aspect buckets {BUCKETS} round-robin, T=333, flow matching, AdamW+clip",
                    "per_gpu_batch": B, "seq_len": 4096 + T, "params": model.numel_flat},
         "loss": loss_val, "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+        "host_enqueue_ms_per_step": min(host_ms),
         "mfma_util_step": (flops / args.steps / (elapsed / args.steps)) / (PEAK_BF16_TFLOPS * 1e12),
         "algorithmic_tflop_per_step": flops / args.steps / 1e12,
         "roofline": {"bound": "mfma", "kernel": "gemm256_kernel / gemm_bf16_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,

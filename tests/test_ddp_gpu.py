@@ -35,6 +35,7 @@ ADAPTER_TARGETS = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_ou
 def _case(kind, seed=2):
     """-> (base model, trained object (model or adapter set), step(i) -> loss with gradients in trained.flat_grad)."""
     g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(1000 + seed)           # the adapters' own init draws from the global CPU RNG (peft's kaiming_uniform_)
     if kind in ("sana", "lokr", "lora"):
         from yat_amd.recipe import SanaRecipe
         model, cfg = _model()

@@ -327,3 +327,63 @@ def test_real_width_block_matches_oracle():
     tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
     print(f"[pixart] real width: grads hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
     assert tot_h <= 1.3 * tot_b + 1e-3
+
+
+def test_pixart_launch_plan_replay_is_bit_identical():
+    """PixArt-Sigma's device path (``PixArtRecipe.train_step_device`` -> ``forward_device`` / ``backward_device``) replays a
+    recorded launch plan once a (bucket shape, buffer addresses, schedule) combination has run (yat_amd/flat.py ``planned``;
+    train_pixart_sigma.py:151-185 is the step): eight optimizer steps alternating between two buckets, with new latents,
+    captions of other lengths (and hence another attention work list length) and new draws every step, must give
+    bit-identical losses and parameters with plans on and off."""
+    from yat_amd import ops
+    from yat_amd.optim import FlatAdamW
+    from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
+    from yat_amd.recipe import PixArtRecipe
+    cfg = PixArtConfig(num_attention_heads=2, attention_head_dim=24, in_channels=4, out_channels=8, num_layers=3,
+                       cross_attention_dim=48, sample_size=8, patch_size=2, caption_channels=64)
+    B, T = 4, 128
+    runs = []
+    for plans in (True, False):
+        hip = PixArtTransformer2DModelHIP(cfg, device=DEV).init_synthetic(4)
+        hip.use_plans = plans
+        opt = FlatAdamW(hip, lr=1e-3, weight_decay=0.01, overlap_update=True)
+        recipe = PixArtRecipe(hip, pad_to=T, device=DEV)
+        g = torch.Generator().manual_seed(9)
+        shapes = ((8, 16), (12, 8))
+        lat = [torch.empty(B, cfg.in_channels, h, w, dtype=BF, device=DEV) for h, w in shapes]       # persistent per bucket
+        noise = [torch.empty_like(t) for t in lat]
+        src = torch.empty(B * T, cfg.caption_channels, dtype=BF, device=DEV)
+        offs = torch.empty(B + 1, dtype=torch.int32, device=DEV)
+        work = torch.empty(B * ((T + 63) // 64), 2, dtype=torch.int32, device=DEV)
+        enc = torch.empty(B, T, cfg.caption_channels, dtype=BF, device=DEV)
+        mask = torch.empty(B, T, dtype=torch.int64, device=DEV)
+        bias, kvl = torch.empty(B, T, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV)
+        t_dev, a_dev, c_dev = torch.empty(B, device=DEV), torch.empty(B, dtype=BF, device=DEV), torch.empty(B, dtype=BF, device=DEV)
+        loss_dev = torch.zeros(1, device=DEV)
+        losses = []
+        for step in range(8):
+            k = step % 2
+            lat[k].copy_((torch.randn(lat[k].shape, generator=g) * 0.5).to(BF))
+            noise[k].copy_(torch.randn(lat[k].shape, generator=g).to(BF))
+            lens = torch.randint(1, T + 1, (B,), generator=g).tolist()
+            o = [0]
+            for L_ in lens:
+                o.append(o[-1] + L_)
+            src[:o[-1]].copy_(torch.randn(o[-1], cfg.caption_channels, generator=g).to(BF))
+            offs.copy_(torch.tensor(o, dtype=torch.int32))
+            wl = ops.kv_work_list(lens, T, "cpu")
+            work[:wl.shape[0]].copy_(wl)
+            ops.pad_mask(src, offs, B, T, cfg.caption_channels, enc, mask, bias, kvl)
+            t, a, c = recipe.scheduler.sample(B, torch.Generator().manual_seed(100 + step))
+            t_dev.copy_(t); a_dev.copy_(a); c_dev.copy_(c)
+            recipe.train_step_device(lat[k], enc, (bias, kvl), noise[k], t_dev, a_dev, c_dev, loss_dev, kv_work=work[:wl.shape[0]])
+            losses.append(loss_dev.clone())
+            opt.step()
+        hip.join_pending_update()
+        torch.cuda.synchronize()
+        runs.append((torch.cat(losses).cpu(), hip.flat_param.clone(), getattr(hip, "plan_replays", 0), len(hip._plans)))
+    (l_a, p_a, replays, nplans), (l_b, p_b, r_b, n_b) = runs
+    print(f"[plans] pixart: {nplans} plans recorded, {replays} replays; losses {l_a.tolist()}")
+    assert r_b == 0 and n_b == 0
+    assert replays >= 2 * 4 and nplans <= 8
+    assert torch.isfinite(l_a).all() and torch.equal(l_a, l_b) and torch.equal(p_a, p_b)

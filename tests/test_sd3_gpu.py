@@ -400,3 +400,52 @@ def test_sd3_adapter_step_matches_oracle(algo):
     print(f"[parity] sd3 {algo} adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
     assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.3 * e_r + 2e-3
     assert torch.equal(base, hip.flat_param)
+
+
+def test_sd3_launch_plan_replay_and_chains_are_bit_identical():
+    """The MMDiT's device path (``SD3Recipe.train_step_device`` -> ``forward_device`` / ``backward_device``; the step is
+    train_sd35.py:165-194): (a) eight optimizer steps alternating between two buckets with new inputs and draws every step
+    give bit-identical losses and parameters with launch plans on and off; (b) the forward as two image-range chains on two
+    streams equals the single-chain forward bit for bit (nothing in the MMDiT mixes images: the joint attention is per image)."""
+    from yat_amd.optim import FlatAdamW
+    from yat_amd.recipe import SD3Recipe
+    from yat_amd.sd3 import SD3Config, SD3Transformer2DModelHIP
+    cfg = SD3Config(sample_size=16, patch_size=2, in_channels=8, out_channels=8, num_layers=3, attention_head_dim=64,
+                    num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128, pooled_projection_dim=64,
+                    pos_embed_max_size=24, dual_attention_layers=(0, 1))
+    B, T = 4, 10
+    runs = []
+    for plans, chains in ((True, 2), (False, 2), (True, 1)):
+        hip = SD3Transformer2DModelHIP(cfg, device=DEV).init_synthetic(4)
+        hip.use_plans, hip.fwd_chains = plans, chains
+        opt = FlatAdamW(hip, lr=1e-3, weight_decay=0.01, overlap_update=True)
+        recipe = SD3Recipe(hip, device=DEV)
+        g = torch.Generator().manual_seed(9)
+        shapes = ((8, 16), (12, 8))
+        lat = [torch.empty(B, cfg.in_channels, h, w, dtype=BF, device=DEV) for h, w in shapes]       # persistent per bucket
+        noise = [torch.empty_like(t) for t in lat]
+        prompt = torch.empty(B, T, cfg.joint_attention_dim, dtype=BF, device=DEV)
+        pooled = torch.empty(B, cfg.pooled_projection_dim, dtype=BF, device=DEV)
+        t_dev, s_dev = torch.empty(B, device=DEV), torch.empty(B, dtype=BF, device=DEV)
+        loss_dev = torch.zeros(1, device=DEV)
+        losses = []
+        for step in range(8):
+            k = step % 2
+            lat[k].copy_((torch.randn(lat[k].shape, generator=g) * 0.5).to(BF))
+            noise[k].copy_(torch.randn(lat[k].shape, generator=g).to(BF))
+            prompt.copy_(torch.randn(prompt.shape, generator=g).to(BF))
+            pooled.copy_(torch.randn(pooled.shape, generator=g).to(BF))
+            _, t, sig = recipe.scheduler.sample(B, torch.Generator().manual_seed(100 + step))
+            t_dev.copy_(t); s_dev.copy_(sig)
+            recipe.train_step_device(lat[k], prompt, pooled, noise[k], t_dev, s_dev, loss_dev)
+            losses.append(loss_dev.clone())
+            opt.step()
+        hip.join_pending_update()
+        torch.cuda.synchronize()
+        runs.append((torch.cat(losses).cpu(), hip.flat_param.clone(), getattr(hip, "plan_replays", 0), len(hip._plans)))
+    (l_a, p_a, replays, nplans), (l_b, p_b, r_b, n_b), (l_c, p_c, _, _) = runs
+    print(f"[plans] sd3: {nplans} plans recorded, {replays} replays; losses {l_a.tolist()}")
+    assert r_b == 0 and n_b == 0
+    assert replays >= 2 * 4 and nplans <= 8
+    assert torch.isfinite(l_a).all() and torch.equal(l_a, l_b) and torch.equal(p_a, p_b), "launch plans on vs off differ"
+    assert torch.equal(l_a, l_c) and torch.equal(p_a, p_c), "two forward chains vs one differ"

@@ -177,6 +177,17 @@ class FlatParamModule(nn.Module):
         self._plans[key] = LaunchPlan(rec.entries, rec.dynamic, result=result, saved=self._saved)
         return result
 
+    def _require_device(self, **tensors):
+        """Inputs of a planned forward must be what the kernels read, in place: a silent ``.to()`` / ``.contiguous()`` copy
+        would be made once, at recording time, and every replay would read that stale copy.  name=(tensor, dtype)."""
+        for name, (t, dtype) in tensors.items():
+            if t is None:
+                continue
+            on_dev = t.device.type == self.dev.type and (self.dev.index is None or t.device.index == self.dev.index)
+            if not on_dev or t.dtype != dtype or not t.is_contiguous():
+                raise ValueError(f"forward_device: `{name}` must be a contiguous {dtype} tensor on {self.dev} "
+                                 f"(got {t.dtype} on {t.device}, contiguous={t.is_contiguous()})")
+
     # stream / event operations of the model code go through these, so that a recorder sees them
     def _ev_record(self, stream):
         ev = torch.cuda.Event()

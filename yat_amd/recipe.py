@@ -304,10 +304,10 @@ class PixArtRecipe(SanaRecipe):
         """Straight-line step on device-resident inputs (bench.py): mix, forward, loss + dL/dpred, backward."""
         bias, kvl = mask_bias_kvl
         noisy = ops.ddpm_add_noise(latents, noise, coef_a, coef_c, self._noisy(latents))
-        out = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work)
+        out = self.model.forward_device(noisy, enc, timesteps, bias, kvl, kv_work=kv_work)      # (launch plans: yat_amd/flat.py)
         dpred = self._dpred(out)
         ops.mse_bf16_chunk(out, noise, loss_out, dpred, self._mse_ws)
-        self.model.backward_impl(dpred)
+        self.model.backward_device(dpred)
         return loss_out
 
 
@@ -375,10 +375,10 @@ class SD3Recipe:
     def train_step_device(self, latents, prompt, pooled, noise, timesteps, sigmas, loss_out):
         """Straight-line step on device-resident inputs (scripts/bench_sd35.py): mix, forward, loss + dL/dpred, backward."""
         noisy, target = ops.flow_mix(latents, noise, sigmas, self._scratch("_noisy_buf", latents), self._scratch("_target_buf", latents))
-        pred = self.model.forward_impl(noisy, prompt, pooled, timesteps)
+        pred = self.model.forward_device(noisy, prompt, pooled, timesteps)                        # (launch plans: yat_amd/flat.py)
         dpred = self._scratch("_dpred_buf", pred)
         ops.mse_bf16_chunk(pred, target, loss_out, dpred, self._mse_ws)
-        self.model.backward_impl(dpred)
+        self.model.backward_device(dpred)
         return loss_out
 
     _scratch = SanaRecipe._scratch

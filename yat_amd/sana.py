@@ -191,6 +191,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         ``kv_off`` (device int32 row offsets, one per image): ``enc`` is the packed [rows, C] text matrix -- the prompts'
         rows back to back, then fewer than 256 zero rows (see ``forward_impl``); the plan key then carries the row count."""
         pev = self.param_events
+        self._require_device(latents=(latents, BF16), enc=(enc, BF16), timestep=(timestep, torch.float32),
+                             key_bias=(key_bias, torch.float32), kv_len=(kv_len, torch.int32), kv_off=(kv_off, torch.int32))
         # (packed text: the row count is a dynamic integer of the plan -- ops.text_rows -- not part of its key)
         enc_shape = tuple(enc.shape) if kv_off is None else ("packed",) + tuple(enc.shape[1:])
         if kv_off is not None:

@@ -136,7 +136,7 @@ class _WholeModel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, latents, enc, pooled, timestep):
         ctx.model = model
-        return model.forward_impl(latents, enc, pooled, timestep)
+        return model.forward_impl(latents, enc, pooled, timestep).clone()          # (the prediction lives in the arena)
 
     @staticmethod
     def backward(ctx, dout):
@@ -156,11 +156,9 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         offs, total = self._alloc_flat(specs, device)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers, first_key="norm1.linear.weight")
         self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"     # weight gradients / modulation linears on a 2nd stream
-        # the text stream's own chain (LayerNorm, projections, FFN on B*333 rows: GEMMs of 84..252 tiles that leave most CUs
-        # idle) on a third stream, meeting the image chain only at the joint attention.  Measured on one box: 405.0 ms per
-        # step with it, 399.7 without -- the step is throughput-bound, the extra events cost more than the fill-in gains.
-        # Off by default; bit-identical either way (tests/test_sd3_gpu.py runs the default).
-        self.text_stream = os.environ.get("YAT_SD3_TEXT_STREAM", "0") != "0"
+        # (a third stream for the text tokens' own chain was measured in round 2 -- 405.0 vs 399.7 ms per step, no gain -- and
+        # is gone; what pays is the forward as independent chains over image ranges, as in yat_amd/sana.py)
+        self.fwd_chains = int(os.environ.get("YAT_SD3_CHAINS", "2"))
         self._pos = {}
 
     def init_synthetic(self, seed: int = 0):
@@ -197,7 +195,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         if torch.is_grad_enabled():
             out = _WholeModel.apply(self._anchor, self, hidden_states, encoder_hidden_states, pooled_projections, timestep)
         else:
-            out = self.forward_impl(hidden_states, encoder_hidden_states, pooled_projections, timestep)
+            out = self.forward_impl(hidden_states, encoder_hidden_states, pooled_projections, timestep).clone()
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
     def _block_meta(self, i):
@@ -205,10 +203,29 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         last, dual = i == cfg.num_layers - 1, i in cfg.dual_attention_layers
         return last, dual, (9 if dual else 6), (2 if last else 6)
 
+    # ------------------------------------------------------------------ device path (launch plans, yat_amd/flat.py)
+    def _schedule_flags(self):
+        return (self.side_wgrad, self.fwd_chains, self.training)
+
+    def forward_device(self, latents, enc, pooled, timestep):
+        """``forward_impl`` on device-resident inputs in persistent buffers, replayed from a launch plan when this (shapes,
+        addresses, schedule) combination has run before (yat_amd/sana.py does the same).  The prediction is an arena buffer:
+        consume it before the next call."""
+        pev = self.param_events
+        self._require_device(latents=(latents, BF16), enc=(enc, BF16), pooled=(pooled, BF16), timestep=(timestep, torch.float32))
+        key = (latents.data_ptr(), tuple(latents.shape), enc.data_ptr(), tuple(enc.shape), pooled.data_ptr(), timestep.data_ptr(),
+               None if pev is None else id(pev[0]), self._schedule_flags())
+        out = self.planned("fwd", key, lambda: self.forward_impl(latents, enc, pooled, timestep))
+        self.param_events = None          # consumed by the forward (recorded or replayed)
+        return out
+
+    def backward_device(self, dpred):
+        key = (id(self._saved), dpred.data_ptr(), self.accumulate_grads, id(self.grad_ready), self._schedule_flags())
+        self.planned("bwd", key, lambda: self.backward_impl(dpred))
+
     # ------------------------------------------------------------------ forward
     def forward_impl(self, latents, enc, pooled, timestep):
         cfg, P = self.cfg, self.P
-        ops.gemm_concurrency(1)                   # one forward chain (the side stream only carries the small modulation linears)
         ad = self.adapters
         if ad is not None:
             ad.materialize(self.training)                     # yat_amd/lora.py / lokr.py / loha.py: this step's adapter state
@@ -231,6 +248,9 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None
+        # (with adapters: one chain, so that an adapter's products cover the whole batch and the backward can reuse them)
+        nchain = 1 if ad is not None else max(1, min(self.fwd_chains, B))
+        ops.gemm_concurrency(nchain)              # the GEMM policy plans each launch for its share of the chip
 
         def lin(x_, w_, bias_=None, out=None, **ep):
             """Linear of a (possibly adapted) target: the adapter term is folded in through the GEMM's pre_add epilogue."""
@@ -241,13 +261,13 @@ class SD3Transformer2DModelHIP(FlatParamModule):
 
         def params_ready(bucket, stream=main):
             if pev is not None:
-                stream.wait_event(pev[bucket])
+                self._ev_wait(stream, pev[bucket])
 
         params_ready(0)
         # 1. PatchEmbed: p x p patches as rows -> GEMM -> + centre crop of the position table
         S.x_tok = ops.patch_rearrange(latents, buf("x_tok", (M, Kp)), B, Cin, Hl, Wl, p, True, True)
-        x = lin(S.x_tok, P["pos_embed.proj.weight"].view(D, Kp), P["pos_embed.proj.bias"], out=buf("x0", (M, D)))
-        ops.add_pos_embed(x, self.pos_table(h, w))
+        x0 = lin(S.x_tok, P["pos_embed.proj.weight"].view(D, Kp), P["pos_embed.proj.bias"], out=buf("x0", (M, D)))
+        ops.add_pos_embed(x0, self.pos_table(h, w))
         # 2. conditioning: temb = TimestepEmbedding(sinusoid(t)) + TextProjection(pooled); every AdaLN takes silu(temb)
         pre = "time_text_embed."
         S.tproj = ops.timestep_embed(t_f32, 256, buf("tproj", (B, 256)))
@@ -264,7 +284,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         S.temb = ops.add_bf16(t_emb, p_emb, buf("temb", (B, D)))
         S.se = ops.act_fwd(S.temb, "silu", buf("te_se", (B, D)))
         # 3. text tokens -> model width
-        c = lin(enc2d, P["context_embedder.weight"], P["context_embedder.bias"], out=buf("c0", (Mt, D)))
+        c0 = lin(enc2d, P["context_embedder.weight"], P["context_embedder.bias"], out=buf("c0", (Mt, D)))
 
         # 4. every AdaLN modulation (a Linear of silu(temb) each): independent of the token streams -> second stream, up front
         S.mod_ready = []
@@ -280,142 +300,153 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                          out=buf(f"b{i}.embc", (B, nc * D)))
                 S.blocks.append(SimpleNamespace(emb1=e1, embc=ec))
                 if side is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(cur)
-                    S.mod_ready.append(ev)
+                    S.mod_ready.append(self._ev_record(cur))
             S.embf = lin(S.se, P["norm_out.linear.weight"], P["norm_out.linear.bias"], out=buf("embf", (B, 2 * D)))
             if side is not None:
-                S.embf_ready = torch.cuda.Event()
-                S.embf_ready.record(cur)
+                S.embf_ready = self._ev_record(cur)
 
         if side is not None:
-            side.wait_stream(main)
+            self._wait_stream(side, main)
             with torch.cuda.stream(side):
                 modulations()
         else:
             modulations()
 
-        text = self._chain_stream(1) if (self.text_stream and side is not None) else None
-        if text is not None:
-            text.wait_stream(main)                          # c0 (and, transitively, the parameters' readiness)
-
-        def on_text(fn):
-            """The text chain: its own stream when enabled (ordered among itself; explicit events towards the image chain)."""
-            if text is None:
-                return fn()
-            with torch.cuda.stream(text):
-                return fn()
-
-        def event(stream):
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            return ev
-
         scale = 1.0 / math.sqrt(dh)
-        S.zero_bias = buf("sa_zero_bias", (B, L), f32).zero_()
-        S.len_joint = torch.full((B,), L, dtype=torch.int32, device=dev)
-        S.len_img = torch.full((B,), N, dtype=torch.int32, device=dev)
+        S.zero_bias = self._const("sa_zero_bias", (B, L), f32, 0.0)        # device constants: no per-step fill launches
+        S.len_joint = self._const("sa_len_joint", (B,), torch.int32, L)
+        S.len_img = self._const("sa_len_img", (B,), torch.int32, N)
         eps = 1e-6
+        # Activations live in whole-batch buffers (the backward runs on the whole batch); the forward walks them as
+        # ``fwd_chains`` independent chains over disjoint image ranges, each on its own stream: nothing in the MMDiT mixes
+        # images (the joint attention is per image), so while one chain sits in a memory-bound kernel the other one's GEMM
+        # has the matrix cores, and a chain's single-round GEMMs no longer leave the other CUs idle (yat_amd/sana.py).
         for i in range(cfg.num_layers):
-            b_ = f"transformer_blocks.{i}."
             last, dual, n1, nc = self._block_meta(i)
             A = S.blocks[i]
             A.last, A.dual, A.n1, A.nc = last, dual, n1, nc
-            A.x_in, A.c_in = x, c
-            if side is not None:
-                main.wait_event(S.mod_ready[i])
-                if text is not None:
-                    text.wait_event(S.mod_ready[i])
-            e1, ec = A.emb1, A.embc
-            ld1, ldc = n1 * D, nc * D
+            A.x_in = x0 if i == 0 else S.blocks[i - 1].x3
+            A.c_in = c0 if i == 0 else S.blocks[i - 1].c3
 
-            def ln(xx, shift, scale_, ld, rpb, tag, rows):
-                return ops.ln_modulate_fwd(xx, shift, scale_, ld, rpb, eps, buf(f"b{i}.{tag}", (rows, D)),
-                                           buf(f"b{i}.{tag}.mean", (rows,), f32), buf(f"b{i}.{tag}.rstd", (rows,), f32))
-            # AdaLayerNormZero on both streams (the last block's text side: AdaLayerNormContinuous, scale first)
-            A.h1, A.mean1, A.rstd1 = ln(x, e1[:, 0:D], e1[:, D:2 * D], ld1, N, "h1", M)
-            # joint attention: fused q|k|v projections of both streams -> per-head RMSNorm on q, k + row concatenation
-            wqkv, _ = self._fused(b_ + "attn.to_q.weight", 3 * D, D)
-            bqkv, _ = self._fused(b_ + "attn.to_q.bias", 3 * D)
-            waqkv, _ = self._fused(b_ + "attn.add_q_proj.weight", 3 * D, D)
-            baqkv, _ = self._fused(b_ + "attn.add_q_proj.bias", 3 * D)
-
-            def text_pre(c=c):
-                if last:
-                    A.hc, A.cmean1, A.crstd1 = ln(c, ec[:, D:2 * D], ec[:, 0:D], ldc, T, "hc", Mt)
-                else:
-                    A.hc, A.cmean1, A.crstd1 = ln(c, ec[:, 0:D], ec[:, D:2 * D], ldc, T, "hc", Mt)
-                A.qkv_c = lin(A.hc, waqkv, baqkv, out=buf(f"b{i}.qkv_c", (Mt, 3 * D)))
-            on_text(text_pre)
-            A.qkv = lin(A.h1, wqkv, bqkv, out=buf(f"b{i}.qkv", (M, 3 * D)))
-            if text is not None:
-                main.wait_event(event(text))                # the text side's q | k | v
-            A.joint = buf(f"b{i}.joint", (B * L, 3 * D))
-            A.jrstd = buf(f"b{i}.jrstd", (B * L, 2 * H), f32)
-            ops.qknorm_concat_fwd(A.qkv, A.qkv_c, B, N, T, H, dh, eps, P[b_ + "attn.norm_q.weight"], P[b_ + "attn.norm_k.weight"],
-                                  P[b_ + "attn.norm_added_q.weight"], P[b_ + "attn.norm_added_k.weight"], A.joint, A.jrstd)
-            A.o, A.lse = buf(f"b{i}.o", (B * L, D)), buf(f"b{i}.lse", (B, H, L), f32)
-            ops.sdpa_fwd(A.joint[:, :D], A.joint[:, D:2 * D], A.joint[:, 2 * D:], B, L, L, H, dh, scale, S.zero_bias,
-                         S.len_joint, A.o, A.lse)
-            A.o_i = buf(f"b{i}.o_i", (M, D))
-            A.o_c = None if last else buf(f"b{i}.o_c", (Mt, D))
-            ops.joint_rows(A.o, A.o_i, A.o_c, B, N, T, to_joint=False)
-            if text is not None and not last:
-                text.wait_event(event(main))                # the attention output's text rows
-            # hidden = hidden + gate_msa * to_out(attn)
-            A.lin1 = buf(f"b{i}.lin1", (M, D))
-            xa = lin(A.o_i, P[b_ + "attn.to_out.0.weight"], P[b_ + "attn.to_out.0.bias"], out=buf(f"b{i}.x1", (M, D)),
-                     aux_out=A.lin1, gate=e1[:, 2 * D:3 * D], ld_gate=ld1, residual=x, rows_per_batch=N)
+            def nb(tag, shape, dtype=BF16, i=i):
+                return buf(f"b{i}.{tag}", shape, dtype)
+            A.h1, A.mean1, A.rstd1 = nb("h1", (M, D)), nb("h1.mean", (M,), f32), nb("h1.rstd", (M,), f32)
+            A.hc, A.cmean1, A.crstd1 = nb("hc", (Mt, D)), nb("hc.mean", (Mt,), f32), nb("hc.rstd", (Mt,), f32)
+            A.qkv_c, A.qkv = nb("qkv_c", (Mt, 3 * D)), nb("qkv", (M, 3 * D))
+            A.joint, A.jrstd = nb("joint", (B * L, 3 * D)), nb("jrstd", (B * L, 2 * H), f32)
+            A.o, A.lse = nb("o", (B * L, D)), nb("lse", (B, H, L), f32)
+            A.o_i, A.o_c = nb("o_i", (M, D)), (None if last else nb("o_c", (Mt, D)))
+            A.lin1, A.x1 = nb("lin1", (M, D)), nb("x1", (M, D))
             if dual:
-                # second, image-only attention from the same LayerNorm with its own (shift, scale, gate)
-                A.h1b, _, _ = ops.ln_modulate_fwd(x, e1[:, 6 * D:7 * D], e1[:, 7 * D:8 * D], ld1, N, eps, buf(f"b{i}.h1b", (M, D)),
-                                                  buf("ln_scratch_mean", (M,), f32), buf("ln_scratch_rstd", (M,), f32))
-                w2, _ = self._fused(b_ + "attn2.to_q.weight", 3 * D, D)
-                b2, _ = self._fused(b_ + "attn2.to_q.bias", 3 * D)
-                A.qkv2 = lin(A.h1b, w2, b2, out=buf(f"b{i}.qkv2", (M, 3 * D)))
-                A.j2, A.j2rstd = buf(f"b{i}.j2", (M, 3 * D)), buf(f"b{i}.j2rstd", (M, 2 * H), f32)
-                ops.qknorm_concat_fwd(A.qkv2, None, B, N, 0, H, dh, eps, P[b_ + "attn2.norm_q.weight"],
-                                      P[b_ + "attn2.norm_k.weight"], None, None, A.j2, A.j2rstd)
-                A.o2, A.lse2 = buf(f"b{i}.o2", (M, D)), buf(f"b{i}.lse2", (B, H, N), f32)
-                ops.sdpa_fwd(A.j2[:, :D], A.j2[:, D:2 * D], A.j2[:, 2 * D:], B, N, N, H, dh, scale, S.zero_bias, S.len_img,
-                             A.o2, A.lse2)
-                A.lin1b = buf(f"b{i}.lin1b", (M, D))
-                xa = lin(A.o2, P[b_ + "attn2.to_out.0.weight"], P[b_ + "attn2.to_out.0.bias"], out=buf(f"b{i}.x1b", (M, D)),
-                         aux_out=A.lin1b, gate=e1[:, 8 * D:9 * D], ld_gate=ld1, residual=xa, rows_per_batch=N)
-            A.xa = xa
-            # image feed-forward
-            A.h2, A.mean2, A.rstd2 = ln(xa, e1[:, 3 * D:4 * D], e1[:, 4 * D:5 * D], ld1, N, "h2", M)
-            A.z = buf(f"b{i}.z", (M, 4 * D))
-            A.f1 = lin(A.h2, P[b_ + "ff.net.0.proj.weight"], P[b_ + "ff.net.0.proj.bias"], out=buf(f"b{i}.f1", (M, 4 * D)),
-                       activation="gelu_tanh", aux_out=A.z)
-            A.lin3 = buf(f"b{i}.lin3", (M, D))
-            x = lin(A.f1, P[b_ + "ff.net.2.weight"], P[b_ + "ff.net.2.bias"], out=buf(f"b{i}.x3", (M, D)), aux_out=A.lin3,
-                    gate=e1[:, 5 * D:6 * D], ld_gate=ld1, residual=xa, rows_per_batch=N)
-            # text stream (ends inside the attention of the last block)
+                A.h1b, A.qkv2 = nb("h1b", (M, D)), nb("qkv2", (M, 3 * D))
+                A.j2, A.j2rstd = nb("j2", (M, 3 * D)), nb("j2rstd", (M, 2 * H), f32)
+                A.o2, A.lse2 = nb("o2", (M, D)), nb("lse2", (B, H, N), f32)
+                A.lin1b, A.x1b = nb("lin1b", (M, D)), nb("x1b", (M, D))
+            A.xa = A.x1b if dual else A.x1
+            A.h2, A.mean2, A.rstd2 = nb("h2", (M, D)), nb("h2.mean", (M,), f32), nb("h2.rstd", (M,), f32)
+            A.z, A.f1 = nb("z", (M, 4 * D)), nb("f1", (M, 4 * D))
+            A.lin3, A.x3 = nb("lin3", (M, D)), nb("x3", (M, D))
+            A.c3 = None
             if not last:
-                def text_post(c=c):
-                    A.clin1 = buf(f"b{i}.clin1", (Mt, D))
-                    A.c1 = lin(A.o_c, P[b_ + "attn.to_add_out.weight"], P[b_ + "attn.to_add_out.bias"],
-                               out=buf(f"b{i}.c1", (Mt, D)), aux_out=A.clin1, gate=ec[:, 2 * D:3 * D], ld_gate=ldc, residual=c,
-                               rows_per_batch=T)
-                    A.hc2, A.cmean2, A.crstd2 = ln(A.c1, ec[:, 3 * D:4 * D], ec[:, 4 * D:5 * D], ldc, T, "hc2", Mt)
-                    A.zc = buf(f"b{i}.zc", (Mt, 4 * D))
-                    A.fc = lin(A.hc2, P[b_ + "ff_context.net.0.proj.weight"], P[b_ + "ff_context.net.0.proj.bias"],
-                               out=buf(f"b{i}.fc", (Mt, 4 * D)), activation="gelu_tanh", aux_out=A.zc)
-                    A.clin3 = buf(f"b{i}.clin3", (Mt, D))
-                    return lin(A.fc, P[b_ + "ff_context.net.2.weight"], P[b_ + "ff_context.net.2.bias"],
-                               out=buf(f"b{i}.c3", (Mt, D)), aux_out=A.clin3, gate=ec[:, 5 * D:6 * D], ld_gate=ldc,
-                               residual=A.c1, rows_per_batch=T)
-                c = on_text(text_post)
-        # 5. output head: AdaLayerNormContinuous (scale first) + proj_out + unpatchify
-        S.x_last = x
-        if side is not None:
-            main.wait_event(S.embf_ready)
-        S.hf, S.meanf, S.rstdf = ops.ln_modulate_fwd(x, S.embf[:, D:2 * D], S.embf[:, 0:D], 2 * D, N, eps, buf("hf", (M, D)),
-                                                     buf("meanf", (M,), f32), buf("rstdf", (M,), f32))
-        out_tok = lin(S.hf, P["proj_out.weight"], P["proj_out.bias"], out=buf("out_tok", (M, Co)))
-        pred = torch.empty(B, cfg.out_channels, Hl, Wl, dtype=BF16, device=dev)
-        ops.patch_rearrange(out_tok, pred, B, cfg.out_channels, Hl, Wl, p, False, False)
+                A.clin1, A.c1 = nb("clin1", (Mt, D)), nb("c1", (Mt, D))
+                A.hc2, A.cmean2, A.crstd2 = nb("hc2", (Mt, D)), nb("hc2.mean", (Mt,), f32), nb("hc2.rstd", (Mt,), f32)
+                A.zc, A.fc = nb("zc", (Mt, 4 * D)), nb("fc", (Mt, 4 * D))
+                A.clin3, A.c3 = nb("clin3", (Mt, D)), nb("c3", (Mt, D))
+        S.x_last = S.blocks[-1].x3
+        S.hf, S.meanf, S.rstdf = buf("hf", (M, D)), buf("meanf", (M,), f32), buf("rstdf", (M,), f32)
+        out_tok = buf("out_tok", (M, Co))
+        pred = buf("pred", (B, cfg.out_channels, Hl, Wl))     # (arena: the caller consumes it before the next forward)
+        ln_sm, ln_sr = buf("ln_scratch_mean", (M,), f32), buf("ln_scratch_rstd", (M,), f32)
+
+        def run_chain(b0, b1, stream):
+            nbt = b1 - b0
+            rs, ts, js, bs = slice(b0 * N, b1 * N), slice(b0 * T, b1 * T), slice(b0 * L, b1 * L), slice(b0, b1)
+            for i in range(cfg.num_layers):
+                b_ = f"transformer_blocks.{i}."
+                A = S.blocks[i]
+                last, dual, n1, nc = A.last, A.dual, A.n1, A.nc
+                params_ready(i + 1, stream)
+                if side is not None:
+                    self._ev_wait(stream, S.mod_ready[i])
+                e1, ec = A.emb1[bs], A.embc[bs]
+                ld1, ldc = n1 * D, nc * D
+                x, c = A.x_in[rs], A.c_in[ts]
+                # AdaLayerNormZero on both streams (the last block's text side: AdaLayerNormContinuous, scale first)
+                ops.ln_modulate_fwd(x, e1[:, 0:D], e1[:, D:2 * D], ld1, N, eps, A.h1[rs], A.mean1[rs], A.rstd1[rs])
+                # joint attention: fused q|k|v projections of both streams -> per-head RMSNorm on q, k + row concatenation
+                wqkv, _ = self._fused(b_ + "attn.to_q.weight", 3 * D, D)
+                bqkv, _ = self._fused(b_ + "attn.to_q.bias", 3 * D)
+                waqkv, _ = self._fused(b_ + "attn.add_q_proj.weight", 3 * D, D)
+                baqkv, _ = self._fused(b_ + "attn.add_q_proj.bias", 3 * D)
+                if last:
+                    ops.ln_modulate_fwd(c, ec[:, D:2 * D], ec[:, 0:D], ldc, T, eps, A.hc[ts], A.cmean1[ts], A.crstd1[ts])
+                else:
+                    ops.ln_modulate_fwd(c, ec[:, 0:D], ec[:, D:2 * D], ldc, T, eps, A.hc[ts], A.cmean1[ts], A.crstd1[ts])
+                lin(A.hc[ts], waqkv, baqkv, out=A.qkv_c[ts])
+                lin(A.h1[rs], wqkv, bqkv, out=A.qkv[rs])
+                ops.qknorm_concat_fwd(A.qkv[rs], A.qkv_c[ts], nbt, N, T, H, dh, eps, P[b_ + "attn.norm_q.weight"],
+                                      P[b_ + "attn.norm_k.weight"], P[b_ + "attn.norm_added_q.weight"],
+                                      P[b_ + "attn.norm_added_k.weight"], A.joint[js], A.jrstd[js])
+                jt = A.joint[js]
+                ops.sdpa_fwd(jt[:, :D], jt[:, D:2 * D], jt[:, 2 * D:], nbt, L, L, H, dh, scale, S.zero_bias[bs], S.len_joint[bs],
+                             A.o[js], A.lse[bs])
+                ops.joint_rows(A.o[js], A.o_i[rs], None if last else A.o_c[ts], nbt, N, T, to_joint=False)
+                # hidden = hidden + gate_msa * to_out(attn)
+                lin(A.o_i[rs], P[b_ + "attn.to_out.0.weight"], P[b_ + "attn.to_out.0.bias"], out=A.x1[rs],
+                    aux_out=A.lin1[rs], gate=e1[:, 2 * D:3 * D], ld_gate=ld1, residual=x, rows_per_batch=N)
+                if dual:
+                    # second, image-only attention from the same LayerNorm with its own (shift, scale, gate)
+                    ops.ln_modulate_fwd(x, e1[:, 6 * D:7 * D], e1[:, 7 * D:8 * D], ld1, N, eps, A.h1b[rs], ln_sm[rs], ln_sr[rs])
+                    w2, _ = self._fused(b_ + "attn2.to_q.weight", 3 * D, D)
+                    b2, _ = self._fused(b_ + "attn2.to_q.bias", 3 * D)
+                    lin(A.h1b[rs], w2, b2, out=A.qkv2[rs])
+                    ops.qknorm_concat_fwd(A.qkv2[rs], None, nbt, N, 0, H, dh, eps, P[b_ + "attn2.norm_q.weight"],
+                                          P[b_ + "attn2.norm_k.weight"], None, None, A.j2[rs], A.j2rstd[rs])
+                    j2 = A.j2[rs]
+                    ops.sdpa_fwd(j2[:, :D], j2[:, D:2 * D], j2[:, 2 * D:], nbt, N, N, H, dh, scale, S.zero_bias[bs], S.len_img[bs],
+                                 A.o2[rs], A.lse2[bs])
+                    lin(A.o2[rs], P[b_ + "attn2.to_out.0.weight"], P[b_ + "attn2.to_out.0.bias"], out=A.x1b[rs],
+                        aux_out=A.lin1b[rs], gate=e1[:, 8 * D:9 * D], ld_gate=ld1, residual=A.x1[rs], rows_per_batch=N)
+                xa = A.xa[rs]
+                # image feed-forward
+                ops.ln_modulate_fwd(xa, e1[:, 3 * D:4 * D], e1[:, 4 * D:5 * D], ld1, N, eps, A.h2[rs], A.mean2[rs], A.rstd2[rs])
+                lin(A.h2[rs], P[b_ + "ff.net.0.proj.weight"], P[b_ + "ff.net.0.proj.bias"], out=A.f1[rs],
+                    activation="gelu_tanh", aux_out=A.z[rs])
+                lin(A.f1[rs], P[b_ + "ff.net.2.weight"], P[b_ + "ff.net.2.bias"], out=A.x3[rs], aux_out=A.lin3[rs],
+                    gate=e1[:, 5 * D:6 * D], ld_gate=ld1, residual=xa, rows_per_batch=N)
+                # text stream (ends inside the attention of the last block)
+                if not last:
+                    lin(A.o_c[ts], P[b_ + "attn.to_add_out.weight"], P[b_ + "attn.to_add_out.bias"], out=A.c1[ts],
+                        aux_out=A.clin1[ts], gate=ec[:, 2 * D:3 * D], ld_gate=ldc, residual=c, rows_per_batch=T)
+                    ops.ln_modulate_fwd(A.c1[ts], ec[:, 3 * D:4 * D], ec[:, 4 * D:5 * D], ldc, T, eps, A.hc2[ts], A.cmean2[ts],
+                                        A.crstd2[ts])
+                    lin(A.hc2[ts], P[b_ + "ff_context.net.0.proj.weight"], P[b_ + "ff_context.net.0.proj.bias"], out=A.fc[ts],
+                        activation="gelu_tanh", aux_out=A.zc[ts])
+                    lin(A.fc[ts], P[b_ + "ff_context.net.2.weight"], P[b_ + "ff_context.net.2.bias"], out=A.c3[ts],
+                        aux_out=A.clin3[ts], gate=ec[:, 5 * D:6 * D], ld_gate=ldc, residual=A.c1[ts], rows_per_batch=T)
+            # 5. output head: AdaLayerNormContinuous (scale first) + proj_out + unpatchify
+            if side is not None:
+                self._ev_wait(stream, S.embf_ready)
+            embf = S.embf[bs]
+            ops.ln_modulate_fwd(S.x_last[rs], embf[:, D:2 * D], embf[:, 0:D], 2 * D, N, eps, S.hf[rs], S.meanf[rs], S.rstdf[rs])
+            lin(S.hf[rs], P["proj_out.weight"], P["proj_out.bias"], out=out_tok[rs])
+            ops.patch_rearrange(out_tok[rs], pred[bs], nbt, cfg.out_channels, Hl, Wl, p, False, False)
+
+        if nchain == 1:
+            run_chain(0, B, main)
+        else:
+            bounds = [(B * c) // nchain for c in range(nchain + 1)]
+            fork = self._ev_record(main)
+            joins = []
+            for c in range(1, nchain):
+                st = self._chain_stream(c)
+                self._ev_wait(st, fork)
+                with torch.cuda.stream(st):
+                    run_chain(bounds[c], bounds[c + 1], st)
+                    joins.append(self._ev_record(st))
+            run_chain(bounds[0], bounds[1], main)
+            for ev in joins:
+                self._ev_wait(main, ev)
         self._saved = S
         return pred
 
@@ -443,28 +474,13 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
 
-        text = self._chain_stream(1) if (self.text_stream and side is not None) else None
-        if text is not None:
-            text.wait_stream(main)
-
-        def on_text(fn):
-            if text is None:
-                return fn()
-            with torch.cuda.stream(text):
-                return fn()
-
-        def event(stream):
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            return ev
-
         def off_chain(fn):
             """Weight / bias / modulation gradients: nothing on the dependent chain reads them -> second stream, right
-            behind their producer (the stream that is current: the image chain's or the text chain's)."""
+            behind their producer."""
             if side is None:
                 fn()
                 return
-            side.wait_stream(torch.cuda.current_stream())
+            self._wait_stream(side, torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 fn()
 
@@ -515,7 +531,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                                         S.Wl, p, False, True)
         wgrad(d_out_tok, S.hf, G["proj_out.weight"], G["proj_out.bias"])
         dhf = dgrad(d_out_tok, P["proj_out.weight"], out=buf("dh.0", (M, D)))
-        dembf = buf("dembf", (B, 2 * D), f32).zero_()
+        dembf = ops.zero_(buf("dembf", (B, 2 * D), f32))
         dx = ops.ln_modulate_bwd(S.x_last, S.meanf, S.rstdf, S.embf[:, 0:D], 2 * D, N, dhf, None, buf("dx.a", (M, D)),
                                  dembf[:, D:2 * D], dembf[:, 0:D], 2 * D, ws_ln)
         off_chain(lambda: mod_grads(dembf, "norm_out.linear.weight", "norm_out.linear.bias", "f"))
@@ -529,16 +545,13 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             ld1, ldc = n1 * D, nc * D
             par = i & 1
             if set_done[par] is not None:
-                main.wait_event(set_done[par])             # block i+2's second-stream work has read this buffer set
-                if text is not None:
-                    text.wait_event(set_done[par])
+                self._ev_wait(main, set_done[par])         # block i+2's second-stream work has read this buffer set
                 set_done[par] = None
 
             def pb(name, shape, dtype=BF16):
                 return buf(f"{name}.{par}", shape, dtype)
-            demb1 = buf(f"demb1.{par}.{n1}", (B, ld1), f32).zero_()
-            dembc = buf(f"dembc.{par}.{nc}", (B, ldc), f32)
-            on_text(dembc.zero_)                           # (only the text chain accumulates into it)
+            demb1 = ops.zero_(buf(f"demb1.{par}.{n1}", (B, ld1), f32))
+            dembc = ops.zero_(buf(f"dembc.{par}.{nc}", (B, ldc), f32))
             # ---- image feed-forward: x3 = xa + gate_mlp * (f1 W2^T + b2)
             dlin3 = pb("dlin3", (M, D))
             ops.gate_bwd(dx, A.lin3, e1[:, 5 * D:6 * D], ld1, N, dlin3, demb1[:, 5 * D:6 * D], ld1, ws_gate,
@@ -594,9 +607,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                                  dbias=G[b_ + "attn.to_add_out.bias"], accumulate_bias=acc)
                     wgrad(dclin1, A.o_c, G[b_ + "attn.to_add_out.weight"])
                     return dc1_, dgrad(dclin1, P[b_ + "attn.to_add_out.weight"], out=buf("do_c", (Mt, D)))
-                dc1, do_c = on_text(text_bwd_a)
-                if text is not None:
-                    main.wait_event(event(text))
+                dc1, do_c = text_bwd_a()
             # ---- joint attention backward
             do_j = buf("do_j", (B * L, D))
             ops.joint_rows(do_j, do_i, do_c, B, N, T, to_joint=True)       # (no text gradient in the last block: zeros)
@@ -613,8 +624,6 @@ class SD3Transformer2DModelHIP(FlatParamModule):
             _, gbqkv = self._fused(b_ + "attn.to_q.bias", 3 * D)
             waqkv, gaqkv = self._fused(b_ + "attn.add_q_proj.weight", 3 * D, D)
             _, gbaqkv = self._fused(b_ + "attn.add_q_proj.bias", 3 * D)
-            if text is not None:
-                text.wait_event(event(main))               # dqkv_c
             wgrad(dqkv, A.h1, gqkv, gbqkv)
             dh1 = dgrad(dqkv, wqkv, out=buf("dh.0", (M, D)))
             # ---- AdaLayerNormZero backward: both modulations of the image stream share one LayerNorm
@@ -638,30 +647,23 @@ class SD3Transformer2DModelHIP(FlatParamModule):
                                                dembc[:, D:2 * D], dembc[:, 0:D], ldc, ws_lnc)
                 return ops.ln_modulate_bwd(A.c_in, A.cmean1, A.crstd1, ec[:, D:2 * D], ldc, T, dhc, dc1, dcn,
                                            dembc[:, 0:D], dembc[:, D:2 * D], ldc, ws_lnc)
-            dc = on_text(text_bwd_b)
+            dc = text_bwd_b()
 
             def block_done(demb1=demb1, dembc=dembc, b_=b_, i=i):
                 mod_grads(demb1, b_ + "norm1.linear.weight", b_ + "norm1.linear.bias", f"1.{i & 1}")
                 mod_grads(dembc, b_ + "norm1_context.linear.weight", b_ + "norm1_context.linear.bias", f"c.{i & 1}")
                 if self.grad_ready is not None:
-                    self.grad_ready(i + 1)                 # DDP hook records on the CURRENT (second) stream
+                    self._callback(self.grad_ready, i + 1)     # DDP hook records on the CURRENT (second) stream
             if side is None:
                 block_done()
             else:
-                side.wait_stream(main)
-                if text is not None:
-                    side.wait_stream(text)                 # the text chain's share of dembc and of this bucket's gradients
+                self._wait_stream(side, main)
                 with torch.cuda.stream(side):
                     block_done()
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                set_done[par] = ev
+                    set_done[par] = self._ev_record(side)
         # ---- embedders (small: back on one stream)
-        if text is not None:
-            main.wait_stream(text)
-            text = None
         if side is not None:
-            main.wait_stream(side)
+            self._wait_stream(main, side)
             side = None
         wgrad(dx, S.x_tok, G["pos_embed.proj.weight"].view(D, Kp), G["pos_embed.proj.bias"], dgrad_follows=False)   # + pos_embed: identity
         wgrad(dc, S.enc2d, G["context_embedder.weight"], G["context_embedder.bias"], dgrad_follows=False)
@@ -679,7 +681,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         wgrad(dzp, S.pooled, G[pre + "text_embedder.linear_1.weight"], G[pre + "text_embedder.linear_1.bias"],
               dgrad_follows=False)
         if self.grad_ready is not None:
-            self.grad_ready(0)
+            self._callback(self.grad_ready, 0)
         if ad is not None:
             assert not pending_ad, "an adapter weight gradient was queued without a following dgrad()"
             ad.project()                  # adapter gradients complete (LoKr: d_P -> d_w1, d_w2_a; DDP hook)
