@@ -307,14 +307,14 @@ def test_sd35_qknorm_concat_full_rows(ops):
     with torch.no_grad():
         o_bf, _, _ = ref(BF)
     # torch's GPU rsqrt / mean differ from the CPU's in the last fp32 bit here and there, so the GPU restatement is held to
-    # "one bf16 ulp on a vanishing share of the elements"; the bit-exact statement is made on the CPU for the first and the
+    # "an ulp or two on a vanishing share of the elements"; the bit-exact statement is made on the CPU for the first and the
     # last image (the CPU restatement is what tests/test_sd3_gpu.py pins at small sizes)
     bad = (joint != o_bf)
     frac = bad.float().mean().item()
     assert frac <= 1e-4, frac
     if frac:
         a, b = joint[bad].float(), o_bf[bad].float()
-        assert ((a - b).abs() <= 2.0 ** -7 * b.abs() + 1e-30).all()
+        assert ((a - b).abs() <= 2.0 ** -6 * b.abs() + 1e-30).all()         # two roundings (normalise, then * weight): <= 2 ulps
     del o_bf, bad
     for img in (0, Bq - 1):
         xi = qkv_i[img * N_:(img + 1) * N_].cpu().view(1, N_, 3, H_, dh)
