@@ -27,20 +27,39 @@ constexpr int DKV_STAGE = 2 * TILE + 512;   // one query-tile stage of the dK/dV
 
 enum { IMG_ROW = 0, IMG_TR = 1 };
 
-// stage a [64 rows][128 cols] bf16 tile (rows past row_limit / cols past dh read as zero)
+// Staging a [64 rows][128 cols] bf16 tile image by LDS-DMA (rows past the limit / cols past dh read as zero).  What a lane
+// contributes to a tile -- (row within the tile, 16-byte chunk) of each of the 16 / NW pieces its wave issues -- never changes,
+// so its byte offsets relative to the tile's first row are loop-invariant registers (``TileSrc``); the tile's position rides
+// in the buffer RESOURCE, rebuilt per tile on the scalar unit: base = first row of the tile (at the head's columns), size =
+// the rows left below the limit, so the hardware range check zero-fills the rows past it.  (The first version computed a
+// 64-bit row index, a compare and a select per piece and lane for every tile: ~55 vector instructions per 64-key tile in
+// loops that are bound by vector issue, not by the matrix pipe.)
+template <int NW = 4>
+struct TileSrc { uint32_t voff[16 / NW]; };
 template <int IMG, int NW = 4>
-__device__ __forceinline__ void stage64x128(__amdgpu_buffer_rsrc_t rsrc, char* lds, int64_t row0, int64_t row_limit,
-                                            int ld, int col0, int dh, int wave, int lane) {
+__device__ __forceinline__ TileSrc<NW> tile_src(int ld, int dh, int wave, int lane) {
+    TileSrc<NW> t;
 #pragma unroll
     for (int j = 0; j < 16 / NW; ++j) {
         const int piece = j * NW + wave;
         const int r = piece * 4 + (lane >> 4);
         const int slot = lane & 15;
         const int chunk = IMG == IMG_ROW ? (slot ^ (r & 15)) : (slot ^ ((r & 7) << 1));
-        const int64_t gr = row0 + r;
-        const uint32_t voff = (gr < row_limit && chunk * 8 < dh) ? (uint32_t)((gr * ld + col0 + chunk * 8) * 2) : YAT_OOB;
-        lds_dma16(rsrc, (YAT_LDS void*)(lds + piece * 1024), voff);
+        t.voff[j] = chunk * 8 < dh ? (uint32_t)((r * ld + chunk * 8) * 2) : YAT_OOB;
     }
+    return t;
+}
+// rows [row0, row_limit) of a matrix with row stride ld, seen from column col0: offset (r * ld + c) * 2 is in range iff
+// r < row_limit - row0 (for every c < ld; columns past the head are switched off per lane in tile_src)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const bf16_t* base, int64_t row0, int64_t row_limit, int ld,
+                                                            int col0) {
+    const int64_t rows = row_limit - row0;
+    return make_rsrc(base + row0 * ld + col0, rows > 0 ? (uint64_t)rows * ld * 2 : 0);
+}
+template <int NW = 4>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds, const TileSrc<NW>& src, int wave) {
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) lds_dma16(rsrc, (YAT_LDS void*)(lds + (j * NW + wave) * 1024), src.voff[j]);
 }
 // operand fragment, natural k order, from a ROW image: idx = row0 + (lane&15), k = ks*32 + 8*(lane>>4) + j
 __device__ __forceinline__ bf16x8 frag_row(const char* lds, int row0, int ks, int lane) {
@@ -126,8 +145,48 @@ __device__ __forceinline__ int64_t kv_row_limit(const SdpaP& p, int64_t r0, int 
 // One stage = K (ROW image) + V (TR image) + the 64 key-bias floats.  Two stages in LDS: tile t+1 (and its bias, by
 // 4-byte LDS-DMA -- an ordinary global load inside the loop would drain the DMAs with its vmcnt(0)) is in flight while
 // tile t is consumed, one barrier per tile.  With ~3 live key tiles per image the loop is latency, not MFMA, bound.
+//
+// Long key loops (self-attention over thousands of keys) are bound by VECTOR ISSUE, not by the matrix pipe: per 64-key
+// tile and wave (dh 72, three 16-query sub-tiles) 66 MFMAs = 1056 pipe cycles stood against ~2100 issue cycles (MFMA 8,
+// v_exp 8, everything else 4 each: MI355X_MICROARCH.md "vector-instruction ISSUE cost") -- 51 exps and ~290 other vector
+// instructions.  The exps are the minimum; what the template switches remove is the rest:
+//   NOBIAS  no key bias and every key attends (self-attention): the scale rides in the exp's own FMA --
+//           exp2(s * (scale log2e) - m * (scale log2e)) with the running maximum kept on the raw scores -- so the
+//           per-score scale/bias FMA, the bias tile and its LDS reads go; keys past T in the last tile are masked there only.
+//   ONES    the row sums come out of the P V product: column dh of the V image (a padding column: dh < 16 DT) holds 1.0 --
+//           written once, the DMA lanes that would zero-fill it are switched off -- so o[.][column dh] accumulates
+//           sum_k bf16(P) with every rescale applied, and the per-score adds and their cross-lane reduction go.
+//   (both)  LAZY RESCALE: the output accumulators are multiplied by exp(m_old - m_new) only when some row's tile maximum
+//           exceeds the running reference by more than 2^8 (then every row moves to its true maximum); otherwise the
+//           reference stays, exp2 arguments stay <= 8 and P <= 256 -- exact in fp32 / bf16, the final O / l ratio is the
+//           same number.  After the first tile this is rare, and the 60 multiplies + 3 exps per tile go with it.
+//   The cross-lane maxima use v_permlane16/32_swap (two VALU instructions per step) instead of ds_bpermute.
 constexpr int FWD_STAGE = 2 * TILE + 256;
-template <int KS, int DT, int QS>
+constexpr float LAZY_LOG2 = 8.0f;                   // rescale threshold, in units of log2 (P stays <= 2^8)
+
+__device__ __forceinline__ float vmaxf(float a, float b) {      // v_max_f32 without the canonicalising self-max
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// reductions across the 4 lane groups that share lane & 15, on the VALU: swap odd / even 16-lane rows, then 32-lane halves
+__device__ __forceinline__ float group_max_swap(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    u2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float group_sum_swap(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}
+#define YAT_SKIP 0xffffffffu                        // TileSrc offset of a lane that does not take part in the DMA (ONES)
+
+template <int KS, int DT, int QS, bool NOBIAS, bool ONES>
 __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     // QS = 16-query sub-tiles per wave: the workgroup covers 64*QS queries.  With QS = 2 every K / V fragment read from LDS
     // feeds two MFMAs and the per-tile costs (9 LDS-DMA issues per wave, the barrier) are shared by twice the work -- the
@@ -140,17 +199,39 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     if (p.xcd_remap) xcd_contiguous3(bx, h, b);
     else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
     const int q0 = bx * (64 * QS) + wave * (16 * QS);
-    const int kvl = p.kv_len ? p.kv_len[b] : 0;
+    const int kvl = (!NOBIAS && p.kv_len) ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, NOBIAS ? 0 : p.bias_bytes);
 
     const int64_t kvr0 = kv_row0(p, b), kvrl = kv_row_limit(p, kvr0, klim);
+    const TileSrc<> src_k = tile_src<IMG_ROW>(p.ldkv, p.dh, wave, lane);
+    TileSrc<> src_v = tile_src<IMG_TR>(p.ldkv, p.dh, wave, lane);
+    if constexpr (ONES) {
+        // column dh of the V image = 1.0 in every row of both stages, never touched by the DMA again
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = j * 4 + wave, r = piece * 4 + (lane >> 4);
+            const int chunk = (lane & 15) ^ ((r & 7) << 1);
+            if (chunk * 8 == p.dh) {
+                src_v.voff[j] = YAT_SKIP;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    *reinterpret_cast<u32x4*>(smem + st * FWD_STAGE + TILE + piece * 1024 + lane * 16) = u32x4{0x3F80u, 0u, 0u, 0u};
+            }
+        }
+    }
     auto stage = [&](int k0, char* base) {
-        stage64x128<IMG_ROW>(rk, base, kvr0 + k0, kvrl, p.ldkv, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR>(rv, base + TILE, kvr0 + k0, kvrl, p.ldkv, col0, p.dh, wave, lane);
-        if (wave == 0) {
+        stage_tile(tile_rsrc(p.k, kvr0 + k0, kvrl, p.ldkv, col0), base, src_k, wave);
+        const __amdgpu_buffer_rsrc_t rv = tile_rsrc(p.v, kvr0 + k0, kvrl, p.ldkv, col0);
+        if constexpr (ONES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (src_v.voff[j] != YAT_SKIP) lds_dma16(rv, (YAT_LDS void*)(base + TILE + (j * 4 + wave) * 1024), src_v.voff[j]);
+        } else {
+            stage_tile(rv, base + TILE, src_v, wave);
+        }
+        if (!NOBIAS && wave == 0) {
             const int key = k0 + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
                                                      key < p.T ? (uint32_t)(((int64_t)b * p.T + key) * 4) : YAT_OOB, 0, 0, 0);
@@ -174,6 +255,9 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
         m[qs] = -1e30f;
         l[qs] = 0.f;
     }
+    // exp2 argument = x * ce - m * ce: x = raw score (NOBIAS, ce = scale log2e) or scaled + biased score (ce = log2e)
+    const float ce = NOBIAS ? p.scale * LOG2E : LOG2E;
+    const float lazy = LAZY_LOG2 / ce;              // the threshold in the units of m
 
     int it = 0;
     for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
@@ -181,7 +265,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // tile `it` landed for every wave; stage (it+1)&1 is free
         if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * FWD_STAGE);
-        mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
+        if constexpr (!NOBIAS) mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
         const char* Ks = cur;
         const char* Vs = cur + TILE;
         const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
@@ -198,37 +282,66 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
                 for (int qs = 0; qs < QS; ++qs) s[qs][nj] = mfma16(kfrag, qf[qs][ks], s[qs][nj]);
             }
         }
-        bf16x8 pf0[QS], pf1[QS];
-        float alpha[QS];
+        if constexpr (NOBIAS) {
+            if (k0 + 64 > p.T) {                               // uniform: keys past T in the last tile vanish from the softmax
 #pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            float mx = -1e30f;
+                for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + nj * 16 + 4 * g + r >= p.T)
+#pragma unroll
+                            for (int qs = 0; qs < QS; ++qs) s[qs][nj][r] = -1e30f;
+            }
+        } else {
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = __builtin_fmaf(s[qs][nj][r], p.scale, bv[r]);
-                    s[qs][nj][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qs][nj][r] = __builtin_fmaf(s[qs][nj][r], p.scale, bv[r]);
             }
-            mx = group_max(mx);
-            const float mn = fmaxf(m[qs], mx);
-            const float nm2 = -mn * LOG2E;
-            alpha[qs] = exp_sub(m[qs], nm2);
+        }
+        // tile maxima; does any row of this wave outrun its reference by more than the threshold?
+        float mx[QS];
+        bool grow = false;
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+            float t = -1e30f;
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t = fmaxf(t, s[qs][nj][r]);
+            mx[qs] = group_max_swap(t);
+            grow |= mx[qs] > m[qs] + lazy;
+        }
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {          // uniform; after the first tile: rare
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) {
+                const float mn = fmaxf(m[qs], mx[qs]);
+                const float alpha = __builtin_amdgcn_exp2f((m[qs] - mn) * ce);
+                m[qs] = mn;
+                l[qs] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qs][dt][r] *= alpha;
+            }
+        }
+        bf16x8 pf0[QS], pf1[QS];
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+            const float nm2 = -m[qs] * ce;
             float rs = 0.f;
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp_sub(s[qs][nj][r], nm2);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qs][nj][r], ce, nm2));
                     s[qs][nj][r] = e;
-                    rs += e;
+                    if constexpr (!ONES) rs += e;
                 }
-            rs = group_sum(rs);
-            l[qs] = l[qs] * alpha[qs] + rs;
-            m[qs] = mn;
+            if constexpr (!ONES) l[qs] += group_sum_swap(rs);
             pf0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
             pf1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
         }
@@ -237,8 +350,6 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
             const bf16x8 v0 = frag_tr_acc(Vs, 0, dt * 16, lane), v1 = frag_tr_acc(Vs, 32, dt * 16, lane);
 #pragma unroll
             for (int qs = 0; qs < QS; ++qs) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qs][dt][r] *= alpha[qs];
                 o[qs][dt] = mfma16(v0, pf0[qs], o[qs][dt]);
                 o[qs][dt] = mfma16(v1, pf1[qs], o[qs][dt]);
             }
@@ -246,6 +357,13 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     }
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
+        if constexpr (ONES) {
+            // the row sum sits in the accumulator of output column dh: lane group (dh % 16) / 4, component dh % 4
+            const int dc = p.dh - (DT - 1) * 16;
+            const f32x4 t = o[qs][DT - 1];
+            const float mine = (dc & 3) == 0 ? t[0] : (dc & 3) == 1 ? t[1] : (dc & 3) == 2 ? t[2] : t[3];
+            l[qs] = __shfl(mine, (dc >> 2) * 16 + li, 64);
+        }
         const int qi = q0 + qs * 16 + li;
         if (qi < p.N) {
             const float inv = 1.0f / l[qs];
@@ -257,7 +375,8 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
                     *reinterpret_cast<u32x2*>(op + d) =
                         pack4(o[qs][dt][0] * inv, o[qs][dt][1] * inv, o[qs][dt][2] * inv, o[qs][dt][3] * inv);
             }
-            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m[qs] + __logf(l[qs]);
+            // lse in the units of the scaled (+ biased) scores, as the backward kernels read it
+            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m[qs] * (NOBIAS ? p.scale : 1.0f) + __logf(l[qs]);
         }
     }
 }
@@ -278,15 +397,14 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     const int kvl = p.kv_len ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.kv_bytes), rv = make_rsrc(p.v, p.kv_bytes);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
     const int64_t qlim = (int64_t)b * p.N + p.N;
 
     const int64_t kvr0 = kv_row0(p, b), kvrl = kv_row_limit(p, kvr0, klim);
+    const TileSrc<> src_k = tile_src<IMG_TR>(p.ldkv, p.dh, wave, lane), src_v = tile_src<IMG_ROW>(p.ldkv, p.dh, wave, lane);
     auto stage = [&](int k0, char* base) {
-        const int64_t r0 = kvr0 + k0, rl = kvrl;
-        stage64x128<IMG_TR>(rk, base, r0, rl, p.ldkv, col0, p.dh, wave, lane);
-        stage64x128<IMG_ROW>(rv, base + TILE, r0, rl, p.ldkv, col0, p.dh, wave, lane);
+        stage_tile(tile_rsrc(p.k, kvr0 + k0, kvrl, p.ldkv, col0), base, src_k, wave);
+        stage_tile(tile_rsrc(p.v, kvr0 + k0, kvrl, p.ldkv, col0), base + TILE, src_v, wave);
         if (wave == 0) {
             const int key = k0 + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
@@ -434,7 +552,7 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             }
         }
     }
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes), rdo = make_rsrc(p.dout, p.do_bytes);
+    const TileSrc<NW> src_q = tile_src<IMG_TR, NW>(p.ldq, p.dh, wave, lane), src_do = tile_src<IMG_TR, NW>(p.lddo, p.dh, wave, lane);
     const uint64_t stat_bytes = p.stat_bytes;
     const __amdgpu_buffer_rsrc_t rlse = make_rsrc(p.lse, stat_bytes), rdel = make_rsrc(p.delta, stat_bytes);
     const int64_t kvr0 = kv_row0(p, b), klimrow = kv_row_limit(p, kvr0, klim);
@@ -460,8 +578,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     // double-buffered query tiles: tile qt+1 is DMA'd while tile qt is consumed
     auto stage_q = [&](int q0, char* base) {
         const int64_t r0 = (int64_t)b * p.N + q0, rl = (int64_t)b * p.N + p.N;
-        stage64x128<IMG_TR, NW>(rq, base, r0, rl, p.ldq, col0, p.dh, wave, lane);
-        stage64x128<IMG_TR, NW>(rdo, base + TILE, r0, rl, p.lddo, col0, p.dh, wave, lane);
+        stage_tile<NW>(tile_rsrc(p.q, r0, rl, p.ldq, col0), base, src_q, wave);
+        stage_tile<NW>(tile_rsrc(p.dout, r0, rl, p.lddo, col0), base + TILE, src_do, wave);
         // lse / delta rows by 4-byte LDS-DMA as well: an ordinary VGPR load here would make the compiler wait
         // vmcnt(0) for it -- draining the 16 tile DMAs just issued and undoing the double buffering.  Rows past N read
         // as 0 (range check); their Q and dO rows are zero too, so P stays finite and dS = P * (0 - 0) = 0.
@@ -613,11 +731,11 @@ constexpr int FWD_LDS = 2 * FWD_STAGE, DQ_LDS = 2 * DQ_STAGE, DKV_LDS = 2 * DKV_
 // The LDS images stay 128 columns wide (columns past dh are zero-filled by the DMA range check); what the head dim decides
 // is how many of the 32-wide k-steps (KS) and 16-wide output tiles (DT) carry data.  Instantiations: dh <= 32 (SANA's
 // softmax variant of attn1), <= 64, <= 80 (PixArt-Sigma: 72), <= 112 (SANA cross-attention), <= 128.
-template <int KS, int DT, int QS>
+template <int KS, int DT, int QS, bool NOBIAS, bool ONES>
 int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdpa_fwd_kernel<KS, DT, QS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)sdpa_fwd_kernel<KS, DT, QS, NOBIAS, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 FWD_LDS) != hipSuccess)
             return YAT_EINVAL;
         attr_set = true;
