@@ -175,6 +175,10 @@ int yat_linear_attn_bwd(int B, int N, int H, const void* qkv, int ld, int k_off,
  * block (dh 72; self-attention over N = T = 4096 with q, k, v = the column blocks of the fused [3D] projection and a
  * zero key_bias; utils/patch_pixart_sigma_transformer.py:150-158).  The kernels pick a head-dim instantiation and the
  * workgroup shape (64 or 128 queries) from dh, N, H, B.
+ * key_bias == NULL (with kv_len == NULL, no work_list, not the packed form): plain attention over all T keys of every
+ * image -- the self-attentions of PixArt-Sigma and of the MMDiT (JointAttnProcessor2_0 passes no mask).  Same result as a
+ * zero bias; the kernels then fold the scale into the exponential's own multiply-add and (forward) take the row sums out
+ * of the P V product, which is what the long key loops (N = T = 4096 ... 4429) are short of: vector issue slots.
  * ------------------------------------------------------------------------------------------ */
 int yat_sdpa_fwd(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                  int ldkv, const float* key_bias, const int* kv_len, void* out, int ldo, float* lse, yat_stream_t stream);

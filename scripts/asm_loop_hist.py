@@ -16,12 +16,18 @@ heads = [i for i, l in enumerate(body) if "Loop Header" in l]
 print(f"{pat}: {end - start} lines, {len(heads)} loop header(s)")
 for hi in heads:
     label = body[hi].split(":")[0]
-    back = [i for i in range(len(body) - 1, hi, -1) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\s*$", body[i].split(";")[0])]
-    if not back:
+    bb = label.lstrip(".L")                     # "BB6_40"
+    # the loop = the header block + every later block the compiler marks "in Loop: Header=<bb>"
+    blocks = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
+    member = [i for i in blocks if i == hi or f"Header={bb} " in body[i] or body[i].rstrip().endswith(f"Header={bb}")]
+    if not member:
         continue
-    j = back[0]
+    lines_in = []
+    for i in member:
+        nxt = next((k for k in blocks if k > i), len(body))
+        lines_in += body[i + 1:nxt]
     cnt = collections.Counter()
-    for l in body[hi + 1:j + 1]:
+    for l in lines_in:
         l = l.strip()
         if l and not l.startswith((";", ".")):
             cnt[l.split()[0]] += 1
@@ -29,7 +35,8 @@ for hi in heads:
     mfma = sum(v for k, v in cnt.items() if k.startswith("v_mfma"))
     valu = sum(v for k, v in cnt.items() if k.startswith("v_")) - trans - mfma
     lds = sum(v for k, v in cnt.items() if k.startswith("ds_"))
-    print(f"\nloop {label}: {sum(cnt.values())} instructions: {mfma} MFMA, {trans} transcendental, {valu} other VALU, {lds} LDS, "
+    print(f"\nloop {label} ({len(member)} blocks, conditional ones included): {sum(cnt.values())} instructions: {mfma} MFMA, "
+          f"{trans} transcendental, {valu} other VALU, {lds} LDS, "
           f"{sum(v for k, v in cnt.items() if k.startswith('s_'))} scalar, {sum(v for k, v in cnt.items() if k.startswith('buffer_'))} buffer")
     print(f"  matrix pipe {16 * mfma} cycles; vector issue ~{8 * mfma + 8 * trans + 4 * valu} cycles (MFMA 8 + trans 8 + VALU 4)")
     for k, v in cnt.most_common(40):

@@ -50,6 +50,35 @@ print(f"self  N=T=4096: fwd={f:8.1f}us ({flops / f / 1e6:6.1f} TF)  dq={t_dq:8.1
       f"dkv={t_dkv:8.1f}us ({2.0 * flops / t_dkv / 1e6:6.1f} TF)", flush=True)
 print("self  rel err (out, dq, dk, dv) vs fp32 softmax:", ["%.2e" % e for e in
       check(q, k, v, N, zero, out, dout, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])], flush=True)
+# the same without a key bias (what the models launch for self-attention): the no-bias instantiations
+f = timeit(lambda: ops.sdpa_fwd(q, k, v, B, N, N, H, dh, sc, None, None, out, lse))
+a = (q, k, v, B, N, N, H, dh, sc, None, None, out, dout, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+t_dq = timeit(lambda: ops.sdpa_bwd(*a, parts=1))
+t_dkv = timeit(lambda: ops.sdpa_bwd(*a, parts=2))
+print(f"self  N=T=4096 no bias: fwd={f:8.1f}us ({flops / f / 1e6:6.1f} TF)  dq={t_dq:8.1f}us ({1.5 * flops / t_dq / 1e6:6.1f} TF)  "
+      f"dkv={t_dkv:8.1f}us ({2.0 * flops / t_dkv / 1e6:6.1f} TF)", flush=True)
+print("self  no bias rel err (out, dq, dk, dv) vs fp32 softmax:", ["%.2e" % e for e in
+      check(q, k, v, N, zero, out, dout, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])], flush=True)
+# SD3.5-Medium's joint attention: 24 heads x 64 over 4096 + 333 tokens
+Hs, dhs, Ls = 24, 64, 4429
+Ds = Hs * dhs
+qkv_s = torch.randn(B * Ls, 3 * Ds, device=dev, generator=g).to(BF)
+out_s = torch.empty(B * Ls, Ds, dtype=BF, device=dev); dout_s = torch.randn(B * Ls, Ds, device=dev, generator=g).to(BF)
+lse_s = torch.empty(B, Hs, Ls, device=dev); delta_s = torch.empty(B, Hs, Ls, device=dev)
+dqkv_s = torch.empty_like(qkv_s)
+scs = 1 / math.sqrt(dhs)
+fl_s = 4.0 * B * Hs * Ls * Ls * dhs
+for tag, bias_s, len_s in (("zero bias", torch.zeros(B, Ls, device=dev), torch.full((B,), Ls, dtype=torch.int32, device=dev)),
+                           ("no bias  ", None, None)):
+    qs_, ks_, vs_ = qkv_s[:, :Ds], qkv_s[:, Ds:2 * Ds], qkv_s[:, 2 * Ds:]
+    f = timeit(lambda: ops.sdpa_fwd(qs_, ks_, vs_, B, Ls, Ls, Hs, dhs, scs, bias_s, len_s, out_s, lse_s))
+    a = (qs_, ks_, vs_, B, Ls, Ls, Hs, dhs, scs, bias_s, len_s, out_s, dout_s, lse_s, delta_s, dqkv_s[:, :Ds], dqkv_s[:, Ds:2 * Ds],
+         dqkv_s[:, 2 * Ds:])
+    t_dq = timeit(lambda: ops.sdpa_bwd(*a, parts=1))
+    t_dkv = timeit(lambda: ops.sdpa_bwd(*a, parts=2))
+    print(f"sd3.5 joint L=4429 dh=64 {tag}: fwd={f:8.1f}us ({fl_s / f / 1e6:6.1f} TF)  dq={t_dq:8.1f}us ({1.5 * fl_s / t_dq / 1e6:6.1f} TF)  "
+          f"dkv={t_dkv:8.1f}us ({2.0 * fl_s / t_dkv / 1e6:6.1f} TF)", flush=True)
+del qkv_s, out_s, dout_s, dqkv_s
 
 T = 300
 lens = [20, 64, 100, 160, 200, 256, 300, 130]

@@ -208,8 +208,7 @@ def test_pixart_self_attention_full_size(ops):
         qkv = grnd(Bp * Np, 3 * Dp, seed=31)
         dout = grnd(Bp * Np, Dp, scale=0.1, seed=32)
         out, lse = torch.empty(Bp * Np, Dp, dtype=BF, device=DEV), torch.empty(Bp, Hp, Np, device=DEV)
-        zero = torch.zeros(Bp, Np, device=DEV)
-        full = torch.full((Bp,), Np, dtype=torch.int32, device=DEV)
+        zero = full = None                       # no key bias, as yat_amd/pixart.py launches attn1 (the no-bias instantiations)
         q, k, v = qkv[:, :Dp], qkv[:, Dp:2 * Dp], qkv[:, 2 * Dp:]
         ops.sdpa_fwd(q, k, v, Bp, Np, Np, Hp, dh, scale, zero, full, out, lse)
         dqkv = torch.full_like(qkv, float("nan"))
@@ -241,7 +240,7 @@ SD_B, SD_N, SD_T, SD_H, SD_DH = 2, 4096, 333, 24, 64
 @pytest.mark.parametrize("L,tag", [(SD_N + SD_T, "joint 4096+333"), (SD_N, "image-only second attention 4096")])
 def test_sd35_attention_full_size(ops, L, tag):
     """The joint attention (L = 4429) and the dual blocks' image-only attention (L = 4096) exactly as yat_amd/sd3.py launches
-    them -- q | k | v = column blocks of the [B*L, 3D] joint buffer, zero bias, kv_len = L -- forward, dQ, dK, dV against torch
+    them -- q | k | v = column blocks of the [B*L, 3D] joint buffer, no key bias -- forward, dQ, dK, dV against torch
     (fp32 truth, torch's own bf16 kernel as the yardstick) on two images."""
     Bs, Hs, dh = SD_B, SD_H, SD_DH
     Ds = Hs * dh
@@ -249,8 +248,7 @@ def test_sd35_attention_full_size(ops, L, tag):
     qkv = grnd(Bs * L, 3 * Ds, seed=41)
     dout = grnd(Bs * L, Ds, scale=0.1, seed=42)
     out, lse = torch.empty(Bs * L, Ds, dtype=BF, device=DEV), torch.empty(Bs, Hs, L, device=DEV)
-    zero = torch.zeros(Bs, L, device=DEV)
-    full = torch.full((Bs,), L, dtype=torch.int32, device=DEV)
+    zero = full = None                           # no key bias (JointAttnProcessor2_0 passes no mask): the no-bias instantiations
     q, k, v = qkv[:, :Ds], qkv[:, Ds:2 * Ds], qkv[:, 2 * Ds:]
     ops.sdpa_fwd(q, k, v, Bs, L, L, Hs, dh, scale, zero, full, out, lse)
     dqkv = torch.full_like(qkv, float("nan"))

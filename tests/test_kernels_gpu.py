@@ -515,6 +515,53 @@ def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
     as_good_as(dkv[:, D:], fl[2], vr.grad, f"sdpa_dv T={T}", tol_flow=1e-2)
 
 
+@pytest.mark.parametrize("B,N,H,dh", [
+    (2, 64, 1, 32), (2, 100, 2, 112), (1, 77, 3, 64), (2, 130, 2, 72), (1, 50, 2, 24), (2, 33, 1, 128), (1, 200, 2, 80),
+    # the 128- and 192-query workgroups (ceil(N/128 | 192) * H * B >= 1024) and the 32-key-per-wave dK/dV, ragged last tiles
+    (8, 250, 64, 32), (16, 200, 32, 64), (16, 400, 32, 72), (8, 130, 64, 112), (16, 385, 32, 64), (8, 300, 64, 72)])
+def test_sdpa_without_bias_matches_zero_bias(ops, B, N, H, dh):
+    """key_bias = NULL (self-attention: PixArt-Sigma attn1, the MMDiT's joint and image-only attentions, SANA's softmax
+    attn1): the no-bias instantiations -- scale folded into the exponential's multiply-add, row sums out of the P V product
+    where the head dim leaves (or is given) a padding column, lazy rescale -- against the zero-bias entry and against torch:
+    as good as torch's own bf16 kernel measured from the fp32 truth, forward (+ lse) and all three gradients, for every
+    head-dim class and for sequence lengths that end inside a 64-key tile."""
+    D, T = H * dh, N
+    scale = 1.0 / math.sqrt(dh)
+    qkv = rnd(B * N, 3 * D, seed=44)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    dout = rnd(B * N, D, seed=45)
+    zero, full = torch.zeros(B, T, device=DEV), torch.full((B,), T, dtype=torch.int32, device=DEV)
+    res = {}
+    for tag, bias, kvl in (("zero", zero, full), ("none", None, None)):
+        out, lse = torch.empty(B * N, D, dtype=BF, device=DEV), torch.empty(B, H, N, device=DEV)
+        ops.sdpa_fwd(q, k, v, B, N, T, H, dh, scale, bias, kvl, out, lse)
+        dqkv = torch.full_like(qkv, float("nan"))
+        ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvl, out, dout, lse, torch.empty(B, H, N, device=DEV),
+                     dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+        assert torch.isfinite(dqkv.float()).all()
+        res[tag] = (out, lse, dqkv)
+
+    def torch_path(dt):
+        t = qkv.to(dt).clone().requires_grad_(True)
+        heads = lambda x: x.reshape(B, N, H, dh).transpose(1, 2)
+        o = F.scaled_dot_product_attention(heads(t[:, :D]), heads(t[:, D:2 * D]), heads(t[:, 2 * D:]))
+        o = o.transpose(1, 2).reshape(B * N, D)
+        o.backward(dout.to(dt))
+        return o.detach(), t.grad
+    o32, g32 = torch_path(torch.float32)
+    obf, gbf = torch_path(BF)
+    s32 = (q.float().view(B, N, H, dh).transpose(1, 2) @ k.float().view(B, N, H, dh).permute(0, 2, 3, 1)) * scale
+    lse_ref = torch.logsumexp(s32, -1)
+    out, lse, dqkv = res["none"]
+    as_good_as(out, obf, o32, f"sdpa_nobias_fwd N={N} dh={dh}")
+    close(lse, lse_ref, f"sdpa_nobias_lse N={N} dh={dh}", tol=1e-4, ulps=0.01, atol=1e-3)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        as_good_as(dqkv[:, sl], gbf[:, sl], g32[:, sl], f"sdpa_nobias_{name} N={N} dh={dh}", tol_flow=1e-2)
+    # and next to the zero-bias entry: the same function, another rounding of P's scale -- a fraction of an ulp apart
+    assert rel(out, res["zero"][0]) <= 3e-3 and rel(dqkv, res["zero"][2]) <= 6e-3
+    assert (lse - res["zero"][1]).abs().max().item() <= 1e-3
+
+
 # ------------------------------------------------------------------------------------------------ GLUMBConv middle
 def _glu_ref(z, wdw, bdw, B, h, w, Hc):
     zi = z.float().view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)

@@ -385,8 +385,10 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
 // Stage = K (TR-swizzled image: read row-wise for S = Q K^T and transposed for dQ = dS K), V (ROW image), key bias.
 // Two stages, one barrier per key tile, as in the forward.
 constexpr int DQ_STAGE = 2 * TILE + 256;
-template <int KS, int DT, int QS>
+template <int KS, int DT, int QS, bool NOBIAS>
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
+    // NOBIAS (no key bias, every key attends): P = exp2(s * (scale log2e) - lse log2e) in one FMA + exp, no bias tile.  Keys
+    // past T in the last tile need no mask here: their K rows are zero-filled, so whatever dS they get multiplies zeros.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -394,18 +396,19 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     if (p.xcd_remap) xcd_contiguous3(bx, h, b);
     else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
     const int q0 = bx * (64 * QS) + wave * (16 * QS);               // QS 16-query sub-tiles per wave, as in the forward
-    const int kvl = p.kv_len ? p.kv_len[b] : 0;
+    const int kvl = (!NOBIAS && p.kv_len) ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, NOBIAS ? 0 : p.bias_bytes);
     const int64_t qlim = (int64_t)b * p.N + p.N;
+    const float ce = p.scale * LOG2E;
 
     const int64_t kvr0 = kv_row0(p, b), kvrl = kv_row_limit(p, kvr0, klim);
     const TileSrc<> src_k = tile_src<IMG_TR>(p.ldkv, p.dh, wave, lane), src_v = tile_src<IMG_ROW>(p.ldkv, p.dh, wave, lane);
     auto stage = [&](int k0, char* base) {
         stage_tile(tile_rsrc(p.k, kvr0 + k0, kvrl, p.ldkv, col0), base, src_k, wave);
         stage_tile(tile_rsrc(p.v, kvr0 + k0, kvrl, p.ldkv, col0), base + TILE, src_v, wave);
-        if (wave == 0) {
+        if (!NOBIAS && wave == 0) {
             const int key = k0 + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
                                                      key < p.T ? (uint32_t)(((int64_t)b * p.T + key) * 4) : YAT_OOB, 0, 0, 0);
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * DQ_STAGE);
-        mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
+        if constexpr (!NOBIAS) mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
         const char* Kt = cur;
         const char* Vs = cur + TILE;
         const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
@@ -470,10 +473,12 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
         for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
+                f32x4 bv;
+                if constexpr (!NOBIAS) bv = *reinterpret_cast<const f32x4*>(bias_s + nj * 16 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = exp_sub(__builtin_fmaf(s[qs][nj][r], p.scale, bv[r]), nlse2[qs]);
+                    const float pr = NOBIAS ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qs][nj][r], ce, nlse2[qs]))
+                                            : exp_sub(__builtin_fmaf(s[qs][nj][r], p.scale, bv[r]), nlse2[qs]);
                     s[qs][nj][r] = pr * (dp[qs][nj][r] - dl[qs]);   // dS (w.r.t. the scaled logits)
                 }
             }
@@ -507,8 +512,10 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <int KS, int DT, int KB, int NW>
+template <int KS, int DT, int KB, int NW, bool NOBIAS>
 __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
+    // NOBIAS: as in the dQ kernel (the scale folded into the exp's FMA); keys past T need no mask -- their dK / dV rows are
+    // not stored and no other key's result depends on them.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // stage layout: Q | dO (TR-swizzled images, read row-wise for S / dP and transposed for dK / dV) | lse[64] | delta[64]
     // (staging a ROW and a TR image of each, as before, made the loop LDS-DMA bound: 64 KB per query tile per CU)
@@ -526,9 +533,10 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     const int b = p.work ? p.work[2 * bx] : bz;
     const int tile = p.work ? p.work[2 * bx + 1] : bx;
     const int k0 = tile * KT + wave * (16 * KB);
-    const int kvl = p.kv_len ? p.kv_len[b] : 0;
+    const int kvl = (!NOBIAS && p.kv_len) ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int ntiles = (klim + KT - 1) / KT;
+    const float ce = p.scale * LOG2E;
     const int col0 = h * p.dh;
 
     if (tile >= ntiles) return;                 // dense-grid fallback only: masked tile, zeros written by its owner below
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             vf[kb][ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
         }
         kvalid[kb] = krow < klimrow;                // padded layout: key < T; packed: key < kv_len (the next row is another image's)
-        kb_[kb] = key < p.T ? p.bias[(int64_t)b * p.T + key] : -1e30f;        // keys past T: P = exp2(-huge) = 0
+        kb_[kb] = NOBIAS ? 0.f : (key < p.T ? p.bias[(int64_t)b * p.T + key] : -1e30f);   // keys past T: P = exp2(-huge) = 0
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { adk[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
@@ -634,7 +642,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ql = nq * 16 + 4 * g + r;
-                        const float pr = exp_sub(__builtin_fmaf(s[kb][nq][r], p.scale, kb_[kb]), nl2[nq][r]);
+                        const float pr = NOBIAS ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][nq][r], ce, nl2[nq][r]))
+                                                : exp_sub(__builtin_fmaf(s[kb][nq][r], p.scale, kb_[kb]), nl2[nq][r]);
                         s[kb][nq][r] = pr;                                      // P
                         dp[kb][nq][r] = pr * (dp[kb][nq][r] - del_s[ql]);       // dS
                     }
@@ -688,7 +697,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
                         for (int r = 0; r < 4; ++r) {
                             // the same arithmetic as the 16-key branch: dense and work-list launches agree bit for bit
                             const int ql = (2 * half + hq) * 16 + 4 * g + r;
-                            const float pr = exp_sub(__builtin_fmaf(s[kb][hq][r], p.scale, kb_[kb]), -lse_s[ql] * LOG2E);
+                            const float pr = NOBIAS ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][hq][r], ce, -lse_s[ql] * LOG2E))
+                                                    : exp_sub(__builtin_fmaf(s[kb][hq][r], p.scale, kb_[kb]), -lse_s[ql] * LOG2E);
                             s[kb][hq][r] = pr;                                  // P
                             dp[kb][hq][r] = pr * (dp[kb][hq][r] - del_s[ql]);   // dS
                         }
@@ -740,27 +750,44 @@ int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
             return YAT_EINVAL;
         attr_set = true;
     }
-    hipLaunchKernelGGL((sdpa_fwd_kernel<KS, DT, QS>), dim3((p.N + 64 * QS - 1) / (64 * QS), p.H, B), dim3(256), FWD_LDS, stream,
-                       p);
+    hipLaunchKernelGGL((sdpa_fwd_kernel<KS, DT, QS, NOBIAS, ONES>), dim3((p.N + 64 * QS - 1) / (64 * QS), p.H, B), dim3(256),
+                       FWD_LDS, stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
+template <int KS, int DT, bool NOBIAS, bool ONES>
+int launch_fwd_x(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    if constexpr (KS <= 3) {
+        if (wide == 2) return launch_fwd_qs<KS, DT, 3, NOBIAS, ONES>(p, B, stream);      // 192-query workgroups
+    }
+    return wide ? launch_fwd_qs<KS, DT, 2, NOBIAS, ONES>(p, B, stream) : launch_fwd_qs<KS, DT, 1, NOBIAS, ONES>(p, B, stream);
+}
 template <int KS, int DT>
 int launch_fwd(const SdpaP& p, int B, int wide, hipStream_t stream) {
-    if (wide == 2) return launch_fwd_qs<KS, DT, 3>(p, B, stream);          // 192-query workgroups
-    return wide ? launch_fwd_qs<KS, DT, 2>(p, B, stream) : launch_fwd_qs<KS, DT, 1>(p, B, stream);
+    return p.bias ? launch_fwd_x<KS, DT, false, false>(p, B, wide, stream) : launch_fwd_x<KS, DT, true, false>(p, B, wide, stream);
+}
+// no key bias (self-attention): the head dims of the models get the ONES form -- the row sums from a padding column of V,
+// which for a head dim that fills its 16-wide output tiles exactly costs one more tile (dh 64: two MFMAs more per 16 queries
+// and key tile, against 16 adds and a cross-lane reduction less, in a loop bound by vector issue)
+int launch_fwd_nobias(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    const int dh = p.dh;
+    if (dh == 32) return launch_fwd_x<1, 3, true, true>(p, B, wide, stream);
+    if (dh == 64) return launch_fwd_x<2, 5, true, true>(p, B, wide, stream);
+    if (dh > 64 && dh < 80) return launch_fwd_x<3, 5, true, true>(p, B, wide, stream);
+    if (dh > 96 && dh <= 112) return launch_fwd_x<4, 8, true, true>(p, B, wide, stream);
+    return -100;            // no ONES instantiation: the caller falls back to the head-dim classes
 }
 template <int KS, int DT, int QS>
 int launch_dq_qs(const SdpaP& p, int B, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<KS, DT, QS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                DQ_LDS) != hipSuccess)
-            return YAT_EINVAL;
-        attr_set = true;
+    const void* fn = p.bias ? (const void*)sdpa_bwd_dq_kernel<KS, DT, QS, false> : (const void*)sdpa_bwd_dq_kernel<KS, DT, QS, true>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[p.bias ? 0 : 1]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS) != hipSuccess) return YAT_EINVAL;
+        attr_set[p.bias ? 0 : 1] = true;
     }
-    hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS>), dim3((p.N + 64 * QS - 1) / (64 * QS), p.H, B), dim3(256), DQ_LDS,
-                       stream, p);
+    const dim3 grid((p.N + 64 * QS - 1) / (64 * QS), p.H, B);
+    if (p.bias) hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS, false>), grid, dim3(256), DQ_LDS, stream, p);
+    else hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS, true>), grid, dim3(256), DQ_LDS, stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
@@ -770,16 +797,16 @@ int launch_dq(const SdpaP& p, int B, int wide, hipStream_t stream) {
 }
 template <int KS, int DT, int KB, int NW>
 int launch_dkv_kb(const SdpaP& p, int B, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel<KS, DT, KB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                DKV_LDS) != hipSuccess)
-            return YAT_EINVAL;
-        attr_set = true;
+    const void* fn = p.bias ? (const void*)sdpa_bwd_dkv_kernel<KS, DT, KB, NW, false> : (const void*)sdpa_bwd_dkv_kernel<KS, DT, KB, NW, true>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[p.bias ? 0 : 1]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) != hipSuccess) return YAT_EINVAL;
+        attr_set[p.bias ? 0 : 1] = true;
     }
     constexpr int KT = 16 * KB * NW;
     const dim3 grid = p.work ? dim3(p.n_work, p.H, 1) : dim3((p.T + KT - 1) / KT, p.H, B);
-    hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<KS, DT, KB, NW>), grid, dim3(64 * NW), DKV_LDS, stream, p);
+    if (p.bias) hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<KS, DT, KB, NW, false>), grid, dim3(64 * NW), DKV_LDS, stream, p);
+    else hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<KS, DT, KB, NW, true>), grid, dim3(64 * NW), DKV_LDS, stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
@@ -806,8 +833,9 @@ int check_common(int B, int N, int T, int H, int dh, int ldq, int ldkv, int64_t 
 int sdpa_fwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q, int ldq, const void* k, const void* v,
                   int ldkv, const int* kv_off, int64_t kv_rows, const float* key_bias, const int* kv_len, void* out, int ldo,
                   float* lse, yat_stream_t stream) {
-    if (check_common(B, N, T, H, dh, ldq, ldkv, kv_rows) || (ldo & 3) || !q || !k || !v || !key_bias || !out) return YAT_EINVAL;
+    if (check_common(B, N, T, H, dh, ldq, ldkv, kv_rows) || (ldo & 3) || !q || !k || !v || !out) return YAT_EINVAL;
     if (kv_off && !kv_len) return YAT_EINVAL;          // packed keys: every image says how many rows it owns (all >= 1)
+    if (!key_bias && (kv_len || kv_off)) return YAT_EINVAL;      // no bias = plain attention over all T keys of every image
     SdpaP p{};
     p.N = N; p.T = T; p.H = H; p.dh = dh; p.scale = scale;
     p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.ldkv = ldkv;
@@ -824,6 +852,10 @@ int sdpa_fwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     int wide = (int64_t)((N + 127) / 128) * H * B >= 1024;
     if (dh <= 80 && (int64_t)((N + 191) / 192) * H * B >= 1024) wide = 2;
     if (wide_env >= 0) wide = wide_env;
+    if (!key_bias) {
+        const int rc = launch_fwd_nobias(p, B, wide, (hipStream_t)stream);
+        if (rc != -100) return rc;
+    }
     return YAT_SDPA_DISPATCH(launch_fwd, dh, p, B, wide, (hipStream_t)stream);
 }
 
@@ -832,8 +864,9 @@ int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
                   int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, void* dv,
                   int lddkv, const int* work_list, int n_work, int parts, yat_stream_t stream) {
     if (check_common(B, N, T, H, dh, ldq, ldkv, kv_rows) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddkv & 3) || !q || !k ||
-        !v || !key_bias || !out || !dout || !lse || !delta || !dq || !dk || !dv)
+        !v || !out || !dout || !lse || !delta || !dq || !dk || !dv)
         return YAT_EINVAL;
+    if (!key_bias && (kv_len || kv_off || work_list)) return YAT_EINVAL;
     if ((uint64_t)B * N * lddo * 2 > 0x7fffffffull) return YAT_EINVAL;
     if (kv_off && !kv_len) return YAT_EINVAL;
     SdpaP p{};

@@ -493,8 +493,11 @@ def linear_attn_bwd(qkv2d, B, N, H, k_off, v_off, dout, dqkv, workspace, state=N
 def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse, kv_off=None):
     """k2d / v2d may be column slices of one fused [B*T, 2*H*dh] projection (same row stride).  ``kv_off`` (device int32, one
     row offset per image): packed keys -- k2d / v2d are the whole [rows, .] matrices without padding rows
-    (include/yat_hip.h: yat_sdpa_fwd_packed)."""
+    (include/yat_hip.h: yat_sdpa_fwd_packed).  ``key_bias`` None (then ``kv_len`` None too): plain attention over all T
+    keys -- self-attention; same result as a zero bias, on the kernels' no-bias instantiations."""
     assert k2d.stride(0) == v2d.stride(0)
+    if key_bias is None and (kv_len is not None or kv_off is not None):
+        raise ValueError("sdpa: no key bias means every key of every image attends (no kv_len, no packed keys)")
     if kv_off is not None:
         rc = _lib().yat_sdpa_fwd_packed(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                                         _p(kv_off), k2d.shape[0], _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(lse),
@@ -517,8 +520,11 @@ def kv_work_list(lens, T, device):
 def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, lse, delta, dq, dk, dv, work=None,
              parts=3, kv_off=None):
     """parts: 1 = dQ + delta, 2 = dK/dV (after part 1, possibly on another stream), 3 = both.  ``kv_off``: packed keys, as in
-    ``sdpa_fwd`` (dk / dv share the packed row layout; rows outside the images' ranges are left alone)."""
+    ``sdpa_fwd`` (dk / dv share the packed row layout; rows outside the images' ranges are left alone).  ``key_bias`` None:
+    as in ``sdpa_fwd``."""
     assert k2d.stride(0) == v2d.stride(0) and dk.stride(0) == dv.stride(0)
+    if key_bias is None and (kv_len is not None or kv_off is not None or work is not None):
+        raise ValueError("sdpa: no key bias means every key of every image attends (no kv_len, no work list, no packed keys)")
     if kv_off is not None:
         rc = _lib().yat_sdpa_bwd_packed(B, N, T, H, dh, scale, _p(q2d), q2d.stride(0), _p(k2d), _p(v2d), k2d.stride(0),
                                         _p(kv_off), k2d.shape[0], _p(key_bias), _p(kv_len), _p(out), out.stride(0), _p(dout),

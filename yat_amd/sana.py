@@ -382,10 +382,6 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         out_tok = buf("out_tok", (M, Cout))
         pred = buf("pred", (B, Cout, N))                 # (arena: the caller consumes it before the next forward)
         la_per_image = H1 * 33 * 32
-        if cfg.modified_blocks:
-            zero_bias = self._const("sa_zero_bias", (B, N), f32, 0.0)
-            full_len = self._const("sa_full_len", (B,), torch.int32, N)
-            S.zero_bias, S.full_len = zero_bias, full_len
 
         def run_chain(b0, b1, stream):
             nb = b1 - b0
@@ -406,7 +402,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                     # the cross-attention kernel with q, k, v = the three column blocks of the fused projection
                     qkv_ = A.qkv[rs]
                     ops.sdpa_fwd(qkv_[:, :D], qkv_[:, D:2 * D], qkv_[:, 2 * D:], nb, N, N, H1, D // H1, 1.0 / math.sqrt(D // H1),
-                                 zero_bias[bs], full_len[bs], A.attn[rs], A.lse1[bs])
+                                 None, None, A.attn[rs], A.lse1[bs])
                 else:
                     ops.linear_attn_fwd(A.qkv[rs], nb, N, H1, D, 2 * D, A.attn[rs],
                                         A.la_state[b0 * la_per_image:b1 * la_per_image])
@@ -690,7 +686,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             dqkv = buf(f"dqkv.{par}", (M, 3 * D))
             if A.softmax1:
                 ops.sdpa_bwd(A.qkv[:, :D], A.qkv[:, D:2 * D], A.qkv[:, 2 * D:], B, N, N, H1, D // H1, 1.0 / math.sqrt(D // H1),
-                             S.zero_bias, S.full_len, A.attn, dattn, A.lse1, buf("delta1", (B, H1, N), f32), dqkv[:, :D],
+                             None, None, A.attn, dattn, A.lse1, buf("delta1", (B, H1, N), f32), dqkv[:, :D],
                              dqkv[:, D:2 * D], dqkv[:, 2 * D:])
             else:
                 ops.linear_attn_bwd(A.qkv, B, N, H1, D, 2 * D, dattn, dqkv, la_ws, state=A.la_state)
