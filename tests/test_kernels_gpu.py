@@ -559,7 +559,8 @@ def test_sdpa_without_bias_matches_zero_bias(ops, B, N, H, dh):
         as_good_as(dqkv[:, sl], gbf[:, sl], g32[:, sl], f"sdpa_nobias_{name} N={N} dh={dh}", tol_flow=1e-2)
     # and next to the zero-bias entry: the same function, another rounding of P's scale -- a fraction of an ulp apart
     assert rel(out, res["zero"][0]) <= 3e-3 and rel(dqkv, res["zero"][2]) <= 6e-3
-    assert (lse - res["zero"][1]).abs().max().item() <= 1e-3
+    # (lse: the no-bias forward sums the bf16-rounded probabilities -- its row sums are those of the P the P V product uses)
+    assert (lse - res["zero"][1]).abs().max().item() <= 3e-3
 
 
 # ------------------------------------------------------------------------------------------------ GLUMBConv middle

@@ -697,8 +697,11 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
                         for (int r = 0; r < 4; ++r) {
                             // the same arithmetic as the 16-key branch: dense and work-list launches agree bit for bit
                             const int ql = (2 * half + hq) * 16 + 4 * g + r;
-                            const float pr = NOBIAS ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][hq][r], ce, -lse_s[ql] * LOG2E))
-                                                    : exp_sub(__builtin_fmaf(s[kb][hq][r], p.scale, kb_[kb]), -lse_s[ql] * LOG2E);
+                            // (NOBIAS keeps this form with kb_ = 0 for head dims past 64: folding the scale into the exp's FMA here moved the
+                            //  register allocation of the <3, 5> instantiation from 235 to > 256 -- one wave per SIMD,
+                            //  1.41 -> 1.96 ms at N = T = 4096 -- for 16 of this loop's 166 vector instructions)
+                            const float pr = (NOBIAS && KS <= 2) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][hq][r], ce, -lse_s[ql] * LOG2E))
+                                                                 : exp_sub(__builtin_fmaf(s[kb][hq][r], p.scale, kb_[kb]), -lse_s[ql] * LOG2E);
                             s[kb][hq][r] = pr;                                  // P
                             dp[kb][hq][r] = pr * (dp[kb][hq][r] - del_s[ql]);   // dS
                         }
