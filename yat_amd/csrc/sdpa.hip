@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     }
 }
 
+#ifdef YAT_SDPA_PIPE_EXPERIMENT     // measured slower (see the comment): kept out of the product build
 // ---- forward, long key loops without a bias (self-attention), SOFTWARE-PIPELINED: after the changes above the SQ counters
 // (profiles/r03_b_attention_sq_counters.txt) show the waves of the forward stalled on issue 41 % of their cycles
 // (SQ_WAIT_INST_ANY: the softmax waits for the Q K^T results, the P V product for the softmax) with the matrix pipe ~55 %
@@ -557,6 +558,8 @@ __global__ __launch_bounds__(256) void sdpa_fwd_pipe_kernel(SdpaP p) {
         }
     }
 }
+
+#endif  // YAT_SDPA_PIPE_EXPERIMENT
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 // Stage = K (TR-swizzled image: read row-wise for S = Q K^T and transposed for dQ = dS K), V (ROW image), key bias.
@@ -935,6 +938,7 @@ int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
+#ifdef YAT_SDPA_PIPE_EXPERIMENT
 template <int KS, int DT, int QS>
 int launch_fwd_pipe(const SdpaP& p, int B, hipStream_t stream) {
     constexpr int LDS = 4 * TILE;
@@ -949,12 +953,17 @@ int launch_fwd_pipe(const SdpaP& p, int B, hipStream_t stream) {
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
+#endif
 template <int KS, int DT, bool NOBIAS, bool ONES>
 int launch_fwd_x(const SdpaP& p, int B, int wide, hipStream_t stream) {
+#ifdef YAT_SDPA_PIPE_EXPERIMENT
     if constexpr (NOBIAS && ONES && KS <= 3) {
-        static const int pipe_env = YAT_TUNE_INT("YAT_SDPA_PIPE", -1);
-        if (pipe_env != 0 && p.T >= 1024 && wide)                 // long key loops: the software-pipelined forward
+        if (p.T >= 1024 && wide)                                  // long key loops: the software-pipelined forward
             return wide == 2 ? launch_fwd_pipe<KS, DT, 3>(p, B, stream) : launch_fwd_pipe<KS, DT, 2>(p, B, stream);
+    }
+#endif
+    if constexpr (NOBIAS && ONES && KS <= 3) {
+        if (wide == 3) return launch_fwd_qs<KS, DT, 4, NOBIAS, ONES>(p, B, stream);      // 256-query workgroups
     }
     if constexpr (KS <= 3) {
         if (wide == 2) return launch_fwd_qs<KS, DT, 3, NOBIAS, ONES>(p, B, stream);      // 192-query workgroups
@@ -1050,6 +1059,8 @@ int sdpa_fwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     // leaves room for them at two waves per SIMD (dh <= 80): 1.26 -> 1.17 ms at N = T = 4096, dh 72
     int wide = (int64_t)((N + 127) / 128) * H * B >= 1024;
     if (dh <= 80 && (int64_t)((N + 191) / 192) * H * B >= 1024) wide = 2;
+    static const int wide4 = YAT_TUNE_INT("YAT_SDPA_WIDE4", 1);
+    if (wide4 && !key_bias && dh <= 80 && (int64_t)((N + 255) / 256) * H * B >= 1024) wide = 3;    // (no-bias ONES classes only)
     if (wide_env >= 0) wide = wide_env;
     if (!key_bias) {
         const int rc = launch_fwd_nobias(p, B, wide, (hipStream_t)stream);
