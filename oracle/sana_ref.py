@@ -177,7 +177,13 @@ class _SelfAttn(nn.Module):
 
 
 class _CrossAttn(nn.Module):
-    """attn2: all projections biased (patch_sana_attention_layers.py:54-65); AttnProcessor2_0 [RECALL]."""
+    """attn2: all projections biased (ctor arguments as in patch_sana_attention_layers.py:54-65).  The processor this oracle
+    restates is ``AttnProcessor2_0`` = ``F.scaled_dot_product_attention`` [RECALL]: what the STOCK diffusers
+    ``SanaTransformerBlock`` installs on attn2 -- the model ``train_sana.py:21,62`` loads and trains -- and what
+    ``patch_sana_attention_layers`` sets on the blocks it modifies (:128-129).  The vendored block class's own ctor (:48,64)
+    passes the classic ``AttnProcessor()`` (bf16 ``baddbmm`` + bf16 softmax instead of the fused kernel): the same function
+    with other bf16 rounding points; that class is only instantiated when the patched transformer builds fresh blocks, which
+    the SANA entry point never does.  Target of this oracle: the SDPA processor."""
 
     def __init__(self, dim, cross_dim, heads, head_dim):
         super().__init__()

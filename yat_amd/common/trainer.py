@@ -14,7 +14,8 @@ What is different (MI355X-first, documented in DESIGN.md):
   one fused launch pair, so ``clip_grad_norm_`` is a no-op hook here;
 * logging (``tb_writer.SummaryWriter``, TensorBoard event files) keeps the loss on the device and writes the
   scalars YAT_LOG_FLUSH steps at a time, so there is no per-step ``.item()`` stall (:364).
-PEFT adapters, dual-GPU mode, Dreambooth, REPA and DeepSpeed are out of scope.
+PEFT adapters (:212-241) are built -- LoRA, DoRA, LoKr, LoHa through ``wrap_adapters`` (yat_amd/lora.py, dora.py, lokr.py,
+loha.py); FourierFT is refused.  Dual-GPU mode, Dreambooth, REPA and DeepSpeed are out of scope.
 """
 from __future__ import annotations
 
