@@ -295,9 +295,9 @@ def test_sd35_qknorm_concat_full_rows(ops):
         return (y * w.to(dt)).to(dt)
 
     def ref(dt):
-        xi = qkv_i.to(dt).view(Bq, N_, 3, H_, dh).requires_grad_(True)
-        xt = qkv_t.to(dt).view(Bq, T_, 3, H_, dh).requires_grad_(True)
-        w = [t.to(dt).requires_grad_(True) for t in ws]
+        xi = qkv_i.detach().clone().to(dt).view(Bq, N_, 3, H_, dh).requires_grad_(True)
+        xt = qkv_t.detach().clone().to(dt).view(Bq, T_, 3, H_, dh).requires_grad_(True)
+        w = [t.detach().clone().to(dt).requires_grad_(True) for t in ws]
         qq = torch.cat([rms(xi[:, :, 0], w[0], dt), rms(xt[:, :, 0], w[2], dt)], 1)
         kk = torch.cat([rms(xi[:, :, 1], w[1], dt), rms(xt[:, :, 1], w[3], dt)], 1)
         vv = torch.cat([xi[:, :, 2], xt[:, :, 2]], 1)
