@@ -387,3 +387,43 @@ def test_pixart_launch_plan_replay_is_bit_identical():
     assert r_b == 0 and n_b == 0
     assert replays >= 2 * 4 and nplans <= 8
     assert torch.isfinite(l_a).all() and torch.equal(l_a, l_b) and torch.equal(p_a, p_b)
+
+
+def test_pixart_device_path_equals_autograd_path():
+    """``PixArtRecipe.optimize_device`` (what ``PixartSigmaTrainer.optimize`` runs when training: one packed H2D copy, noise
+    drawn on the device into a persistent buffer, launch plans) against ``optimize`` + ``loss.backward()`` (the autograd path
+    every oracle test pins) on the same host batch and the same global RNG state (train_pixart_sigma.py:170,172 draw from the
+    global device / CPU streams): loss and every gradient bit-identical, also on a replayed plan and with a CPU generator;
+    ``gscale`` (gradient accumulation, common/trainer.py:317,343) scales the gradient."""
+    from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
+    from yat_amd.recipe import PixArtRecipe
+    cfg = PixArtConfig(num_attention_heads=2, attention_head_dim=24, in_channels=4, out_channels=8, num_layers=2,
+                       cross_attention_dim=48, sample_size=8, patch_size=2, caption_channels=64)
+    hip = PixArtTransformer2DModelHIP(cfg, device=DEV).init_synthetic(4)
+    recipe = PixArtRecipe(hip, pad_to=64, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    latents = (torch.randn(3, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (5, 64, 17)]
+
+    def seeded(fn):
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        out = fn()
+        torch.cuda.synchronize()
+        return out.detach().clone(), hip.flat_grad.clone()
+
+    def autograd_path(gen=None):
+        loss = recipe.optimize(latents, embs, gen)
+        loss.backward()
+        return loss
+    la, ga = seeded(autograd_path)
+    for rep in range(3):                                            # the third call replays the recorded plans
+        r0 = getattr(hip, "plan_replays", 0)
+        ld, gd = seeded(lambda: recipe.optimize_device(latents, embs, None))
+        assert ld.dtype == BF and torch.equal(la, ld) and torch.equal(ga, gd), rep
+    assert hip.plan_replays - r0 == 2
+    lc, gc = seeded(lambda: autograd_path(torch.Generator().manual_seed(7)))
+    ld, gd = seeded(lambda: recipe.optimize_device(latents, embs, torch.Generator().manual_seed(7)))
+    assert torch.equal(lc, ld) and torch.equal(gc, gd) and not torch.equal(ga, gc)
+    _, gh = seeded(lambda: recipe.optimize_device(latents, embs, None, gscale=0.5))
+    assert rel(gh, 0.5 * ga.float()) <= 8e-3

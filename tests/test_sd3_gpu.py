@@ -449,3 +449,40 @@ def test_sd3_launch_plan_replay_and_chains_are_bit_identical():
     assert replays >= 2 * 4 and nplans <= 8
     assert torch.isfinite(l_a).all() and torch.equal(l_a, l_b) and torch.equal(p_a, p_b), "launch plans on vs off differ"
     assert torch.equal(l_a, l_c) and torch.equal(p_a, p_c), "two forward chains vs one differ"
+
+
+def test_sd3_device_path_equals_autograd_path():
+    """``SD3Recipe.optimize_device`` (what ``SD35Trainer.optimize`` runs when training) against ``optimize`` +
+    ``loss.backward()`` on the same host batch and global RNG state (train_sd35.py:180,182): loss and every gradient
+    bit-identical, also on a replayed plan; ``gscale`` scales the gradient."""
+    from yat_amd.recipe import SD3Recipe
+    from yat_amd.sd3 import SD3Config, SD3Transformer2DModelHIP
+    cfg = SD3Config(sample_size=16, patch_size=2, in_channels=8, out_channels=8, num_layers=3, attention_head_dim=64,
+                    num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128, pooled_projection_dim=64,
+                    pos_embed_max_size=24, dual_attention_layers=(0, 1))
+    hip = SD3Transformer2DModelHIP(cfg, device=DEV).init_synthetic(4)
+    recipe = SD3Recipe(hip, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    latents = (torch.randn(3, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+    embs = [(torch.randn(10, cfg.joint_attention_dim, generator=g).to(BF), torch.randn(cfg.pooled_projection_dim, generator=g).to(BF))
+            for _ in range(3)]
+
+    def seeded(fn):
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        out = fn()
+        torch.cuda.synchronize()
+        return out.detach().clone(), hip.flat_grad.clone()
+
+    def autograd_path():
+        loss = recipe.optimize(latents, embs, None)
+        loss.backward()
+        return loss
+    la, ga = seeded(autograd_path)
+    for rep in range(3):
+        r0 = getattr(hip, "plan_replays", 0)
+        ld, gd = seeded(lambda: recipe.optimize_device(latents, embs, None))
+        assert ld.dtype == BF and torch.equal(la, ld) and torch.equal(ga, gd), rep
+    assert hip.plan_replays - r0 == 2
+    _, gh = seeded(lambda: recipe.optimize_device(latents, embs, None, gscale=0.5))
+    assert rel(gh, 0.5 * ga.float()) <= 8e-3

@@ -70,7 +70,14 @@ class PixartSigmaTrainer(Model):
 
     def optimize(self, ratio, latents, embeddings, repa_tokens=None, generator: torch.Generator = None):
         """train_pixart_sigma.py:151-185 on the HIP path.  The reference draws noise and timesteps from the GLOBAL RNGs
-        (:170,172) and ignores the trainer's per-step generator; so does this."""
+        (:170,172) and ignores the trainer's per-step generator; so does this.  With gradients enabled (the training call,
+        common/trainer.py:337) the step runs on the allocation-free device path (one packed H2D copy, launch plans:
+        ``PixArtRecipe.optimize_device``) and the returned loss is marked so that ``accelerator.backward`` does not run a second
+        backward; under ``no_grad`` (exploration trials) it is the plain forward + loss."""
+        if torch.is_grad_enabled() and not latents.is_cuda and os.environ.get("YAT_TRAINER_FAST", "1") != "0":
+            loss = self.recipe.optimize_device(latents, embeddings, None, gscale=1.0 / self.accelerator.gradient_accumulation_steps)
+            loss.yat_backward_done = True
+            return loss
         return self.recipe.optimize(latents, embeddings, None)
 
 

@@ -103,7 +103,13 @@ class SD35Trainer(Model):
         return out
 
     def optimize(self, ratio, latents, embeddings, repa_tokens=None, generator: torch.Generator = None):
-        """train_sd35.py:165-194 on the HIP path (yat_amd.recipe.SD3Recipe.optimize); global RNG streams as there."""
+        """train_sd35.py:165-194 on the HIP path (yat_amd.recipe.SD3Recipe); global RNG streams as there.  With gradients
+        enabled (the training call, common/trainer.py:337) the step runs on the allocation-free device path (one packed H2D copy,
+        launch plans: ``SD3Recipe.optimize_device``) and the loss is marked "backward done"."""
+        if torch.is_grad_enabled() and not latents.is_cuda and os.environ.get("YAT_TRAINER_FAST", "1") != "0":
+            loss = self.recipe.optimize_device(latents, embeddings, None, gscale=1.0 / self.accelerator.gradient_accumulation_steps)
+            loss.yat_backward_done = True
+            return loss
         return self.recipe.optimize(latents, embeddings, None)
 
 

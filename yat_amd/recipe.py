@@ -300,15 +300,85 @@ class PixArtRecipe(SanaRecipe):
         loss = _MseBf16Chunk.apply(out, noise, self._mse_ws)
         return (loss, out, noise) if return_pred else loss
 
-    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, coef_a, coef_c, loss_out, kv_work=None):
-        """Straight-line step on device-resident inputs (bench.py): mix, forward, loss + dL/dpred, backward."""
+    def train_step_device(self, latents, enc, mask_bias_kvl, noise, timesteps, coef_a, coef_c, loss_out, kv_work=None,
+                          gscale=1.0):
+        """Straight-line step on device-resident inputs (scripts/bench_pixart.py, ``optimize_device``): mix, forward, loss +
+        dL/dpred (scaled by ``gscale``), backward."""
         bias, kvl = mask_bias_kvl
         noisy = ops.ddpm_add_noise(latents, noise, coef_a, coef_c, self._noisy(latents))
         out = self.model.forward_device(noisy, enc, timesteps, bias, kvl, kv_work=kv_work)      # (launch plans: yat_amd/flat.py)
         dpred = self._dpred(out)
-        ops.mse_bf16_chunk(out, noise, loss_out, dpred, self._mse_ws)
+        ops.mse_bf16_chunk(out, noise, loss_out, dpred, self._mse_ws, gscale=gscale)
         self.model.backward_device(dpred)
         return loss_out
+
+    def optimize_device(self, latents, embeddings, generator=None, gscale=1.0):
+        """The trainer's step (train_pixart_sigma.py:151-185 + the backward of common/trainer.py:344) on the allocation-free
+        path, as ``SanaRecipe.optimize_device``: the host side of the step -- cached latents, the ragged T5 rows, their
+        offsets, the timesteps and the two add_noise coefficients the host looks up, the attention work list -- is ONE pinned
+        buffer and ONE H2D copy; the noise is drawn on the device from the global RNG as the reference draws it (:170; a CPU
+        generator, when given, draws it on the host in the reference's order instead); pad / mask, add_noise, forward, bf16
+        loss + dL/dpred and backward are straight-line launches replayed from a launch plan.  -> loss (0-dim bf16 device
+        tensor, as the reference's ``MSELoss`` on bf16 operands returns); gradients are in the flat gradient buffer."""
+        if latents.is_cuda or embeddings[0].is_cuda:
+            raise ValueError("optimize_device stages host batches (the sampler yields CPU tensors)")
+        B, T = len(embeddings), self.pad_to
+        C = embeddings[0].shape[1]
+        lens = [int(e.shape[0]) for e in embeddings]
+        if max(lens) > T:
+            raise ValueError(f"embedding longer than pad length {T}")
+        rows = sum(lens)
+        pairs = [(b, t) for b, L in enumerate(lens) for t in range(((L if L > 0 else T) + 63) // 64)]     # ops.kv_work_list
+        nlat = latents.numel()
+        max_pairs = B * ((T + 63) // 64)
+        cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
+        host_noise = cpu_gen is not None
+        (o_lat, o_noise, o_off, o_t, o_a, o_c, o_work, o_emb), total = _layout(
+            [2 * nlat, 2 * nlat if host_noise else 0, 4 * (B + 1), 4 * B, 2 * B, 2 * B, 8 * max_pairs, 2 * rows * C])
+        st = self._stager = getattr(self, "_stager", None) or _Stager(self.dev)
+        pin = st.begin(total, capacity=total + 2 * (B * T - rows) * C)
+
+        def seg(o, n, dtype):
+            return pin[o:o + n].view(dtype)
+        seg(o_lat, 2 * nlat, BF16).view(latents.shape).copy_(latents)
+        if host_noise:                                                                                           # :170
+            torch.randn(latents.shape, generator=cpu_gen, dtype=BF16, out=seg(o_noise, 2 * nlat, BF16).view(latents.shape))
+        t, a, c = self.scheduler.sample(B, cpu_gen)                                                              # :172-174
+        if rows:
+            torch.cat([e.to(BF16) for e in embeddings], out=seg(o_emb, 2 * rows * C, BF16).view(rows, C))
+        offs = [0]
+        for L in lens:
+            offs.append(offs[-1] + L)
+        seg(o_off, 4 * (B + 1), torch.int32).copy_(torch.tensor(offs, dtype=torch.int32))
+        seg(o_t, 4 * B, torch.float32).copy_(t)                     # int64 timestep -> the float the embedder takes (exact)
+        seg(o_a, 2 * B, BF16).copy_(a)
+        seg(o_c, 2 * B, BF16).copy_(c)
+        seg(o_work, 8 * len(pairs), torch.int32).copy_(torch.tensor(pairs, dtype=torch.int32).flatten())
+        land = st.commit(total)
+
+        def dseg(o, n, dtype):
+            return land[o:o + n].view(dtype)
+        lat_d = dseg(o_lat, 2 * nlat, BF16).view(latents.shape)
+        if host_noise:
+            noise_d = dseg(o_noise, 2 * nlat, BF16).view(latents.shape)
+        else:
+            noise_d = self._scratch("_noise_buf", lat_d)
+            dev_gen = generator if (generator is not None and generator.device.type == "cuda") else None
+            torch.randn(latents.shape, generator=dev_gen, device=self.dev, dtype=BF16, out=noise_d)              # :170
+        fixed = getattr(self, "_fixed", None)
+        if fixed is None or fixed[0].shape != (B, T, C):
+            fixed = self._fixed = (torch.empty(B, T, C, dtype=BF16, device=self.dev),
+                                   torch.empty(B, T, dtype=torch.int64, device=self.dev),
+                                   torch.empty(B, T, dtype=torch.float32, device=self.dev),
+                                   torch.empty(B, dtype=torch.int32, device=self.dev),
+                                   torch.zeros(1, dtype=torch.float32, device=self.dev))
+        enc, mask, bias, kvl, loss_out = fixed
+        ops.pad_mask(dseg(o_emb, 2 * rows * C, BF16).view(rows, C), dseg(o_off, 4 * (B + 1), torch.int32), B, T, C, enc, mask,
+                     bias, kvl)                                                                                  # :158-168
+        self.train_step_device(lat_d, enc, (bias, kvl), noise_d, dseg(o_t, 4 * B, torch.float32), dseg(o_a, 2 * B, BF16),
+                               dseg(o_c, 2 * B, BF16), loss_out,
+                               kv_work=dseg(o_work, 8 * len(pairs), torch.int32).view(len(pairs), 2), gscale=gscale)
+        return loss_out[0].to(BF16)
 
 
 class _MseBf16Chunk(torch.autograd.Function):
@@ -372,13 +442,58 @@ class SD3Recipe:
         loss = _MseBf16Chunk.apply(pred, target, self._mse_ws)
         return (loss, pred, target) if return_pred else loss
 
-    def train_step_device(self, latents, prompt, pooled, noise, timesteps, sigmas, loss_out):
-        """Straight-line step on device-resident inputs (scripts/bench_sd35.py): mix, forward, loss + dL/dpred, backward."""
+    def train_step_device(self, latents, prompt, pooled, noise, timesteps, sigmas, loss_out, gscale=1.0):
+        """Straight-line step on device-resident inputs (scripts/bench_sd35.py, ``optimize_device``): mix, forward, loss +
+        dL/dpred (scaled by ``gscale``), backward."""
         noisy, target = ops.flow_mix(latents, noise, sigmas, self._scratch("_noisy_buf", latents), self._scratch("_target_buf", latents))
         pred = self.model.forward_device(noisy, prompt, pooled, timesteps)                        # (launch plans: yat_amd/flat.py)
         dpred = self._scratch("_dpred_buf", pred)
-        ops.mse_bf16_chunk(pred, target, loss_out, dpred, self._mse_ws)
+        ops.mse_bf16_chunk(pred, target, loss_out, dpred, self._mse_ws, gscale=gscale)
         self.model.backward_device(dpred)
         return loss_out
+
+    def optimize_device(self, latents, embeddings, generator=None, gscale=1.0):
+        """The trainer's step (train_sd35.py:165-194 + the backward of common/trainer.py:344) on the allocation-free path: cached
+        latents, the fixed-length prompt embeddings, the pooled projections, timesteps and sigmas travel in ONE pinned buffer and
+        ONE H2D copy; the noise is drawn on the device from the global RNG as the reference draws it (:180; a CPU generator,
+        when given, draws it on the host instead); mix, forward, bf16 loss + dL/dpred and backward replay a launch plan.
+        -> loss (0-dim bf16 device tensor); gradients are in the flat gradient buffer."""
+        prompt, pooled = self.stack_embeddings(embeddings)
+        if latents.is_cuda or prompt.is_cuda:
+            raise ValueError("optimize_device stages host batches (the sampler yields CPU tensors)")
+        B = latents.shape[0]
+        nlat, npr, npo = latents.numel(), prompt.numel(), pooled.numel()
+        cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
+        host_noise = cpu_gen is not None
+        (o_lat, o_noise, o_pr, o_po, o_t, o_sig), total = _layout([2 * nlat, 2 * nlat if host_noise else 0, 2 * npr, 2 * npo,
+                                                                   4 * B, 2 * B])
+        st = self._stager = getattr(self, "_stager", None) or _Stager(self.dev)
+        pin = st.begin(total)
+
+        def seg(o, n, dtype):
+            return pin[o:o + n].view(dtype)
+        seg(o_lat, 2 * nlat, BF16).view(latents.shape).copy_(latents)
+        if host_noise:
+            torch.randn(latents.shape, generator=cpu_gen, dtype=BF16, out=seg(o_noise, 2 * nlat, BF16).view(latents.shape))
+        _, t, sig = self.scheduler.sample(B, cpu_gen)                                                            # :182-184
+        seg(o_pr, 2 * npr, BF16).view(prompt.shape).copy_(prompt)
+        seg(o_po, 2 * npo, BF16).view(pooled.shape).copy_(pooled)
+        seg(o_t, 4 * B, torch.float32).copy_(t)
+        seg(o_sig, 2 * B, BF16).copy_(sig)
+        land = st.commit(total)
+
+        def dseg(o, n, dtype):
+            return land[o:o + n].view(dtype)
+        lat_d = dseg(o_lat, 2 * nlat, BF16).view(latents.shape)
+        if host_noise:
+            noise_d = dseg(o_noise, 2 * nlat, BF16).view(latents.shape)
+        else:
+            noise_d = self._scratch("_noise_buf", lat_d)
+            dev_gen = generator if (generator is not None and generator.device.type == "cuda") else None
+            torch.randn(latents.shape, generator=dev_gen, device=self.dev, dtype=BF16, out=noise_d)              # :180
+        loss_out = self.__dict__.setdefault("_loss_out", torch.zeros(1, dtype=torch.float32, device=self.dev))
+        self.train_step_device(lat_d, dseg(o_pr, 2 * npr, BF16).view(prompt.shape), dseg(o_po, 2 * npo, BF16).view(pooled.shape),
+                               noise_d, dseg(o_t, 4 * B, torch.float32), dseg(o_sig, 2 * B, BF16), loss_out, gscale=gscale)
+        return loss_out[0].to(BF16)
 
     _scratch = SanaRecipe._scratch
