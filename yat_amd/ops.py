@@ -205,6 +205,12 @@ def linear_dgrad_act(dy2d, w, z, act, out=None):
 FUSE_BIAS_GRAD = os.environ.get("YAT_FUSE_BIAS_GRAD", "1") != "0"
 
 
+def wgrad_fuses_bias(N, K):
+    """Does ``linear_wgrad`` take the bias gradient out of the weight-gradient GEMM itself ([N, K] weight)?  Only where the
+    shape policy would not split K anyway (>= 96 tiles of 256 x 256); otherwise it is a separate column-sum pass."""
+    return FUSE_BIAS_GRAD and ((N + 255) // 256) * ((K + 255) // 256) >= 96
+
+
 def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=None):
     """dW = dy^T x : dy [M,N], x [M,K] -> out [N,K] (optionally += for gradient accumulation).  ``bias_grad`` [N]: the bias
     gradient (column sums of dy) from the same launch (yat_gemm_epilogue.a_rowsum_out) -- or, with YAT_FUSE_BIAS_GRAD=0 and a
@@ -214,7 +220,7 @@ def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=Non
     # fused only where the shape policy would not split K anyway (>= 96 tiles of 256 x 256: csrc/gemm.hip est_time_256) -- the
     # fused form is one workgroup per tile over the whole K, and a 25-tile, K = 32768 weight gradient (PixArt's D x D) left
     # unsplit makes the weight-gradient stream the critical path (PixArt 228 -> 244 ms when it was fused unconditionally)
-    fused = bias_grad is not None and FUSE_BIAS_GRAD and ((N + 255) // 256) * ((K + 255) // 256) >= 96
+    fused = bias_grad is not None and wgrad_fuses_bias(N, K)
     r = gemm(dy2d, x2d, out, a_t=True, b_t=True, M=N, N=K, K=M, lda=dy2d.stride(0), ldb=K, ldc=K,
              residual=out if accumulate else None, a_rowsum=bias_grad if fused else None, a_rowsum_accumulate=accumulate,
              dyn="K")

@@ -148,6 +148,12 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         # in a one-workgroup-per-CU GEMM does not.  Off by default.
         self.fuse_act_bwd = os.environ.get("YAT_FUSE_ACT_BWD", "0") != "0"
         self.split_parts = os.environ.get("YAT_PIXART_SPLIT", "1") != "0"    # LN statistics / cross dK,dV off the chain
+        # Bias gradients that are their own column-sum pass (weight gradients of < 96 tiles are split along K, and the fused
+        # row-sum form needs the whole K in one workgroup) leave the weight-gradient stream: a 14 us column sum queued there
+        # waits for CUs that the GEMM workgroups of both streams hold for their whole life -- the kernel trace shows it
+        # "running" for a median 216 - 270 us, and the next weight gradient queued behind it.  On the forward's second chain
+        # stream (idle during the backward) it trickles in beside them instead.
+        self.aux_colsum = os.environ.get("YAT_AUX_COLSUM", "1") != "0"
         self.fwd_chains = int(os.environ.get("YAT_PIXART_CHAINS", "2"))      # independent forward chains (image ranges):
         #                                                                      241.9 -> 237.9 ms per step with two (same box)
         self.pos_bf16_base = True         # the base-grid table is a module buffer: ``.to(bfloat16)`` rounds it (:52)
@@ -189,7 +195,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
 
     # ------------------------------------------------------------------ device path (launch plans, yat_amd/flat.py)
     def _schedule_flags(self):
-        return (self.side_wgrad, self.fuse_act_bwd, self.split_parts, self.fwd_chains, self.training)
+        return (self.side_wgrad, self.fuse_act_bwd, self.split_parts, self.fwd_chains, self.aux_colsum, self.training)
 
     def forward_device(self, latents, enc, timestep, key_bias, kv_len, kv_work=None):
         """``forward_impl`` on device-resident inputs in persistent buffers, replayed from a launch plan when this (shapes,
@@ -404,6 +410,8 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         ad = self.adapters
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
+        aux = self._chain_stream(1) if (side is not None and self.aux_colsum and ad is None) else None
+        aux_used = [False]
         pending_ad = []                   # adapter weight gradients wait for the H product of the dgrad of the same dy
 
         def dgrad(dy_, w_, out=None, residual=None):
@@ -437,9 +445,16 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
                     off_chain(lambda: ad.wgrad(dy, x, gw, accumulate=acc))
                 return
 
+            own_pass = aux is not None and gbias is not None and not ops.wgrad_fuses_bias(dy.shape[1], x.shape[1])
+
             def run():
-                ops.linear_wgrad(dy, x, gw, accumulate=acc, bias_grad=gbias, colsum_ws=ws_col)      # bias gradient: same launch
+                ops.linear_wgrad(dy, x, gw, accumulate=acc, bias_grad=None if own_pass else gbias, colsum_ws=ws_col)
             off_chain(run)
+            if own_pass:                      # the separate column-sum pass: third stream (see __init__)
+                self._wait_stream(aux, torch.cuda.current_stream())
+                with torch.cuda.stream(aux):
+                    ops.colsum(dy, gbias, ws_col, accumulate=acc)
+                aux_used[0] = True
 
         # ---- output head
         d_out_tok = ops.patch_rearrange(dpred.to(BF16).contiguous(), buf("d_out_tok", (M, Co)), B, cfg.out_channels, S.Hl,
@@ -537,13 +552,18 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
                 block_done()
             else:
                 self._wait_stream(side, main)
+                if aux_used[0]:
+                    self._wait_stream(side, aux)      # this bucket's bias gradients; the buffers they read (parity sets)
+                    aux_used[0] = False
                 with torch.cuda.stream(side):
                     block_done()
                     set_done[par] = self._ev_record(side)
         # ---- embedders (small: back on one stream)
         if side is not None:
+            if aux_used[0]:
+                self._wait_stream(side, aux)
             self._wait_stream(main, side)
-            side = None
+            side = aux = None
         wgrad(dx, S.x_tok, G["pos_embed.proj.weight"].view(D, Kp), G["pos_embed.proj.bias"], dgrad_follows=False)   # + pos_embed: identity
         # caption branch: encp = linear_2(gelu_tanh(linear_1(enc)))
         wgrad(denc, S.c1, G["caption_projection.linear_2.weight"], G["caption_projection.linear_2.bias"])
