@@ -266,8 +266,10 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     hipStream_t stream = (hipStream_t)stream_;
     // policy word: tile variant + 100 * forced K split (tests / tuning) + 10000 * independent GEMM streams the caller keeps
     // in flight (0 / 1: this launch has the chip to itself) -- per call, so the library holds no policy state
-    int ksplit = 1, streams = 1;
+    int ksplit = 1, streams = 1, group = 0;
     if (variant < 0) return YAT_EINVAL;
+    if (variant >= 1000000) { group = variant / 1000000; variant %= 1000000; }      // tile-order row group (tuning; 0 = policy)
+    if (group > 64) return YAT_EINVAL;
     if (variant >= 10000) { streams = variant / 10000; variant %= 10000; }
     if (streams > 8) return YAT_EINVAL;
     {
@@ -330,6 +332,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (ksplit > 1 && (!workspace || !wide_ok || (uint64_t)ksplit * M * N * 4 > workspace_bytes)) return YAT_EINVAL;
         p.ksplit = ksplit;
         p.partial = (float*)workspace;
+        p.group = group;
         const int rc = yat_gemm256_launch(a_t, b_t, variant, p, stream);
         if (rc || ksplit == 1) return rc;
         return yat_gemm_splitk_reduce(p, stream);

@@ -194,7 +194,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #ifndef YAT_GEMM_GROUP
 #define YAT_GEMM_GROUP 4
 #endif
-    const int GROUP = YAT_GEMM_GROUP;
+    const int GROUP = p.group > 0 ? p.group : YAT_GEMM_GROUP;
     const int per_group = GROUP * p.nbn;
     const int gid = id / per_group, first_m = gid * GROUP;
     const int gsz = min(p.nbm - first_m, GROUP);
@@ -680,7 +680,7 @@ __device__ __forceinline__ void gemm1w_body(const GemmP p, int id) {
 
     const int ksl = id % p.ksplit;
     id /= p.ksplit;
-    const int GROUP = YAT_GEMM_GROUP;
+    const int GROUP = p.group > 0 ? p.group : YAT_GEMM_GROUP;
     const int per_group = GROUP * p.nbn;
     const int gid = id / per_group, first_m = gid * GROUP;
     const int gsz = min(p.nbm - first_m, GROUP);

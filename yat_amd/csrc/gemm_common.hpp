@@ -23,6 +23,7 @@ struct GemmP {
     int ld_z;
     bf16_t* rowsum;        // wgrad layout: [M] row sums of the A operand over K (the Linear's bias gradient) or null
     int rowsum_acc;
+    int group;             // gemm256: 256-row tiles per row group of the XCD-contiguous tile order (0 = the default, 4)
 };
 
 // GLU backward fused into the producer of dy (= this GEMM's result d, rounded to bf16 like the Linear's output):
