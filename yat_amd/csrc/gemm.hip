@@ -332,7 +332,11 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (ksplit > 1 && (!workspace || !wide_ok || (uint64_t)ksplit * M * N * 4 > workspace_bytes)) return YAT_EINVAL;
         p.ksplit = ksplit;
         p.partial = (float*)workspace;
-        p.group = group;
+        // Tile order: 4 rows of 256-row tiles share their B panels inside one XCD's contiguous run.  Swept per shape
+        // (scripts/gemm_group_sweep.py, profiles/r03_d_gemm_group_sweep.txt): the L2-miss traffic moves by up to 2.7 x with the
+        // group size (profiles/r03_d_gemm_traffic_vs_tile_order.txt) and the time by < 1 % -- the re-reads are served by the
+        // Infinity Cache -- except the long-K input gradient (8192 x 2240 x 11200: 7 MB B panels), 3 - 6 % faster with 8.
+        p.group = group ? group : ((!a_t && b_t && K >= 8192) ? 8 : 0);
         const int rc = yat_gemm256_launch(a_t, b_t, variant, p, stream);
         if (rc || ksplit == 1) return rc;
         return yat_gemm_splitk_reduce(p, stream);
