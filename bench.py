@@ -452,67 +452,72 @@ def main():
     # stream and around the compute stream's wait for it.  Every rank runs them (collectives), rank 0 reports.
     comm = None
     if ddp is not None:
-        K = max(2, args.comm_steps)
-        base = args.warmup + args.steps + len(BUCKETS)
-        base += (-base) % len(BUCKETS)                     # every pass starts on the same bucket
+        try:
+            K = max(2, args.comm_steps)
+            base = args.warmup + args.steps + len(BUCKETS)
+            base += (-base) % len(BUCKETS)                     # every pass starts on the same bucket
 
-        def timed_pass():
-            barrier()
-            tp = time.perf_counter()
-            for i in range(K):
-                step(base + i)
-            barrier()
-            dt = time.perf_counter() - tp
+            def timed_pass():
+                barrier()
+                tp = time.perf_counter()
+                for i in range(K):
+                    step(base + i)
+                barrier()
+                dt = time.perf_counter() - tp
+                if world > 1:
+                    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = tt.item()
+                return 1e3 * dt / K
+            step(base)                                         # (plans of this bucket order are recorded by now; one settle step)
+            ms_live = timed_pass()
+            ddp.dryrun = True
+            ms_dry = timed_pass()
+            ddp.dryrun = False
             if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = tt.item()
-            return 1e3 * dt / K
-        step(base)                                         # (plans of this bucket order are recorded by now; one settle step)
-        ms_live = timed_pass()
-        ddp.dryrun = True
-        ms_dry = timed_pass()
-        ddp.dryrun = False
-        if world > 1:
-            ddp.broadcast_parameters()                     # the dry steps did not average: bring the replicas back together
-        ddp.timing, ddp.timed_buckets, ddp.timed_waits = True, [], []
-        b0, n0 = ddp.bytes_reduced, ddp.buckets_reduced
-        ms_timing = timed_pass()
-        ddp.timing = False
-        torch.cuda.synchronize()
-        durs = sorted(e0.elapsed_time(e1) for _, _, e0, e1 in ddp.timed_buckets)
-        sizes = [nb for _, nb, _, _ in ddp.timed_buckets]
-        waits = [w0.elapsed_time(w1) for w0, w1 in ddp.timed_waits]
-        comm_ms = sum(durs) / K
-        exposed = max(0.0, ms_live - ms_dry)
-        big = [(nb, e0.elapsed_time(e1)) for _, nb, e0, e1 in ddp.timed_buckets if nb >= (32 << 20)]
-        comm = {
-            "world": world, "forced_one_rank": bool(force_ddp and world == 1),
-            "transport": "native (yat_comm_* behind the C ABI)" if ddp.native is not None else f"torch.distributed ({backend})",
-            "buckets_per_step": (ddp.buckets_reduced - n0) / K, "bytes_per_step": (ddp.bytes_reduced - b0) / K,
-            "bucket_mb_min_max": [min(sizes) / 2 ** 20, max(sizes) / 2 ** 20] if sizes else None,
-            "bucket_us_min_median_max": [1e3 * durs[0], 1e3 * durs[len(durs) // 2], 1e3 * durs[-1]] if durs else None,
-            "comm_stream_ms_per_step": comm_ms,
-            # per-rank algorithm bandwidth of the large buckets (bytes / time) and the bus bandwidth a ring moves for it
-            "algbw_gbps_large_buckets": (sum(nb for nb, _ in big) / (1e-3 * sum(t for _, t in big)) / 1e9) if big else None,
-            "busbw_factor": 2.0 * (world - 1) / world,
-            "step_ms": ms_live, "step_ms_collective_off": ms_dry, "step_ms_timing_pass": ms_timing,
-            "exposed_ms_per_step": exposed,
-            "optimizer_wait_ms_per_step": sum(waits) / max(1, len(waits)),
-            "overlap_frac": (1.0 - min(1.0, exposed / comm_ms)) if comm_ms > 0 else None,
-            "rccl_channels": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")},
-            "coalesce": ddp.coalesce, "steps_per_pass": K,
-            "note": ("exposed = step - step with the collective switched off (same inputs, same hooks / events / streams); "
-                     "overlap_frac = 1 - exposed / summed comm-stream time; optimizer_wait = how long the compute stream sat "
-                     "in HipDDP.wait() before clip + AdamW" + ("; ONE rank: RCCL runs its one-rank copy kernel, the link "
-                     "figures mean nothing -- the line is a rehearsal of the reporting" if world == 1 else "")),
-        }
-        if args.lokr or args.lora:
-            # BASELINE config 5: ONE small bucket (the adapter set's flat gradient), latency-bound
-            comm["adapter_allreduce_latency_us"] = 1e3 * durs[len(durs) // 2] if durs else None
-            comm["adapter_bucket_bytes"] = sizes[0] if sizes else None
-        log(f"data-parallel diagnostics: step {ms_live:.2f} ms, collective off {ms_dry:.2f} ms, comm stream {comm_ms:.2f} ms/step "
-            f"-> overlap {comm['overlap_frac']}")
+                ddp.broadcast_parameters()                     # the dry steps did not average: bring the replicas back together
+            ddp.timing, ddp.timed_buckets, ddp.timed_waits = True, [], []
+            b0, n0 = ddp.bytes_reduced, ddp.buckets_reduced
+            ms_timing = timed_pass()
+            ddp.timing = False
+            torch.cuda.synchronize()
+            durs = sorted(e0.elapsed_time(e1) for _, _, e0, e1 in ddp.timed_buckets)
+            sizes = [nb for _, nb, _, _ in ddp.timed_buckets]
+            waits = [w0.elapsed_time(w1) for w0, w1 in ddp.timed_waits]
+            comm_ms = sum(durs) / K
+            exposed = max(0.0, ms_live - ms_dry)
+            big = [(nb, e0.elapsed_time(e1)) for _, nb, e0, e1 in ddp.timed_buckets if nb >= (32 << 20)]
+            comm = {
+                "world": world, "forced_one_rank": bool(force_ddp and world == 1),
+                "transport": "native (yat_comm_* behind the C ABI)" if ddp.native is not None else f"torch.distributed ({backend})",
+                "buckets_per_step": (ddp.buckets_reduced - n0) / K, "bytes_per_step": (ddp.bytes_reduced - b0) / K,
+                "bucket_mb_min_max": [min(sizes) / 2 ** 20, max(sizes) / 2 ** 20] if sizes else None,
+                "bucket_us_min_median_max": [1e3 * durs[0], 1e3 * durs[len(durs) // 2], 1e3 * durs[-1]] if durs else None,
+                "comm_stream_ms_per_step": comm_ms,
+                # per-rank algorithm bandwidth of the large buckets (bytes / time) and the bus bandwidth a ring moves for it
+                "algbw_gbps_large_buckets": (sum(nb for nb, _ in big) / (1e-3 * sum(t for _, t in big)) / 1e9) if big else None,
+                "busbw_factor": 2.0 * (world - 1) / world,
+                "step_ms": ms_live, "step_ms_collective_off": ms_dry, "step_ms_timing_pass": ms_timing,
+                "exposed_ms_per_step": exposed,
+                "optimizer_wait_ms_per_step": sum(waits) / max(1, len(waits)),
+                "overlap_frac": (1.0 - min(1.0, exposed / comm_ms)) if comm_ms > 0 else None,
+                "rccl_channels": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")},
+                "coalesce": ddp.coalesce, "steps_per_pass": K,
+                "note": ("exposed = step - step with the collective switched off (same inputs, same hooks / events / streams); "
+                         "overlap_frac = 1 - exposed / summed comm-stream time; optimizer_wait = how long the compute stream sat "
+                         "in HipDDP.wait() before clip + AdamW" + ("; ONE rank: RCCL runs its one-rank copy kernel, the link "
+                         "figures mean nothing -- the line is a rehearsal of the reporting" if world == 1 else "")),
+            }
+            if args.lokr or args.lora:
+                # BASELINE config 5: ONE small bucket (the adapter set's flat gradient), latency-bound
+                comm["adapter_allreduce_latency_us"] = 1e3 * durs[len(durs) // 2] if durs else None
+                comm["adapter_bucket_bytes"] = sizes[0] if sizes else None
+            log(f"data-parallel diagnostics: step {ms_live:.2f} ms, collective off {ms_dry:.2f} ms, comm stream {comm_ms:.2f} ms/step "
+                f"-> overlap {comm['overlap_frac']}")
+        except Exception as e:     # a reported side object: it must never sink the bench line (every rank takes the same path)
+            ddp.dryrun = ddp.timing = False
+            comm = {"error": repr(e)}
+            log(f"data-parallel diagnostics failed: {e!r}")
 
     # ---- optional phase probe (after the timed region; nothing of it runs otherwise): GPU timestamps of the step's phases
     # from a handful of HIP events per step -- unlike a profiler's kernel trace it does not slow the host's enqueue, so the
