@@ -281,3 +281,77 @@ def pixart_optimize_ref(model, sched: DDPMSchedule, latents, embeddings, noise=N
     target = noise[: pred.shape[0], : pred.shape[1], : pred.shape[2], : pred.shape[3]]   # :183
     loss = nn.MSELoss()(pred.to(noise.dtype), target)                                    # :184
     return (loss, out, noise, timesteps) if return_pred else loss
+
+
+# --------------------------------------------------------------------------- validation sampler (test-only oracle)
+class DPMSolverPP2MRef:
+    """[RECALL] diffusers DPMSolverMultistepScheduler as the PixArt-Sigma pipelines configure it (dpmsolver++, order 2,
+    midpoint, lower_order_final, linear betas, epsilon prediction, linspace spacing, final sigma zero): tables in numpy float32 /
+    float64 exactly as ``set_timesteps`` builds them; the step written out formula by formula.  PARITY UNPINNED (no diffusers
+    offline)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02):
+        betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        acp = torch.cumprod(1.0 - betas, dim=0)
+        self.train_sigmas = (((1 - acp) / acp) ** 0.5).numpy()
+        self.n_train = num_train_timesteps
+
+    def set_timesteps(self, n):
+        ts = np.linspace(0, self.n_train - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+        sig = np.interp(ts, np.arange(0, len(self.train_sigmas)), self.train_sigmas)
+        self.timesteps = torch.from_numpy(ts)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.model_outputs, self.step_index, self.lower_order_nums = [None, None], 0, 0
+
+    @staticmethod
+    def _a_s(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def step(self, model_output, sample):
+        i, n = self.step_index, len(self.timesteps)
+        lower_order_final = i == n - 1                                  # final_sigmas_type == "zero"
+        alpha_t, sigma_t = self._a_s(self.sigmas[i])
+        x0 = (sample - sigma_t * model_output) / alpha_t                # convert_model_output (tensor dtype wins over 0-dim fp32)
+        self.model_outputs = [self.model_outputs[1], x0]
+        sample = sample.to(torch.float32)
+        a_t, s_t = self._a_s(self.sigmas[i + 1])
+        a_s0, s_s0 = self._a_s(self.sigmas[i])
+        lam_t, lam_s0 = torch.log(a_t) - torch.log(s_t), torch.log(a_s0) - torch.log(s_s0)
+        h = lam_t - lam_s0
+        if self.lower_order_nums < 1 or lower_order_final:
+            prev = (s_t / s_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * x0
+        else:
+            a_s1, s_s1 = self._a_s(self.sigmas[i - 1])
+            lam_s1 = torch.log(a_s1) - torch.log(s_s1)
+            r0 = (lam_s0 - lam_s1) / h
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            d0, d1 = m0, (1.0 / r0) * (m0 - m1)
+            prev = (s_t / s_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * d0 - 0.5 * (a_t * (torch.exp(-h) - 1.0)) * d1
+        if self.lower_order_nums < 2:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev.to(model_output.dtype)
+
+
+@torch.no_grad()
+def sample_latents_pixart_ref(model, latents, prompt_embeds, prompt_mask, negative_embeds, negative_mask,
+                              num_inference_steps=20, guidance_scale=5.0, dtype=torch.bfloat16):
+    """The denoising loop of utils/patch_pixart_sigma_pipeline.py:158-208 (vendored by the reference) over the oracle
+    transformer in ``dtype`` with the [RECALL] DPM-Solver++ scheduler above; dtype=float32: ground truth for the same start."""
+    sched = DPMSolverPP2MRef()
+    sched.set_timesteps(num_inference_steps)
+    x = latents.to(dtype)
+    enc = torch.cat([negative_embeds, prompt_embeds]).to(dtype)
+    mask = torch.cat([negative_mask, prompt_mask])
+    cin = x.shape[1]
+    for i, t in enumerate(sched.timesteps):
+        x_in = torch.cat([x] * 2)
+        cur = t[None].expand(x_in.shape[0])
+        eps = model(x_in, enc, cur, encoder_attention_mask=mask)
+        e_u, e_c = eps.chunk(2)
+        eps = e_u + guidance_scale * (e_c - e_u)
+        if eps.shape[1] // 2 == cin:
+            eps = eps.chunk(2, dim=1)[0]
+        x = sched.step(eps, x)
+    return x

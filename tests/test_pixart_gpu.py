@@ -427,3 +427,40 @@ def test_pixart_device_path_equals_autograd_path():
     assert torch.equal(lc, ld) and torch.equal(gc, gd) and not torch.equal(ga, gc)
     _, gh = seeded(lambda: recipe.optimize_device(latents, embs, None, gscale=0.5))
     assert rel(gh, 0.5 * ga.float()) <= 8e-3
+
+
+def test_pixart_validation_sampler_matches_oracle():
+    """CFG + DPM-Solver++ (2M) latent sampler -- the middle third of the reference's PixArt-Sigma ``validate()``
+    (train_pixart_sigma.py:117-129 over the vendored denoising loop utils/patch_pixart_sigma_pipeline.py:158-208; the scheduler is
+    [RECALL]): schedule tables equal to the oracle's, then the HIP model vs the oracle in bf16 and fp32 from the same initial
+    latents over 6 steps (first-order start, second-order multistep, first-order final step) on a tiny configuration."""
+    from oracle.pixart_ref import DPMSolverPP2MRef, sample_latents_pixart_ref
+    from yat_amd.sampler import sample_latents_pixart
+    from yat_amd.scheduler import DPMSolverPP2M
+    a, b = DPMSolverPP2M(), DPMSolverPP2MRef()
+    a.set_timesteps(20)
+    b.set_timesteps(20)
+    assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.sigmas, b.sigmas)
+    assert int(a.timesteps[0]) == 999 and int(a.timesteps[-1]) == 50 and float(a.sigmas[-1]) == 0.0 and len(a.sigmas) == 21
+    ref_bf, ref_32, hip, _, embs, _ = _setup(dict(num_layers=2), 2, 8, 12, [9, 16], seed=3)
+    C = embs[0].shape[1]
+    T = 16
+    enc = torch.zeros(2, T, C, dtype=BF)
+    mask = torch.zeros(2, T, dtype=torch.int64)
+    for i, e in enumerate(embs):
+        enc[i, :e.shape[0]] = e
+        mask[i, :e.shape[0]] = 1
+    g = torch.Generator().manual_seed(11)
+    neg = torch.zeros_like(enc)
+    neg[:, :2] = torch.randn(2, 2, C, generator=g).to(BF)
+    nmask = torch.zeros_like(mask)
+    nmask[:, :2] = 1
+    x0 = torch.randn(2, ref_bf.cfg.in_channels, 8, 12, generator=g).to(BF)
+    steps = 6
+    out = sample_latents_pixart(hip, enc, mask, neg, nmask, 8, 12, num_inference_steps=steps, guidance_scale=5.0, latents=x0)
+    o_bf = sample_latents_pixart_ref(ref_bf, x0, enc, mask, neg, nmask, steps, 5.0, BF)
+    o_32 = sample_latents_pixart_ref(ref_32, x0, enc, mask, neg, nmask, steps, 5.0, torch.float32)
+    e_hip, e_ref = rel(out, o_32), rel(o_bf, o_32)
+    print(f"[parity] pixart sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
+    assert torch.isfinite(out.float()).all() and out.shape == x0.shape
+    assert e_hip <= 1.3 * e_ref + 2e-3

@@ -63,3 +63,51 @@ def test_oracle_step_runs_and_learned_sigma_half_gets_no_gradient():
     assert {"pos_embed.proj.weight", "pos_embed.pos_embed", "adaln_single.linear.weight", "caption_projection.linear_2.bias",
             "transformer_blocks.1.attn2.to_out.0.bias", "transformer_blocks.0.ff.net.0.proj.weight",
             "transformer_blocks.0.ff.net.2.bias", "scale_shift_table", "proj_out.bias"} <= keys
+
+
+def test_dpm_solver_pp_2m_known_answers():
+    """The validation sampler's scheduler (yat_amd.scheduler.DPMSolverPP2M / oracle DPMSolverPP2MRef, [RECALL] of diffusers'
+    DPMSolverMultistepScheduler as the PixArt-Sigma pipeline configures it): the 20-step table (999, 949, ..., 50; trailing sigma
+    0), analytic properties of the update -- a zero noise prediction keeps x0 = x / alpha fixed, so every step is the DDIM
+    rescale x <- (alpha_t / alpha_s) x and the last one (sigma 0) returns x0 itself; a noise prediction that is exact for a
+    fixed x0 reproduces x0 at the end for any order -- and the two restatements agree bit for bit in fp32 and bf16."""
+    from oracle.pixart_ref import DPMSolverPP2MRef
+    from yat_amd.scheduler import DPMSolverPP2M
+    a = DPMSolverPP2M()
+    a.set_timesteps(20)
+    assert a.timesteps.tolist() == [int(round(x)) for x in torch.linspace(0, 999, 21).flip(0)[:-1].tolist()]
+    assert a.timesteps[0] == 999 and a.timesteps[-1] == 50 and a.sigmas[-1] == 0 and a.sigmas.shape == (21,)
+    acp = torch.cumprod(1 - torch.linspace(1e-4, 0.02, 1000), 0)
+    assert abs(float(a.sigmas[0]) - float(((1 - acp[999]) / acp[999]) ** 0.5)) < 1e-3 * float(a.sigmas[0])
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 6, 6, generator=g)
+    # (1) eps = 0: DDIM rescale, the final step lands on x0 = x_first / alpha_first
+    a.set_timesteps(5)
+    alpha = 1 / (a.sigmas ** 2 + 1) ** 0.5
+    cur = x.clone()
+    for i in range(5):
+        nxt = a.step(torch.zeros_like(cur), cur)
+        assert torch.allclose(nxt, cur * (alpha[i + 1] / alpha[i]), rtol=2e-5, atol=1e-6), i
+        cur = nxt
+    assert torch.allclose(cur, x / alpha[0], rtol=1e-4)
+    # (2) the exact noise for a fixed clean sample x0: x_t = alpha_t x0 + sigma_t' n  ->  the sampler returns x0
+    x0, n = torch.randn(2, 4, 6, 6, generator=g), torch.randn(2, 4, 6, 6, generator=g)
+    for cls in (DPMSolverPP2M, DPMSolverPP2MRef):
+        s = cls()
+        s.set_timesteps(7)
+        al = 1 / (s.sigmas ** 2 + 1) ** 0.5
+        cur = al[0] * x0 + s.sigmas[0] * al[0] * n
+        for i in range(7):
+            eps = (cur - al[i] * x0) / (s.sigmas[i] * al[i])
+            cur = s.step(eps, cur)
+        assert torch.allclose(cur, x0, rtol=1e-3, atol=1e-4), cls.__name__
+    # (3) the two restatements, step by step, both dtypes
+    for dt in (torch.float32, torch.bfloat16):
+        p, q = DPMSolverPP2M(), DPMSolverPP2MRef()
+        p.set_timesteps(6)
+        q.set_timesteps(6)
+        xa = xb = torch.randn(2, 4, 8, 8, generator=g).to(dt)
+        for i in range(6):
+            eps = torch.randn(2, 4, 8, 8, generator=g).to(dt)
+            xa, xb = p.step(eps, xa), q.step(eps, xb)
+            assert torch.equal(xa, xb), (dt, i)

@@ -66,7 +66,32 @@ class PixartSigmaTrainer(Model):
         raise NotImplementedError("text encoding is outside the hot-path scope; train from cached-feature shards")
 
     def validate(self):
-        raise NotImplementedError("PixArt validation pipeline (PAG + DPM-Solver + VAE decode) is outside the hot-path scope")
+        """Middle third of train_pixart_sigma.py:76-149: the 20-step DPM-Solver++ sampling with CFG 5.0 over the HIP transformer
+        (:117-129; ``pag_scale`` lands in the plain pipeline's ``**kwargs`` and is ignored), generator seeded 42 on the device
+        (:94).  The T5 encoder and the VAE are outside this build's scope, so the prompt embeddings come from a cached file
+        (``validation_embeds.pt`` next to the shards or in the cwd: a list of (prompt_embeds [1,T,C], mask [1,T],
+        negative_embeds, negative_mask) tuples as ``pipe.encode_prompt`` returns them, :100-108) and the result is the latents
+        (``output_type='latent'``), stored under models/<step>/ with a three-channel preview for the logger (:143)."""
+        from yat_amd.sampler import sample_latents_pixart
+        cands = [os.path.join(os.path.dirname(p), "validation_embeds.pt") for p in (self.params.local_shard_paths or [])]
+        path = next((c for c in cands + ["validation_embeds.pt"] if os.path.isfile(c)), None)
+        if path is None:
+            raise NotImplementedError("no cached validation embeddings (text encoding is outside the hot-path scope)")
+        embeds = torch.load(path, map_location="cpu")
+        gen = torch.Generator(device=self.accelerator.device).manual_seed(42)
+        side = self.model.config.sample_size
+        out = []
+        for pe, pm, ne, nm in embeds:
+            out.append(sample_latents_pixart(self.model, pe, pm, ne, nm, side, side, num_inference_steps=20, guidance_scale=5.0,
+                                             generator=gen).cpu())
+        os.makedirs(f"models/{self.global_step}", exist_ok=True)
+        torch.save(out, f"models/{self.global_step}/validation_latents.pt")
+        if self.logger is not None:
+            for idx, lat in enumerate(out):
+                x = lat[0, :3].float()
+                x = (x - x.amin()) / (x.amax() - x.amin()).clamp_min(1e-6)
+                self.logger.add_image(f"validation_latents/{idx}", x, self.global_step)
+        return out
 
     def optimize(self, ratio, latents, embeddings, repa_tokens=None, generator: torch.Generator = None):
         """train_pixart_sigma.py:151-185 on the HIP path.  The reference draws noise and timesteps from the GLOBAL RNGs

@@ -96,3 +96,43 @@ def sample_latents_sd3(model, prompt_embeds, pooled, negative_embeds, negative_p
             v = (v_u + guidance_scale * (v_c - v_u)).to(BF16)       # the pipeline combines in the model dtype
         latents = (latents.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(BF16)
     return latents
+
+
+@torch.no_grad()
+def sample_latents_pixart(model, prompt_embeds, prompt_mask, negative_embeds, negative_mask, height, width, *,
+                          num_inference_steps=20, guidance_scale=5.0, generator=None, solver=None, latents=None):
+    """The middle third of the reference's PixArt-Sigma ``validate()`` (train_pixart_sigma.py:117-129) over the HIP transformer:
+    the denoising loop of the pipeline as the reference vendors it (utils/patch_pixart_sigma_pipeline.py:158-208 -- CFG batch
+    (unconditional | conditional), ``scale_model_input`` = identity, integer timestep expanded to the batch, no micro-conditions,
+    ``noise_pred_uncond + g (noise_pred_text - noise_pred_uncond)``, the learned-sigma half dropped with ``.chunk(2, dim=1)[0]``,
+    ``scheduler.step``) with the pipe's DPM-Solver++ (2M) scheduler (``yat_amd.scheduler.DPMSolverPP2M`` [RECALL]).
+    ``pag_scale=2.0`` in the reference's call lands in the plain pipeline's ``**kwargs`` and is ignored (:67), so there is no
+    perturbed-attention pass.  height, width in latent pixels; returns latents [B, C_in, height, width] (bf16)."""
+    from .scheduler import DPMSolverPP2M
+    solver = solver or DPMSolverPP2M()
+    dev = model.device
+    B = prompt_embeds.shape[0]
+    cin = model.cfg.in_channels
+    if latents is None:
+        if generator is not None and generator.device.type == "cuda":
+            latents = torch.randn(B, cin, height, width, generator=generator, device=dev, dtype=BF16)
+        else:
+            latents = torch.randn(B, cin, height, width, generator=generator, dtype=BF16).to(dev)
+    latents = latents.to(device=dev, dtype=BF16) * solver.init_noise_sigma
+    do_cfg = guidance_scale > 1.0
+    enc = (torch.cat([negative_embeds, prompt_embeds]) if do_cfg else prompt_embeds).to(device=dev, dtype=BF16)
+    mask = (torch.cat([negative_mask, prompt_mask]) if do_cfg else prompt_mask).to(dev)
+    timesteps = solver.set_timesteps(num_inference_steps)
+    solver.sigmas = solver.sigmas.to(dev)
+    learned_sigma = model.cfg.out_channels // 2 == cin
+    for i in range(num_inference_steps):
+        x_in = torch.cat([latents, latents]) if do_cfg else latents
+        t = timesteps[i].expand(x_in.shape[0]).to(dev)
+        eps = model(x_in, encoder_hidden_states=enc, timestep=t, encoder_attention_mask=mask).sample
+        if do_cfg:
+            e_u, e_c = eps.chunk(2)
+            eps = e_u + guidance_scale * (e_c - e_u)              # in the model dtype, as the pipeline combines
+        if learned_sigma:
+            eps = eps.chunk(2, dim=1)[0]
+        latents = solver.step(eps.contiguous(), latents)
+    return latents
