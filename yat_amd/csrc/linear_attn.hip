@@ -91,6 +91,11 @@ __device__ __forceinline__ bf16x8 tok_frag(const bf16_t* base, int ld, int tok, 
     if (tok < N) z = *reinterpret_cast<const bf16x8*>(base + (int64_t)tok * ld + 8 * (lane >> 4));
     return z;
 }
+// the same four channels as raw bf16 pairs (to be unpacked later: lets a kernel issue every global load of its token range
+// up front -- these kernels run two waves per SIMD and a load consumed right where it is issued costs its full latency)
+__device__ __forceinline__ u32x2 tok4_raw(const bf16_t* base, int ld, int tok, int N, int c0) {
+    return tok < N ? *reinterpret_cast<const u32x2*>(base + (int64_t)tok * ld + c0) : u32x2{0u, 0u};
+}
 // 4 consecutive channels (c0..c0+3) of token `tok` as floats (output layout of the swapped MFMA)
 __device__ __forceinline__ void tok4(const bf16_t* base, int ld, int tok, int N, int c0, float* o) {
     if (tok < N) unpack4(*reinterpret_cast<const u32x2*>(base + (int64_t)tok * ld + c0), o);
@@ -210,13 +215,15 @@ __global__ __launch_bounds__(256) void la_fwd_kernel(int N, int H, const bf16_t*
     const bf16_t* qb = qkv + (int64_t)b * N * ld + h * C;
     bf16_t* ob = out + (int64_t)b * N * ld_out + h * C;
     const int g = lane >> 4, li = lane & 15;
+    // every load of the wave's 64 tokens first (tokens past N read as zero; their stores are guarded): one latency, not four
+    bf16x8 qfr[4];
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) qfr[grp] = tok_frag(qb, ld, cx * TB + wave * 64 + grp * 16 + li, N, lane);
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-        const int n0 = cx * TB + wave * 64 + grp * 16;
-        if (n0 >= N) break;
-        const int n = n0 + li;
+        const int n = cx * TB + wave * 64 + grp * 16 + li;
         f32x4 ut[3];
-        u_tiles(shi, slo, relu8(tok_frag(qb, ld, n, N, lane)), ut);
+        u_tiles(shi, slo, relu8(qfr[grp]), ut);
         const float den = __shfl(ut[2][0], li, 64) + 1e-15f;     // U[32] sits on lanes 0..15 (g = 0, r = 0)
         const float inv = 1.0f / den;
         if (n < N) {
@@ -276,13 +283,26 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) ds[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // every global load of the wave's 64 tokens first (see tok4_raw): q fragments, dO and q in the output layout
+    bf16x8 qfr[4];
+    u32x2 d4r[4][2], q4r[4][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int n = cx * TB + wave * 64 + s4 * 16 + li;
+        qfr[s4] = tok_frag(qb, ld, n, N, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            d4r[s4][t] = tok4_raw(dob, ld_do, n, N, t * 16 + 4 * g);
+            q4r[s4][t] = tok4_raw(qb, ld, n, N, t * 16 + 4 * g);
+        }
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                       // 32 tokens per dS k-step
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int n0 = cx * TB + wave * 64 + half * 32 + sub * 16;
             const int n = n0 + li;
-            const bf16x8 qf = relu8(tok_frag(qb, ld, n, N, lane));
+            const bf16x8 qf = relu8(qfr[half * 2 + sub]);
             f32x4 ut[3];
             u_tiles(shi, slo, qf, ut);
             const float den = __shfl(ut[2][0], li, 64) + 1e-15f;
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float d4[4];
-                tok4(dob, ld_do, n, N, t * 16 + 4 * g, d4);
+                unpack4(d4r[half * 2 + sub][t], d4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dot += d4[r] * (ut[t][r] * inv);             // dO . O
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
                 dq = mfma16(xhi[ct], dlo, dq);
                 dq = mfma16(xlo[ct], dhi, dq);
                 float q4v[4];
-                tok4(qb, ld, n, N, ct * 16 + 4 * g, q4v);
+                unpack4(q4r[half * 2 + sub][ct], q4v);
                 if (valid) {
                     float o[4];
 #pragma unroll
@@ -423,13 +443,21 @@ __global__ __launch_bounds__(256) void la_bwd_kv_kernel(int N, int H, const bf16
     const bf16_t* vb = qkv + (int64_t)b * N * ld + h * C + v_off;
     bf16_t* dkb = dqkv + (int64_t)b * N * ld_dq + h * C + k_off;
     bf16_t* dvb = dqkv + (int64_t)b * N * ld_dq + h * C + v_off;
+    bf16x8 kfr[4], vfr[4];
+    u32x2 k4r[4][2];
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {          // every load of the wave's 64 tokens first (see tok4_raw)
+        const int n = cx * TB + wave * 64 + grp * 16 + li;
+        kfr[grp] = tok_frag(kb, ld, n, N, lane);
+        vfr[grp] = tok_frag(vb, ld, n, N, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) k4r[grp][t] = tok4_raw(kb, ld, n, N, t * 16 + 4 * g);
+    }
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-        const int n0 = cx * TB + wave * 64 + grp * 16;
-        if (n0 >= N) break;
-        const int n = n0 + li;
-        const bf16x8 kf = relu8(tok_frag(kb, ld, n, N, lane));
-        const bf16x8 vf = tok_frag(vb, ld, n, N, lane);
+        const int n = cx * TB + wave * 64 + grp * 16 + li;
+        const bf16x8 kf = relu8(kfr[grp]);
+        const bf16x8 vf = vfr[grp];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             // dv^T[c'][n] = sum_c dS[c'][c] relu(k)[n][c]
@@ -439,7 +467,7 @@ __global__ __launch_bounds__(256) void la_bwd_kv_kernel(int N, int H, const bf16
             f32x4 dk = mfma16(chi[t], vf, f32x4{0.f, 0.f, 0.f, 0.f});
             dk = mfma16(clo[t], vf, dk);
             float k4[4];
-            tok4(kb, ld, n, N, t * 16 + 4 * g, k4);
+            unpack4(k4r[grp][t], k4);
             if (n < N) {
                 *reinterpret_cast<u32x2*>(dvb + (int64_t)n * ld_dq + t * 16 + 4 * g) = pack4(dv[0], dv[1], dv[2], dv[3]);
                 float o[4];
