@@ -254,7 +254,10 @@ __device__ __forceinline__ uint32_t q_off(uint32_t row, uint32_t byte) {
 __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_t* qkv, int ld, const bf16_t* dout, int ld_do,
                                                        const float* S_all, bf16_t* dqkv, int ld_dq, float* dS_part) {
     // wave-private: dU hi and lo images [32 tokens][64 c'] bf16 (128-B rows) + q image [32 tokens][32 c] bf16 (64-B rows)
-    __shared__ __attribute__((aligned(16))) char lds[4 * (2 * 4096 + 2048) + 4 * 6 * 64 * 16];
+    // (the workgroup's final reduction reuses the images' bytes: 40 KB instead of 64 KB per workgroup = three workgroups per CU
+    //  instead of two for a kernel that waits on memory)
+    __shared__ __attribute__((aligned(16))) char lds[4 * (2 * 4096 + 2048)];
+    static_assert(4 * 6 * 64 * 16 <= 4 * (2 * 4096 + 2048), "reduction slab must fit in the images");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int cx, h, b;
     xcd_contiguous3(cx, h, b);                  // chunks of a head, then the next head, on one XCD
@@ -384,7 +387,8 @@ __global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // workgroup partial: sum the 4 waves in LDS (fixed order), write slab [33][32]
-    float* red = reinterpret_cast<float*>(lds + 4 * 10240);
+    __syncthreads();                            // every wave is done with its images: their bytes become the reduction slab
+    float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
