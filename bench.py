@@ -621,7 +621,10 @@ def main():
             alg_bytes = sum(t[4] for t in timer if len(t) > 4) / max(1, sum(1 for t in timer if len(t) > 4))
             res["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel / gemm_bf16_kernel (NT/NN/TN, all epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE: requests of the L2s to the fabric -- "
+                                               "re-reads served by the 256 MB Infinity Cache are counted, so this bounds the HBM "
+                                               "bytes from above; DESIGN.md section 14, item 6b)",
                                "traffic_source": traffic_src, "algorithmic_operand_bytes_per_launch": alg_bytes,
                                "mode": f"serialized-stream pass of {args.roofline_steps} steps after the timed region",
                                "launches": len(timer), "avg_launch_us": 1e3 * gms / len(timer),
