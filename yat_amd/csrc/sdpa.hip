@@ -1001,6 +1001,9 @@ int launch_dq_qs(const SdpaP& p, int B, hipStream_t stream) {
 }
 template <int KS, int DT>
 int launch_dq(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    if constexpr (KS <= 2) {
+        if (wide == 2) return launch_dq_qs<KS, DT, 3>(p, B, stream);          // 192-query workgroups (dh <= 64)
+    }
     return wide ? launch_dq_qs<KS, DT, 2>(p, B, stream) : launch_dq_qs<KS, DT, 1>(p, B, stream);
 }
 template <int KS, int DT, int KB, int NW>
@@ -1095,7 +1098,9 @@ int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     if (parts & 1) {                               // dQ, and delta = rowsum(dO * O) which the dK/dV part reads
         // (three sub-tiles per wave with the key tile walked in halves fit -- 254 registers at dh 72 -- but measured only
         //  -2.4 % at N = T = 4096 and +5 % on the T = 300 cross-attention: not instantiated)
-        const int wide = wide_env >= 0 ? (wide_env != 0) : ((int64_t)((N + 127) / 128) * H * B >= 1024);
+        int wide = wide_env >= 0 ? wide_env : ((int64_t)((N + 127) / 128) * H * B >= 1024);
+        static const int dq3 = YAT_TUNE_INT("YAT_SDPA_DQ3", 0);
+        if (dq3 && wide_env < 0 && dh <= 64 && (int64_t)((N + 191) / 192) * H * B >= 1024) wide = 2;
         const int rc = YAT_SDPA_DISPATCH(launch_dq, dh, p, B, wide, (hipStream_t)stream);
         if (rc != YAT_OK) return rc;
     }
