@@ -1099,7 +1099,7 @@ int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
         // (three sub-tiles per wave with the key tile walked in halves fit -- 254 registers at dh 72 -- but measured only
         //  -2.4 % at N = T = 4096 and +5 % on the T = 300 cross-attention: not instantiated)
         int wide = wide_env >= 0 ? wide_env : ((int64_t)((N + 127) / 128) * H * B >= 1024);
-        static const int dq3 = YAT_TUNE_INT("YAT_SDPA_DQ3", 0);
+        static const int dq3 = YAT_TUNE_INT("YAT_SDPA_DQ3", 1);      // dh 64, L = 4429: 1524 -> 1421 us (profiles/r03_f)
         if (dq3 && wide_env < 0 && dh <= 64 && (int64_t)((N + 191) / 192) * H * B >= 1024) wide = 2;
         const int rc = YAT_SDPA_DISPATCH(launch_dq, dh, p, B, wide, (hipStream_t)stream);
         if (rc != YAT_OK) return rc;
