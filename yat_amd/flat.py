@@ -135,6 +135,8 @@ class FlatParamModule(nn.Module):
             if t is not None:
                 self._plans.clear()       # a buffer moves: every recorded plan may hold its old address
             t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+            if os.environ.get("YAT_ARENA_FILL") and t.is_floating_point():      # diagnostic runs that skip kernels (ops.ABLATE):
+                t.normal_(0.0, 0.5)                                             # realistic operand statistics, no NaNs
             self._arena[name] = t
         return t[:n].view(shape)
 
