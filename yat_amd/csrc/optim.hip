@@ -82,29 +82,64 @@ __device__ __forceinline__ void adamw_elem(float& pr, float g, float& mr_, float
     vr_ = vr;
 }
 
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(int64_t nvec, bf16_t* p, bf16_t* g, bf16_t* m, bf16_t* v,
                                                     const float* clip_coef, bf16_t* ema, AdamP a) {
+    // U vectors of 8 parameters per thread and iteration, every load of the iteration issued before the first use (4 U
+    // independent 16-byte loads in flight per lane); NT: the state streams through once per step -- non-temporal accesses
+    // keep 22 GB of it from evicting what the forward that runs beside this kernel re-reads.
     const float coef = clip_coef ? clip_coef[0] : 1.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        float pp[8], gg[8], mm[8], vv[8], ss[8];
-        unpack8(*reinterpret_cast<const u32x4*>(p + i * 8), pp);
-        unpack8(*reinterpret_cast<const u32x4*>(g + i * 8), gg);
-        unpack8(*reinterpret_cast<const u32x4*>(m + i * 8), mm);
-        unpack8(*reinterpret_cast<const u32x4*>(v + i * 8), vv);
-        if (ema) unpack8(*reinterpret_cast<const u32x4*>(ema + i * 8), ss);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += stride * U) {
+        u32x4 rp[U], rg[U], rm[U], rv[U], rs[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            adamw_elem(pp[e], gg[e], mm[e], vv[e], coef, clip_coef != nullptr, a);
-            if (ema) {                                                  // s.sub_(one_minus_decay * (s - p))
-                const float d = rbf(ss[e] - pp[e]);
-                ss[e] = rbf(ss[e] - rbf(a.ema_omd * d));
+        for (int q = 0; q < U; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < nvec) {
+                if (NT) {
+                    rp[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + i * 8));
+                    rg[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(g + i * 8));
+                    rm[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(m + i * 8));
+                    rv[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(v + i * 8));
+                } else {
+                    rp[q] = *reinterpret_cast<const u32x4*>(p + i * 8);
+                    rg[q] = *reinterpret_cast<const u32x4*>(g + i * 8);
+                    rm[q] = *reinterpret_cast<const u32x4*>(m + i * 8);
+                    rv[q] = *reinterpret_cast<const u32x4*>(v + i * 8);
+                }
+                if (ema) rs[q] = *reinterpret_cast<const u32x4*>(ema + i * 8);
             }
         }
-        *reinterpret_cast<u32x4*>(p + i * 8) = pack8(pp);
-        *reinterpret_cast<u32x4*>(m + i * 8) = pack8(mm);
-        *reinterpret_cast<u32x4*>(v + i * 8) = pack8(vv);
-        if (ema) *reinterpret_cast<u32x4*>(ema + i * 8) = pack8(ss);
-        if (a.zero_grad) *reinterpret_cast<u32x4*>(g + i * 8) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i >= nvec) continue;
+            float pp[8], gg[8], mm[8], vv[8], ss[8];
+            unpack8(rp[q], pp);
+            unpack8(rg[q], gg);
+            unpack8(rm[q], mm);
+            unpack8(rv[q], vv);
+            if (ema) unpack8(rs[q], ss);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                adamw_elem(pp[e], gg[e], mm[e], vv[e], coef, clip_coef != nullptr, a);
+                if (ema) {                                                  // s.sub_(one_minus_decay * (s - p))
+                    const float d = rbf(ss[e] - pp[e]);
+                    ss[e] = rbf(ss[e] - rbf(a.ema_omd * d));
+                }
+            }
+            if (NT) {
+                __builtin_nontemporal_store(pack8(pp), reinterpret_cast<u32x4*>(p + i * 8));
+                __builtin_nontemporal_store(pack8(mm), reinterpret_cast<u32x4*>(m + i * 8));
+                __builtin_nontemporal_store(pack8(vv), reinterpret_cast<u32x4*>(v + i * 8));
+            } else {
+                *reinterpret_cast<u32x4*>(p + i * 8) = pack8(pp);
+                *reinterpret_cast<u32x4*>(m + i * 8) = pack8(mm);
+                *reinterpret_cast<u32x4*>(v + i * 8) = pack8(vv);
+            }
+            if (ema) *reinterpret_cast<u32x4*>(ema + i * 8) = pack8(ss);
+            if (a.zero_grad) *reinterpret_cast<u32x4*>(g + i * 8) = u32x4{0u, 0u, 0u, 0u};
+        }
     }
 }
 
@@ -189,10 +224,19 @@ int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_
         return YAT_OK;
     }
     const int64_t nvec = n >> 3;
-    int64_t nb = (nvec + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, nvec, (bf16_t*)param,
-                       (bf16_t*)grad, (bf16_t*)exp_avg, (bf16_t*)exp_avg_sq, clip_coef, (bf16_t*)ema_shadow, a);
+    static const int variant = YAT_TUNE_INT("YAT_ADAMW_VARIANT", 0);      // 0: one vector per iteration; 1: two; 2: two, non-temporal; 3: one, non-temporal
+    static const int max_blocks = YAT_TUNE_INT("YAT_ADAMW_BLOCKS", 8192);
+    const int U = (variant == 1 || variant == 2) ? 2 : 1;
+    int64_t nb = (nvec + 256 * U - 1) / (256 * U);
+    if (nb > max_blocks) nb = max_blocks;
+#define YAT_ADAMW_LAUNCH(UU, NTT)                                                                                            \
+    hipLaunchKernelGGL((adamw_kernel<UU, NTT>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, nvec, (bf16_t*)param, \
+                       (bf16_t*)grad, (bf16_t*)exp_avg, (bf16_t*)exp_avg_sq, clip_coef, (bf16_t*)ema_shadow, a)
+    if (variant == 1) YAT_ADAMW_LAUNCH(2, false);
+    else if (variant == 2) YAT_ADAMW_LAUNCH(2, true);
+    else if (variant == 3) YAT_ADAMW_LAUNCH(1, true);
+    else YAT_ADAMW_LAUNCH(1, false);
+#undef YAT_ADAMW_LAUNCH
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
