@@ -20,4 +20,4 @@ e0.record()
 for s in range(3, 9): run(s)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 6
-print(f"adamw variant {os.environ.get('YAT_ADAMW_VARIANT', '0')} blocks {os.environ.get('YAT_ADAMW_BLOCKS', '8192')}: {ms:.3f} ms  {14.0 * n / ms / 1e9:.0f} GB/s  checksum {p.float().sum().item():.4f}")
+print(f"adamw variant {os.environ.get('YAT_ADAMW_VARIANT', '0')} blocks {os.environ.get('YAT_ADAMW_BLOCKS', '8192')}: {ms:.3f} ms  {14.0 * n / ms / 1e6:.0f} GB/s  checksum {p.float().sum().item():.4f}")

@@ -142,34 +142,59 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_rows_kernel(int M, int D, int 
     }
 }
 
-// grid = (ceil(D/512), ceil(rpb/128), B); partial rows ws[(b*ngroups + rg)][2][D]
+// grid = (ceil(D/512), ceil(rpb / (WAVES * LN_COL_ROWS)), B); one partial row per workgroup: ws[(b*gridDim.y + by)][2][D].
+// Eight rows' loads (x, dy, mean, rstd) are issued before the first use: with one row in flight per wave the 1280 waves of
+// a 8192 x 2240 gradient kept 2.6 MB in flight, a quarter of what the HBM pipe needs (3.7 TB/s measured).
+constexpr int LN_COL_ROWS = 16;
 __global__ __launch_bounds__(256) void ln_mod_bwd_cols_kernel(int rpb, int D, const bf16_t* x, const float* mean_in,
                                                               const float* rstd_in, const bf16_t* dy, float* ws) {
+    __shared__ float red[2 * WAVES * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 512 + lane * 8;
     const int b = blockIdx.z;
-    const int rg = blockIdx.y * WAVES + wave, ngroups = gridDim.y * WAVES;
-    if (c0 >= D) return;
+    const int rg = blockIdx.y * WAVES + wave;
     float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int rr = 0; rr < 32; ++rr) {
-        const int rl = rg * 32 + rr;
-        if (rl >= rpb) break;
-        const int64_t row = (int64_t)b * rpb + rl;
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float xv[8], gv[8];
-        unpack8(*reinterpret_cast<const u32x4*>(x + row * D + c0), xv);
-        unpack8(*reinterpret_cast<const u32x4*>(dy + row * D + c0), gv);
+    if (c0 < D) {
+        for (int r0 = 0; r0 < LN_COL_ROWS; r0 += 8) {
+            u32x4 vx[8], vg[8];
+            float mean[8], rstd[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a1[e] += gv[e];
-            a2[e] += gv[e] * rbf((xv[e] - mean) * rstd);
+            for (int q = 0; q < 8; ++q) {
+                const int rl = rg * LN_COL_ROWS + r0 + q;
+                const bool in = rl < rpb;
+                const int64_t row = (int64_t)b * rpb + (in ? rl : 0);
+                vx[q] = *reinterpret_cast<const u32x4*>(x + row * D + c0);
+                vg[q] = in ? *reinterpret_cast<const u32x4*>(dy + row * D + c0) : u32x4{0u, 0u, 0u, 0u};
+                mean[q] = mean_in[row];
+                rstd[q] = rstd_in[row];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float xv[8], gv[8];
+                unpack8(vx[q], xv);
+                unpack8(vg[q], gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a1[e] += gv[e];
+                    a2[e] += gv[e] * rbf((xv[e] - mean[q]) * rstd[q]);
+                }
+            }
         }
     }
-    float* wp = ws + ((int64_t)b * ngroups + rg) * 2 * D + c0;
-    *reinterpret_cast<f32x4*>(wp) = f32x4{a1[0], a1[1], a1[2], a1[3]};
-    *reinterpret_cast<f32x4*>(wp + 4) = f32x4{a1[4], a1[5], a1[6], a1[7]};
-    *reinterpret_cast<f32x4*>(wp + D) = f32x4{a2[0], a2[1], a2[2], a2[3]};
-    *reinterpret_cast<f32x4*>(wp + D + 4) = f32x4{a2[4], a2[5], a2[6], a2[7]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[wave * 512 + lane * 8 + e] = a1[e];
+        red[(WAVES + wave) * 512 + lane * 8 + e] = a2[e];
+    }
+    __syncthreads();
+    float* wp = ws + ((int64_t)b * gridDim.y + blockIdx.y) * 2 * D;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int cl = threadIdx.x + 256 * k, c = blockIdx.x * 512 + cl;
+        if (c >= D) continue;
+        wp[c] = red[cl] + red[512 + cl] + red[1024 + cl] + red[1536 + cl];
+        wp[D + c] = red[2048 + cl] + red[2560 + cl] + red[3072 + cl] + red[3584 + cl];
+    }
 }
 
 // Partial-row reductions: a 256-thread block owns 64 columns; 4 thread rows split the G partial rows and meet in LDS
@@ -295,7 +320,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int M, int D, const bf
 }
 
 // ------------------------------------------------------------------ strip kernels (512 columns x 32 rows per wave)
-constexpr int STRIP_ROWS = 32;
+constexpr int STRIP_ROWS = 32;            // rows per wave of the column sum
+constexpr int GATE_ROWS = 16;             // ... of the gate backward (three streams per row: twice the workgroups)
 // MODE 0: column sum of x.  MODE 1: gate backward: dlin = bf16(gate*dout), partial = dout*lin, and (ws2 != null) the
 // column sum of dlin, i.e. the bias gradient of the gated Linear, for free.
 // The four waves of a workgroup are summed in LDS: one partial row per workgroup (the follow-up reduction reads 4x less).
@@ -309,6 +335,7 @@ __global__ __launch_bounds__(256) void strip_kernel(int rows_per_batch, int cols
     const int c0 = blockIdx.x * 512 + lane * 8;
     const int b = blockIdx.z;
     const int rg = blockIdx.y * WAVES + wave;                 // row group within the batch
+    constexpr int SR = MODE == 1 ? GATE_ROWS : STRIP_ROWS;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float g[8];
     if (MODE == 1 && c0 < cols) unpack8(*reinterpret_cast<const u32x4*>(gate + (int64_t)b * gate_ld + c0), g);
@@ -333,18 +360,25 @@ __global__ __launch_bounds__(256) void strip_kernel(int rows_per_batch, int cols
             }
         }
     } else if (c0 < cols) {
-        for (int rr = 0; rr < STRIP_ROWS; ++rr) {
-            const int rl = rg * STRIP_ROWS + rr;
-            if (rl >= rows_per_batch) break;
-            const int64_t row = (int64_t)b * rows_per_batch + rl;
-            float a[8];
-            unpack8(*reinterpret_cast<const u32x4*>(x + row * ld + c0), a);
-            if (MODE == 0) {
+        // gate backward: the same eight-rows-in-flight shape (x and lin: 16 loads per lane before the first multiply)
+        for (int r0 = 0; r0 < SR; r0 += 8) {
+            u32x4 va[8], vl[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += a[e];
-            } else {
-                float l[8], o[8];
-                unpack8(*reinterpret_cast<const u32x4*>(lin + row * ld + c0), l);
+            for (int q = 0; q < 8; ++q) {
+                const int rl = rg * SR + r0 + q;
+                const int64_t row = (int64_t)b * rows_per_batch + rl;
+                const bool in = rl < rows_per_batch;
+                va[q] = in ? *reinterpret_cast<const u32x4*>(x + row * ld + c0) : u32x4{0u, 0u, 0u, 0u};
+                vl[q] = in ? *reinterpret_cast<const u32x4*>(lin + row * ld + c0) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int rl = rg * SR + r0 + q;
+                if (rl >= rows_per_batch) continue;
+                const int64_t row = (int64_t)b * rows_per_batch + rl;
+                float a[8], l[8], o[8];
+                unpack8(va[q], a);
+                unpack8(vl[q], l);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { acc[e] += rbf(a[e] * l[e]); o[e] = rbf(g[e] * a[e]); acc2[e] += o[e]; }
                 *reinterpret_cast<u32x4*>(dlin + row * ld + c0) = pack8(o);
@@ -434,8 +468,8 @@ int yat_ln_modulate_fwd(int M, int D, int rpb, float eps, const void* x, const v
 
 uint64_t yat_ln_bwd_workspace_bytes(int M, int D, int rpb) {
     if (M <= 0 || rpb <= 0) return 0;
-    const uint64_t gy = (rpb + WAVES * 32 - 1) / (WAVES * 32);
-    return (uint64_t)(M / rpb) * gy * WAVES * 2 * D * sizeof(float);
+    const uint64_t gy = (rpb + WAVES * LN_COL_ROWS - 1) / (WAVES * LN_COL_ROWS);
+    return (uint64_t)(M / rpb) * gy * 2 * D * sizeof(float);
 }
 
 int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean, const float* rstd, const void* scale,
@@ -454,11 +488,11 @@ int yat_ln_modulate_bwd(int M, int D, int rpb, const void* x, const float* mean,
         return YAT_OK;
     });
     if (rc || !(parts & 2)) return rc;
-    const int gy = (rpb + WAVES * 32 - 1) / (WAVES * 32);
+    const int gy = (rpb + WAVES * LN_COL_ROWS - 1) / (WAVES * LN_COL_ROWS);
     hipLaunchKernelGGL(ln_mod_bwd_cols_kernel, dim3((D + 511) / 512, gy, B), dim3(256), 0, (hipStream_t)stream, rpb, D,
                        (const bf16_t*)x, mean, rstd, (const bf16_t*)dy, (float*)workspace);
     YAT_CHECK_LAUNCH();
-    const int W = 2 * D, G = gy * WAVES;
+    const int W = 2 * D, G = gy;
     hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((W + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, B, G, W,
                        (const float*)workspace, dshift_acc, dscale_acc, D, acc_ld);
     YAT_CHECK_LAUNCH();
@@ -520,7 +554,7 @@ int yat_colsum_bf16(int rows, int cols, const void* x, int ld, void* out, int ac
 
 uint64_t yat_gate_bwd_workspace_bytes(int M, int D, int rpb) {
     if (M <= 0 || rpb <= 0) return 0;
-    const uint64_t gy = (rpb + WAVES * STRIP_ROWS - 1) / (WAVES * STRIP_ROWS);
+    const uint64_t gy = (rpb + WAVES * GATE_ROWS - 1) / (WAVES * GATE_ROWS);
     return 2 * (uint64_t)(M / rpb) * gy * D * sizeof(float);        // gate partials + bias-gradient partials
 }
 
@@ -530,7 +564,7 @@ int yat_gate_bwd(int M, int D, int rpb, const void* dout, const void* lin, const
         !workspace)
         return YAT_EINVAL;
     const int B = M / rpb;
-    const int gy = (rpb + WAVES * STRIP_ROWS - 1) / (WAVES * STRIP_ROWS);
+    const int gy = (rpb + WAVES * GATE_ROWS - 1) / (WAVES * GATE_ROWS);
     float* ws2 = dbias ? (float*)workspace + (int64_t)B * gy * D : nullptr;
     hipLaunchKernelGGL((strip_kernel<1>), dim3((D + 511) / 512, gy, B), dim3(256), 0, (hipStream_t)stream, rpb, D,
                        (const bf16_t*)dout, D, (const bf16_t*)lin, (const bf16_t*)gate, gate_ld, (bf16_t*)dlin,
