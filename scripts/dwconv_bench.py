@@ -34,6 +34,9 @@ for (h, w) in ((32, 32), (16, 64), (24, 42), (44, 22)):
     dzs = torch.empty(2 * Hc, dtype=BF, device=dev)
     fu = timeit(lambda: ops.dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y, u_out=u))       # the step's configuration: keeps u
     b2 = timeit(lambda: ops.dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, None, dz, dw, db, ws, dz_colsum=dzs, du=du))   # pass 2 only
+    import hashlib
+    hsh = hashlib.sha1(y.view(torch.int16).cpu().numpy().tobytes() + u.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:12]
+    print(f"dwconv {h:2d}x{w:2d}: sha1(y,u)={hsh}")
     print(f"dwconv {h:2d}x{w:2d}: in-step config  fwd+u={fu:7.1f}us ({(M * 2 * Hc * 2 + M * Hc) * 2 / fu / 1e6:5.2f} TB/s)  "
           f"bwd2(du given)={b2:7.1f}us ({(M * 2 * Hc * 4) * 2 / b2 / 1e6:5.2f} TB/s)", flush=True)
     f = timeit(lambda: ops.dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y))

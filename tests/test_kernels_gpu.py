@@ -574,8 +574,10 @@ def _glu_ref(z, wdw, bdw, B, h, w, Hc):
 
 
 # the last two cases take the direct (non-tiled) kernels: w > 64, and a channel count that is not a multiple of 8
+# (the streaming forward takes the shapes whose rows fill its 16 run slots: 5x9, 32x32, 7x20, 9x16, 10x8, 31x30)
 @pytest.mark.parametrize("B,h,w,Hc", [(2, 4, 4, 16), (2, 5, 9, 40), (1, 16, 64, 160), (2, 33, 3, 8), (2, 32, 32, 72),
-                                      (1, 3, 70, 8), (1, 6, 5, 12)])
+                                      (1, 3, 70, 8), (1, 6, 5, 12), (1, 7, 20, 40), (2, 9, 16, 64), (1, 10, 8, 24),
+                                      (3, 31, 30, 136)])
 def test_dwconv_glu_fwd_bwd(ops, B, h, w, Hc):
     M = B * h * w
     z = rnd(M, 2 * Hc, seed=37)

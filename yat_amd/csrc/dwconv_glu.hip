@@ -208,6 +208,8 @@ int launch_tile_best(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t*
     static const int force = YAT_TUNE_INT("YAT_DW_VARIANT", 0);     // 1: v32w3, 2: v64w3, 3: v64w2
     int v = MODE == 0 ? (w > 48 ? 3 : 2) : 1;
     if (force) v = force;
+    static const int stream_on = YAT_TUNE_INT("YAT_DW_STREAM", 1);
+    if (MODE == 0 && stream_on && v64w3::launch_stream(B, h, w, Hc, s, wdw, bdw, out, u_out, stream) == 0) return 0;
     if (v == 3 && v64w2::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream) == 0) return 0;
     if (v >= 2 && v64w3::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream) == 0) return 0;
     return v32w3::launch_tile<MODE>(B, h, w, Hc, s, wdw, bdw, dy, out, u_out, stream);
