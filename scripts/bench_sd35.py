@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--gemm-detail", default=None)
+    ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile of four steps enqueued onto an idle GPU")
     ap.add_argument("--roofline-steps", type=int, default=2)
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -116,6 +117,19 @@ def main():
     torch.cuda.synchronize()
     log(f"host enqueue of one step onto an idle GPU: {min(host_ms):.1f} ms (per bucket: {', '.join(f'{v:.1f}' for v in host_ms)}; "
         f"launch plans {'on' if model.use_plans else 'off'}, {getattr(model, 'plan_replays', 0)} replays)")
+
+    if args.host_profile:
+        import cProfile, pstats, io
+        pr = cProfile.Profile()
+        for i in range(len(BUCKETS)):
+            torch.cuda.synchronize()
+            pr.enable()
+            step(args.warmup + args.steps + i)
+            pr.disable()
+        torch.cuda.synchronize()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(35)
+        open(args.host_profile, "w").write(buf.getvalue())
 
     # serialized pass for the per-launch GEMM figure
     saved = (model.side_wgrad, opt.overlap_update, model.fwd_chains)
