@@ -13,6 +13,8 @@
 //    so each tap is applied exactly once and nothing is shuffled between registers.  Measured (B=8, 32x32, Hc=5600):
 //    forward ~89 us, backward ~350 us; PMC shows the forward at ~75 % VALU utilisation (unpack + FMA + SiLU), i.e. these
 //    are VALU-bound at ~3 TB/s of algorithmic traffic, not HBM-bound.
+//  * a streaming forward (dwglu_stream_kernel, dwconv_tile_fwd.inc) for the shapes whose rows fill its 16 run slots (32 x 32):
+//    ring of 2R+2 tile rows, the next R rows' LDS-DMA under the current rows' arithmetic; same tap order -> same bits.
 //  * direct kernels (dwconv_glu_kernel<0/1>, dwconv_bwd2_kernel) for wider images: lanes along channels (8 B per lane),
 //    one guarded global load per (row, column, half), register double buffer.  ~25 % slower; kept as the general path.
 #include "common.hpp"
