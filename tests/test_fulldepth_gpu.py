@@ -43,7 +43,7 @@ def full_models():
 
 
 # Both bench buckets that differ in kind: the square 32 x 32 one and the non-square 24 x 42 one, two images of different text
-# length each (the CPU oracle's two passes over 1.6 B parameters are ~100 s of host time per case).
+# length each (the CPU oracle's two passes over 1.6 B parameters are ~25 s of host time per case on 16 cores).
 #
 # The HIP side runs the path the benchmark and the trainer run -- ``SanaRecipe.optimize_device``: one packed H2D, PACKED text
 # rows, launch plans on, two forward chains -- three times, so that what is compared with the oracle is a REPLAYED plan; then
