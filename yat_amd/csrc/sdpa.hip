@@ -382,184 +382,10 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     }
 }
 
-#ifdef YAT_SDPA_PIPE_EXPERIMENT     // measured slower (see the comment): kept out of the product build
-// ---- forward, long key loops without a bias (self-attention), SOFTWARE-PIPELINED: after the changes above the SQ counters
-// (profiles/r03_b_attention_sq_counters.txt) show the waves of the forward stalled on issue 41 % of their cycles
-// (SQ_WAIT_INST_ANY: the softmax waits for the Q K^T results, the P V product for the softmax) with the matrix pipe ~55 %
-// busy: inside one wave the three phases of a tile are a dependent chain, and two waves per SIMD do not cover it.  Here the
-// Q K^T product of tile t+1 is issued in the same straight-line block as the exponentials of tile t (independent work for the
-// scheduler to interleave), at the price of a second set of score registers.  K and V tiles therefore live in separate
-// double buffers: iteration t reads K(t+1) and V(t), while K(t+2) and V(t+1) are in flight -- same LDS, same one barrier per
-// tile.  The loop body exists twice (even / odd tile), so every LDS offset is an immediate and the two score sets swap roles
-// without copies.  The product for the tile past the last one runs on whatever the K slot holds and is never read.
-template <int KS, int DT, int QS>
-__global__ __launch_bounds__(256) void sdpa_fwd_pipe_kernel(SdpaP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KSLOT = TILE, VBASE = 2 * TILE, VSLOT = TILE;       // [K0 | K1 | V0 | V1]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, li = lane & 15;
-    int bx, h, b;
-    if (p.xcd_remap) xcd_contiguous3(bx, h, b);
-    else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
-    const int q0 = bx * (64 * QS) + wave * (16 * QS);
-    const int T = p.T;
-    const int col0 = h * p.dh;
-    const int64_t kvr0 = (int64_t)b * T, kvrl = kvr0 + T;
-    const TileSrc<> src_k = tile_src<IMG_ROW>(p.ldkv, p.dh, wave, lane);
-    TileSrc<> src_v = tile_src<IMG_TR>(p.ldkv, p.dh, wave, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                   // column dh of both V slots = 1.0, never touched by the DMA (ONES above)
-        const int piece = j * 4 + wave, r = piece * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ ((r & 7) << 1);
-        if (chunk * 8 == p.dh) {
-            src_v.voff[j] = YAT_SKIP;
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-                *reinterpret_cast<u32x4*>(smem + VBASE + st * VSLOT + piece * 1024 + lane * 16) = u32x4{0x3F80u, 0u, 0u, 0u};
-        }
-    }
-    auto stage_k = [&](int t, int slot) {
-        stage_tile(tile_rsrc(p.k, kvr0 + 64 * t, kvrl, p.ldkv, col0), smem + slot * KSLOT, src_k, wave);
-    };
-    auto stage_v = [&](int t, int slot) {
-        const __amdgpu_buffer_rsrc_t rv = tile_rsrc(p.v, kvr0 + 64 * t, kvrl, p.ldkv, col0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (src_v.voff[j] != YAT_SKIP)
-                lds_dma16(rv, (YAT_LDS void*)(smem + VBASE + slot * VSLOT + (j * 4 + wave) * 1024), src_v.voff[j]);
-    };
-    const int nt = (T + 63) / 64;
-    stage_k(0, 0);
-    stage_v(0, 0);
-
-    bf16x8 qf[QS][KS];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[qs][ks] = frag_global(p.q, (int64_t)b * p.N + q0 + qs * 16 + li, (int64_t)b * p.N + p.N, p.ldq, col0, p.dh, ks, lane);
-    f32x4 o[QS][DT];
-    float m[QS];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m[qs] = -1e30f;
-    }
-    const float ce = p.scale * LOG2E;
-    const float lazy = LAZY_LOG2 / ce;
-
-    auto qk = [&](const char* Ks, f32x4 (&s)[QS][4]) {
-#pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-#pragma unroll
-            for (int qs = 0; qs < QS; ++qs) s[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kfrag = frag_row(Ks, nj * 16, ks, lane);
-#pragma unroll
-                for (int qs = 0; qs < QS; ++qs) s[qs][nj] = mfma16(kfrag, qf[qs][ks], s[qs][nj]);
-            }
-        }
-    };
-    // one tile: `s` holds Q K(t)^T; leaves Q K(t+1)^T in `sn`.  PAR = t & 1 (compile time: LDS slots are immediates).
-    auto tile = [&](auto par, int t, f32x4 (&s)[QS][4], f32x4 (&sn)[QS][4]) {
-        constexpr int PAR = decltype(par)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // K(t+1), V(t) landed for every wave; K slot PAR and V slot PAR^1 are free
-        if (t + 2 < nt) stage_k(t + 2, PAR);
-        if (t + 1 < nt) stage_v(t + 1, PAR ^ 1);
-        const int k0 = 64 * t;
-        if (k0 + 64 > T) {                     // uniform: keys past T in the last tile vanish from the softmax
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k0 + nj * 16 + 4 * g + r >= T)
-#pragma unroll
-                        for (int qs = 0; qs < QS; ++qs) s[qs][nj][r] = -1e30f;
-        }
-        float mx[QS];
-        bool grow = false;
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            float tmax = -1e30f;
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[qs][nj][r]);
-            mx[qs] = group_max_swap(tmax);
-            grow |= mx[qs] > m[qs] + lazy;
-        }
-        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
-#pragma unroll
-            for (int qs = 0; qs < QS; ++qs) {
-                const float mn = fmaxf(m[qs], mx[qs]);
-                const float alpha = __builtin_amdgcn_exp2f((m[qs] - mn) * ce);
-                m[qs] = mn;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qs][dt][r] *= alpha;
-            }
-        }
-        // ---- one straight-line block from here: next tile's Q K^T (matrix pipe) beside this tile's exponentials (vector)
-        qk(smem + (PAR ^ 1) * KSLOT, sn);
-        bf16x8 pf0[QS], pf1[QS];
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            const float nm2 = -m[qs] * ce;
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[qs][nj][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qs][nj][r], ce, nm2));
-            pf0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
-            pf1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
-        }
-        const char* Vs = smem + VBASE + PAR * VSLOT;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 v0 = frag_tr_acc(Vs, 0, dt * 16, lane), v1 = frag_tr_acc(Vs, 32, dt * 16, lane);
-#pragma unroll
-            for (int qs = 0; qs < QS; ++qs) {
-                o[qs][dt] = mfma16(v0, pf0[qs], o[qs][dt]);
-                o[qs][dt] = mfma16(v1, pf1[qs], o[qs][dt]);
-            }
-        }
-    };
-
-    f32x4 sa[QS][4], sb[QS][4];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                           // K(0) (and V(0)) landed
-    if (nt > 1) stage_k(1, 1);
-    qk(smem, sa);
-    for (int t = 0; t < nt; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t, sa, sb);
-        if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1, sb, sa);
-    }
-    const int dc = p.dh - (DT - 1) * 16;       // the row sum: accumulator of output column dh
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-        const f32x4 tt = o[qs][DT - 1];
-        const float mine = (dc & 3) == 0 ? tt[0] : (dc & 3) == 1 ? tt[1] : (dc & 3) == 2 ? tt[2] : tt[3];
-        const float l = __shfl(mine, (dc >> 2) * 16 + li, 64);
-        const int qi = q0 + qs * 16 + li;
-        if (qi < p.N) {
-            const float inv = 1.0f / l;
-            bf16_t* op = p.out + ((int64_t)b * p.N + qi) * p.ldo + col0;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = dt * 16 + 4 * g;
-                if (d < p.dh)
-                    *reinterpret_cast<u32x2*>(op + d) =
-                        pack4(o[qs][dt][0] * inv, o[qs][dt][1] * inv, o[qs][dt][2] * inv, o[qs][dt][3] * inv);
-            }
-            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m[qs] * p.scale + __logf(l);
-        }
-    }
-}
-
-#endif  // YAT_SDPA_PIPE_EXPERIMENT
+// (A software-pipelined forward for the long no-bias key loops -- the Q K^T product of tile t+1 issued beside the exponentials
+// of tile t, K and V in separate double buffers, the loop body twice so that every LDS offset is an immediate -- was built and
+// measured in round 3 and was not faster than the kernel above with 256-query workgroups; DESIGN.md section 10.  It lived here
+// behind a macro until the end of round 3 (git history: 6014b8f .. 68ea669); removed rather than kept as dead code.)
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 // Stage = K (TR-swizzled image: read row-wise for S = Q K^T and transposed for dQ = dS K), V (ROW image), key bias.
@@ -938,30 +764,8 @@ int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
-#ifdef YAT_SDPA_PIPE_EXPERIMENT
-template <int KS, int DT, int QS>
-int launch_fwd_pipe(const SdpaP& p, int B, hipStream_t stream) {
-    constexpr int LDS = 4 * TILE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<KS, DT, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess)
-            return YAT_EINVAL;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<KS, DT, QS>), dim3((p.N + 64 * QS - 1) / (64 * QS), p.H, B), dim3(256), LDS, stream, p);
-    YAT_CHECK_LAUNCH();
-    return YAT_OK;
-}
-#endif
 template <int KS, int DT, bool NOBIAS, bool ONES>
 int launch_fwd_x(const SdpaP& p, int B, int wide, hipStream_t stream) {
-#ifdef YAT_SDPA_PIPE_EXPERIMENT
-    if constexpr (NOBIAS && ONES && KS <= 3) {
-        if (p.T >= 1024 && wide)                                  // long key loops: the software-pipelined forward
-            return wide == 2 ? launch_fwd_pipe<KS, DT, 3>(p, B, stream) : launch_fwd_pipe<KS, DT, 2>(p, B, stream);
-    }
-#endif
     if constexpr (NOBIAS && ONES && KS <= 3) {
         if (wide == 3) return launch_fwd_qs<KS, DT, 4, NOBIAS, ONES>(p, B, stream);      // 256-query workgroups
     }
