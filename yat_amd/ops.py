@@ -73,6 +73,10 @@ RECORDER = None
 # step time is read -- to see how much of the step each family's chip time is worth on this schedule (a kernel made x us
 # faster alone buys anything between 0 and x in the step: they run beside GEMMs of another stream).  Never set in a product run.
 ABLATE = frozenset(x for x in os.environ.get("YAT_ABLATE", "").split(",") if x)
+if ABLATE:
+    import sys as _sys
+    print(f"[yat_amd] YAT_ABLATE={','.join(sorted(ABLATE))}: these kernel families are SKIPPED -- results are wrong, timing diagnostic only",
+          file=_sys.stderr, flush=True)
 
 # Packed text rows (yat_amd/sana.py forward_impl, kv_off): the number of text rows changes from batch to batch, and a launch
 # plan must not be keyed by it (every new (bucket, row count) pair would be a fresh recording).  Inside ``with
