@@ -30,6 +30,7 @@ def _ddp_worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from yat_amd.ddp import HipDDP
+    from yat_amd.common.trainer import HipAccelerator
     m = _FlatModel(100, [(0, 30), (30, 70), (70, 100)])
     m.flat_param += rank + 1
     ddp = HipDDP(m)
@@ -48,6 +49,7 @@ def _ddp_worker(rank, world, port, tmp):
     assert torch.all(m.flat_grad == rank)
     t = ddp.all_reduce_scalar_mean(torch.tensor([float(rank)]))
     assert t.item() == 0.5
+    assert ddp.carried_loss is None                           # a model without spare gradient elements: nothing rides along
 
     # the REAL model's flat layout and bucket order (built on the CPU: no kernel runs here): buckets complete last block
     # first, embedders last, exactly as backward_impl reports them; every bucket is reduced once, the tail of the last
@@ -72,6 +74,36 @@ def _ddp_worker(rank, world, port, tmp):
         assert torch.allclose(real.flat_grad, torch.arange(real.numel_flat, dtype=torch.float32) * (1.5 + step))
     assert ddp_real.bytes_reduced == 2 * real.numel_flat * 4
 
+    # the logged loss rides behind the top bucket (trainer.py:359's gather(avg_loss).mean() without its own collective):
+    # armed per micro-step by track_loss, reported by the model before its backward, harvested by wait()
+    from yat_amd.flat import GRAD_TAIL
+    store = torch.zeros(real.numel_flat + GRAD_TAIL)
+    real._grad_store, real.flat_grad, real.grad_tail = store, store[:real.numel_flat], store[real.numel_flat:]
+    ddp_l = HipDDP(real)
+    assert real.loss_ready is not None
+    for step, (acc, loss) in enumerate([(None, 0.25 + rank), (torch.tensor(1.0 + rank), 0.5)]):
+        real.flat_grad[:] = float(rank + 1)
+        ddp_l.track_loss(acc)
+        real.loss_ready(torch.tensor([loss]))                 # the device path's report (recipe._report_loss)
+        for i in (3, 2, 1, 0):
+            real.grad_ready(i)
+        ddp_l.wait()
+        want = [0.75, 2.0][step]                              # mean over ranks of (running sum + loss)
+        assert abs(ddp_l.carried_loss.item() - want) < 1e-6 and torch.all(real.flat_grad == 1.5)
+        assert torch.all(real.grad_tail == 0)
+        ddp_l.carried_loss = None
+    real.flat_grad[:] = 1.0                                   # not armed (bench.py): plain buckets, nothing carried
+    real.loss_ready(torch.tensor([3.0]))
+    for i in (3, 2, 1, 0):
+        real.grad_ready(i)
+    ddp_l.wait()
+    assert ddp_l.carried_loss is None and torch.all(real.grad_tail == 0)
+    acc2 = HipAccelerator(1, device="cpu")
+    acc2.ddp = ddp_l
+    ddp_l.carried_loss = torch.tensor(0.5)
+    assert acc2.mean_loss(torch.tensor(9.0)).item() == 0.5 and ddp_l.carried_loss is None
+    assert acc2.mean_loss(torch.tensor(float(rank))).item() == 0.5          # nothing carried: the gather of the reference
+
     # PEFT adapters under data parallel: the adapter set is the "model" HipDDP sees; its single bucket is reduced when
     # project() (the last thing the backward does) reports the gradients complete
     from yat_amd.lora import LoRAAdapters
@@ -95,7 +127,6 @@ def _ddp_worker(rank, world, port, tmp):
     from tests.test_host_logic import _make_shards
     from yat_amd.common.aspect_ratios import ASPECT_RATIO_1024_BIN
     from yat_amd.common.bucket_sampler import BucketSampler
-    from yat_amd.common.trainer import HipAccelerator
     import pathlib
     paths = _make_shards(pathlib.Path(tmp) / f"r{rank}", 2, 30, seed=rank)
     model = type("M", (), {"aspect_ratios": ASPECT_RATIO_1024_BIN})()

@@ -356,3 +356,43 @@ def test_ddp_diagnostic_modes_do_not_change_results(one_rank_group, transport):
     finally:
         if NativeComm._instance is not None:
             NativeComm.get().destroy()
+
+
+@pytest.mark.parametrize("transport", ["torch", "native"])
+def test_logged_loss_rides_with_the_top_bucket(one_rank_group, transport):
+    """common/trainer.py:359 gathers the averaged loss with a collective of its own every step; here the device path reports
+    its loss before the backward (recipe._report_loss -> HipDDP.on_loss) and it travels in the spare element behind the
+    gradients with the first bucket the backward completes.  Armed per micro-step (track_loss); unarmed steps (bench.py) are
+    byte-for-byte the plain buckets."""
+    from yat_amd.ddp import HipDDP, NativeComm
+    from yat_amd.flat import GRAD_TAIL
+    from yat_amd.recipe import SanaRecipe
+    model, cfg = _model()
+    recipe = SanaRecipe(model, pad_to=32, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    latents = (torch.randn(4, cfg.in_channels, 8, 12, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (7, 32, 1, 19)]
+    ddp = HipDDP(model, force=True, transport=transport)
+    try:
+        n = model.numel_flat
+        recipe.optimize_device(latents, embs, torch.Generator().manual_seed(1))
+        ddp.wait()
+        torch.cuda.synchronize()
+        assert ddp.carried_loss is None and ddp.bytes_reduced == 2 * n
+        plain = model.flat_grad.clone()
+        ddp.track_loss(torch.tensor(0.5, device=DEV))                  # the window's earlier micro-steps
+        loss = recipe.optimize_device(latents, embs, torch.Generator().manual_seed(1))
+        ddp.wait()
+        torch.cuda.synchronize()
+        want = (loss.float() + 0.5).to(BF).float().item()             # the slot has the gradient buffer's dtype
+        assert ddp.carried_loss.item() == want, (ddp.carried_loss.item(), want)
+        assert torch.equal(model.flat_grad, plain)                     # same draws, same gradients: the passenger disturbs nothing
+        assert ddp.bytes_reduced == 2 * (2 * n + GRAD_TAIL) and torch.all(model.grad_tail == 0)
+        ddp.carried_loss = None
+        recipe.optimize_device(latents, embs, torch.Generator().manual_seed(1))      # armed for ONE micro-step only
+        ddp.wait()
+        torch.cuda.synchronize()
+        assert ddp.carried_loss is None
+    finally:
+        if NativeComm._instance is not None:
+            NativeComm.get().destroy()

@@ -85,6 +85,8 @@ class HipAccelerator:
     def backward(self, loss):
         # a recipe's device path has already run the backward (scaled by 1 / gradient_accumulation_steps) inside optimize()
         if not getattr(loss, "yat_backward_done", False):
+            if self.ddp is not None and self.sync_gradients:
+                self.ddp.on_loss(loss)                   # (the device path reports it itself: model.loss_ready)
             (loss / self.gradient_accumulation_steps if self.gradient_accumulation_steps > 1 else loss).backward()
         if self.ddp is not None and self.sync_gradients:
             self.ddp.wait()
@@ -98,6 +100,19 @@ class HipAccelerator:
         out = [torch.empty_like(t) for _ in range(self.num_processes)]
         dist.all_gather(out, t)
         return torch.stack(out)
+
+    def track_loss(self, running_sum):
+        """Before a micro-step: let its loss (+ ``running_sum`` of the window's earlier ones) ride with the gradient
+        all-reduce instead of a collective of its own (yat_amd/ddp.py); ``mean_loss`` then needs no communication."""
+        if self.ddp is not None and self.num_processes > 1:
+            self.ddp.track_loss(running_sum)
+
+    def mean_loss(self, t):
+        """``accelerator.gather(avg_loss).mean()`` (common/trainer.py:359)."""
+        if self.ddp is not None and self.ddp.carried_loss is not None:
+            v, self.ddp.carried_loss = self.ddp.carried_loss, None
+            return v.to(t.dtype) if t.is_floating_point() else v
+        return self.gather(t).mean()
 
     def reduce(self, t, reduction="mean"):
         if self.num_processes > 1:
@@ -355,6 +370,7 @@ class Model:
                                 states.append(generator.get_state())
                                 losses.append(self.optimize(ratio, latents, embeddings, repa, generator))
                         generator.set_state(states[int(torch.argmin(torch.stack(losses)))])
+                    self.accelerator.track_loss(avg_loss)
                     loss = self.optimize(ratio, latents, embeddings, repa, generator)
                     avg_loss = avg_loss + loss.detach()
                     self.accelerator.backward(loss)
@@ -364,7 +380,7 @@ class Model:
                         if self.lr_scheduler is not None:
                             self.lr_scheduler.step()
                 if self.accelerator.sync_gradients:
-                    mean_loss = self.accelerator.gather(avg_loss).mean()
+                    mean_loss = self.accelerator.mean_loss(avg_loss)
                     avg_loss = torch.zeros((), device=dev)
                     self.loss_history.append(mean_loss)
                     if self.logger is not None and self.accelerator.is_main_process:

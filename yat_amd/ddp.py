@@ -112,6 +112,17 @@ class HipDDP:
         self.coalesce = max(1, int(os.environ.get("YAT_DDP_COALESCE", "1")))
         self._pending = None
         model.grad_ready = self.bucket_ready
+        # The logged loss (``accelerator.gather(avg_loss).mean()``, common/trainer.py:359) without a collective of its own:
+        # a caller that wants it calls ``track_loss(running sum)`` before the micro-step; the model reports the step's loss
+        # when it exists (``on_loss``: before the backward), the sum is written into the spare element behind the gradients
+        # and travels with the top bucket -- the first one the backward completes -- and ``wait()`` leaves the mean over
+        # ranks in ``carried_loss``.  Without ``track_loss`` (bench.py) nothing of this runs.
+        tail = getattr(model, "grad_tail", None)
+        self._tail = tail if (tail is not None and tail.numel() >= 1 and hasattr(model, "_grad_store")) else None
+        self._loss_acc, self._track, self._tail_armed, self._tail_sent = None, False, False, False
+        self.carried_loss = None
+        if self._tail is not None:
+            model.loss_ready = self.on_loss
 
     def broadcast_parameters(self, src=0):
         """accelerator.prepare -> DDP's rank0 -> all parameter broadcast (trainer.py:253)."""
@@ -120,6 +131,20 @@ class HipDDP:
                 self.native.broadcast(self.model.flat_param, src)
             else:
                 dist.broadcast(self.model.flat_param, src=src, group=self.pg)
+
+    def track_loss(self, running_sum=None):
+        """Arm the piggyback for the coming micro-step; ``running_sum``: the window's earlier micro-step losses (device
+        scalar) that ``gather(avg_loss)`` would have included, or None."""
+        self._loss_acc, self._track = running_sum, True
+
+    def on_loss(self, loss):
+        if not self._track or self._tail is None or (self.world == 1 and not self.force):
+            return
+        x = loss.detach().float().reshape(())
+        if self._loss_acc is not None:
+            x = x + self._loss_acc.detach().float().reshape(()).to(x.device)
+        self._tail[0:1].copy_(x.reshape(1))               # (rounds to the gradient buffer's dtype)
+        self._tail_armed = True
 
     def bucket_ready(self, i):
         if (self.world == 1 and not self.force) or not self.sync:
@@ -136,6 +161,9 @@ class HipDDP:
                 return
             (lo, hi, _), self._pending = self._pending, None
         chunk = self.model.flat_grad[lo:hi]
+        if self._tail_armed and hi == self.model.flat_grad.numel():       # the top bucket carries the loss element(s)
+            chunk = self.model._grad_store[lo:hi + self._tail.numel()]
+            self._tail_armed, self._tail_sent = False, True
         self.bytes_reduced += chunk.numel() * chunk.element_size()
         self.buckets_reduced += 1
         rccl = self.on_gpu and (self.native is not None or dist.get_backend(self.pg) == "nccl")
@@ -200,6 +228,7 @@ class HipDDP:
                 w1.record(cur)
                 self.timed_waits.append((w0, w1))
             self._works.clear()
+            self._harvest_loss()
             return
         if self.native is not None:
             self.native.wait(torch.cuda.current_stream())
@@ -213,6 +242,17 @@ class HipDDP:
                 if self.average:
                     chunk.div_(self.world)
         self._works.clear()
+        self._harvest_loss()
+
+    def _harvest_loss(self):
+        self._track, self._loss_acc = False, None
+        if not self._tail_sent:
+            self._tail_armed = False
+            return
+        self._tail_sent = False
+        v = self._tail[0].float().clone()                 # (a copy: the slot is cleared below)
+        self.carried_loss = v if self.average else v / self.world
+        self._tail.zero_()
 
     def all_reduce_scalar_mean(self, t):
         """accelerator.gather(avg_loss).mean() (trainer.py:359) as one tiny all-reduce."""

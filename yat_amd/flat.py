@@ -46,6 +46,9 @@ def compute_stream(device):
     return torch.cuda.Stream(device=device, priority=-1 if isolate_streams() else 0)
 
 
+GRAD_TAIL = 8        # 16 bytes: the flat gradient buffer stays a whole number of 16-byte vectors
+
+
 class FlatParamModule(nn.Module):
     def _alloc_flat(self, specs, device):
         """``specs``: [(diffusers key, shape)] in forward-execution order."""
@@ -56,7 +59,11 @@ class FlatParamModule(nn.Module):
             off += (math.prod(shape) + 7) // 8 * 8            # 16-byte aligned segment starts
         self.numel_flat = off
         self.flat_param = torch.zeros(off, dtype=BF16, device=self.dev)
-        self.flat_grad = torch.zeros(off, dtype=BF16, device=self.dev)
+        # GRAD_TAIL spare elements behind the gradients: the data-parallel wrapper lets the step's loss ride in the first of them
+        # with the top bucket's all-reduce (yat_amd/ddp.py ``on_loss``); the optimizer and the norm never see them
+        self._grad_store = torch.zeros(off + GRAD_TAIL, dtype=BF16, device=self.dev)
+        self.flat_grad = self._grad_store[:off]
+        self.grad_tail = self._grad_store[off:]
         self.seg_start = torch.tensor(offs + [off], dtype=torch.int64)     # host copy (true tensor extents)
         self._seg_numel = [math.prod(s) for _, s in specs]
         self.P, self.G = {}, {}
@@ -68,6 +75,7 @@ class FlatParamModule(nn.Module):
             self.P[name], self.G[name] = param.data, param.grad
         self._offset = dict(zip([n for n, _ in specs], offs))
         self.grad_ready = None            # callable(bucket_index) set by HipDDP
+        self.loss_ready = None            # callable(loss tensor) set by HipDDP: the device path reports its loss before the backward
         self.adapters = None              # yat_amd.lokr.LoKrAdapters when the config asks for PEFT adapters
         self.param_events = None          # set by FlatAdamW(overlap_update=True): one event per bucket
         self.accumulate_grads = False     # True on non-first micro-steps of gradient accumulation

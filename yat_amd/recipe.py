@@ -71,6 +71,14 @@ class _Stager:
         return self.land
 
 
+def _report_loss(model, loss):
+    """The device path has no ``accelerator.backward(loss)`` between its loss and its backward: a data-parallel wrapper that
+    carries the logged loss with the gradients (yat_amd/ddp.py ``on_loss``) is told here."""
+    hook = getattr(model, "loss_ready", None)
+    if hook is not None:
+        hook(loss)
+
+
 def _layout(sizes):
     """16-byte aligned offsets of consecutive byte segments -> (offsets, total)."""
     offs, o = [], 0
@@ -180,6 +188,7 @@ class SanaRecipe:
             pred = self.model.forward_impl(noisy, enc, timesteps, None, key_bias=bias, kv_len=kvl, kv_work=kv_work, **packed)
         dpred = self._dpred(pred)
         ops.mse_fwd_bwd(pred, target, loss_out, dpred, self._mse_ws, gscale=gscale)
+        _report_loss(self.model, loss_out)
         if dev_path:
             self.model.backward_device(dpred)
         else:
@@ -309,6 +318,7 @@ class PixArtRecipe(SanaRecipe):
         out = self.model.forward_device(noisy, enc, timesteps, bias, kvl, kv_work=kv_work)      # (launch plans: yat_amd/flat.py)
         dpred = self._dpred(out)
         ops.mse_bf16_chunk(out, noise, loss_out, dpred, self._mse_ws, gscale=gscale)
+        _report_loss(self.model, loss_out)
         self.model.backward_device(dpred)
         return loss_out
 
@@ -449,6 +459,7 @@ class SD3Recipe:
         pred = self.model.forward_device(noisy, prompt, pooled, timesteps)                        # (launch plans: yat_amd/flat.py)
         dpred = self._scratch("_dpred_buf", pred)
         ops.mse_bf16_chunk(pred, target, loss_out, dpred, self._mse_ws, gscale=gscale)
+        _report_loss(self.model, loss_out)
         self.model.backward_device(dpred)
         return loss_out
 
