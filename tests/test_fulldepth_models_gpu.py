@@ -69,7 +69,9 @@ def _check(tag, l_h, l_b, l_t, taps_h, taps_b, taps_t, pred_h, pred_b, pred_t, g
     assert tot_h <= 1.3 * tot_b + 1e-3
 
 
-def test_pixart_sigma_xl_full_depth_step_matches_oracle():
+# side = 128: the 1024 px training resolution itself (BASELINE config 3: 128 x 128 latents, N = 4096 tokens per image)
+@pytest.mark.parametrize("side", [64, 128])
+def test_pixart_sigma_xl_full_depth_step_matches_oracle(side):
     from oracle.pixart_ref import PixArtConfig as RefCfg, PixArtTransformerRef, DDPMSchedule as RefSched, pixart_optimize_ref
     from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
     from yat_amd.recipe import PixArtRecipe
@@ -82,14 +84,14 @@ def test_pixart_sigma_xl_full_depth_step_matches_oracle():
     cfg = ref_bf.cfg
     assert cfg.num_layers == 28 and hip.cfg.inner_dim == 1152
     g = torch.Generator().manual_seed(2024)
-    latents = (torch.randn(1, cfg.in_channels, 64, 64, generator=g) * 0.5).to(BF)
+    latents = (torch.randn(1, cfg.in_channels, side, side, generator=g) * 0.5).to(BF)
     embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (253,)]
-    noise = torch.randn(1, cfg.in_channels, 64, 64, generator=g).to(BF)
+    noise = torch.randn(1, cfg.in_channels, side, side, generator=g).to(BF)
     tap_blocks = (0, 6, 13, 27)
 
     recipe = PixArtRecipe(hip, pad_to=300, device=DEV)
     loss, out, _ = recipe.optimize(latents, embs, torch.Generator(), return_pred=True, noise=noise.to(DEV))
-    taps_h = {i: hip._saved.blocks[i].x3.detach().clone().view(1, 1024, -1) for i in tap_blocks}
+    taps_h = {i: hip._saved.blocks[i].x3.detach().clone().view(1, (side // 2) ** 2, -1) for i in tap_blocks}
     loss.backward()
     torch.cuda.synchronize()
     g_h = hip.flat_grad.detach().float().cpu()
@@ -119,10 +121,12 @@ def test_pixart_sigma_xl_full_depth_step_matches_oracle():
     ref_32 = copy.deepcopy(ref_bf).float()
     l_t, o_t, t_t, g_t = oracle(ref_32, lambda t: t.float())
     del ref_32
-    _check("pixart-sigma-xl full depth 64x64", loss.item(), l_b, l_t, taps_h, t_b, t_t, out, o_b, o_t, g_h, g_b, g_t, 2.0 ** -7)
+    _check(f"pixart-sigma-xl full depth {side}x{side}", loss.item(), l_b, l_t, taps_h, t_b, t_t, out, o_b, o_t, g_h, g_b, g_t, 2.0 ** -7)
 
 
-def test_sd35_medium_full_depth_step_matches_oracle():
+# side = 128: the 1024 px training resolution itself (BASELINE config 4: joint sequence of 4096 + 333 = 4429 tokens)
+@pytest.mark.parametrize("side", [48, 128])
+def test_sd35_medium_full_depth_step_matches_oracle(side):
     from oracle.sd3_ref import SD3Config as RefCfg, SD3TransformerRef, optimize_ref
     from oracle.recipe_ref import FlowMatchSchedule as RefSched
     from yat_amd.sd3 import SD3Config, SD3Transformer2DModelHIP
@@ -132,14 +136,14 @@ def test_sd35_medium_full_depth_step_matches_oracle():
     cfg = ref_bf.cfg
     assert cfg.num_layers == 24 and hip.cfg.inner_dim == 1536 and len(cfg.dual_attention_layers) == 13
     g = torch.Generator().manual_seed(3035)
-    latents = (torch.randn(1, cfg.in_channels, 48, 48, generator=g) * 0.5).to(BF)
+    latents = (torch.randn(1, cfg.in_channels, side, side, generator=g) * 0.5).to(BF)
     prompt = torch.randn(1, 333, cfg.joint_attention_dim, generator=g).to(BF)
     pooled = torch.randn(1, cfg.pooled_projection_dim, generator=g).to(BF)
     tap_blocks = (0, 5, 12, 22)               # image stream after block i = input of block i + 1
 
     recipe = SD3Recipe(hip, device=DEV)
     loss, pred, _ = recipe.optimize(latents, (prompt, pooled), torch.Generator().manual_seed(7), return_pred=True)
-    taps_h = {i: hip._saved.blocks[i + 1].x_in.detach().clone().view(1, 576, -1) for i in tap_blocks}
+    taps_h = {i: hip._saved.blocks[i + 1].x_in.detach().clone().view(1, (side // 2) ** 2, -1) for i in tap_blocks}
     loss.backward()
     torch.cuda.synchronize()
     g_h = hip.flat_grad.detach().float().cpu()
@@ -161,4 +165,4 @@ def test_sd35_medium_full_depth_step_matches_oracle():
     ref_32 = copy.deepcopy(ref_bf).float()
     l_t, p_t, t_t, g_t = oracle(ref_32, torch.float32)
     del ref_32
-    _check("sd3.5-medium full depth 64x64", loss.item(), l_b, l_t, taps_h, t_b, t_t, pred, p_b, p_t, g_h, g_b, g_t, 2.0 ** -7)
+    _check(f"sd3.5-medium full depth {side}x{side} latents", loss.item(), l_b, l_t, taps_h, t_b, t_t, pred, p_b, p_t, g_h, g_b, g_t, 2.0 ** -7)
