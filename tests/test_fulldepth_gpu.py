@@ -148,6 +148,82 @@ def test_full_depth_step_matches_oracle(full_models, h, w, lens):
             assert e1 <= 1.5 * e2 + 2e-3, (bi, e1, e2)
 
 
+def test_lokr_full_depth_step_matches_oracle(full_models):
+    """BASELINE config 5 at the real size: LoKr rank 8 (alpha 8, the bench's targets) on the frozen SANA-1.6B base, all 20
+    blocks -- loss, prediction and every adapter gradient of one training step against the oracle's restatement of the peft
+    wrap (oracle/lokr_ref.py) in bf16 and fp32.  w1 is moved off its zero init so that the adapters act (a fresh LoKr adapter
+    is the identity) and their gradients flow through the whole stack."""
+    from oracle.lokr_ref import LoKrWrapped, apply_lokr
+    from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
+    from yat_amd.lokr import LoKrAdapters
+    from yat_amd.recipe import SanaRecipe
+    hip, ref_shared = full_models
+    targets = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
+    ref_bf = copy.deepcopy(ref_shared)                   # the wrap replaces modules: not on the shared oracle
+    cfg = ref_bf.cfg
+    ad = LoKrAdapters(hip, targets, r=8, alpha=8.0, module_dropout=0.0)
+    try:
+        g = torch.Generator().manual_seed(77)
+        for e in ad.entries:
+            w1, _, _ = ad._views(e, ad.flat_param)
+            w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+        wrapped = apply_lokr(ref_bf, targets, r=8, alpha=8.0)
+        assert sorted(wrapped) == sorted(e["module"] for e in ad.entries) and len(wrapped) > 200
+        sd = ad.state_dict()
+        with torch.no_grad():
+            for name, w in wrapped.items():
+                pre = f"base_model.model.{name}."
+                w.lokr_w1.copy_(sd[pre + "lokr_w1"].cpu())
+                w.lokr_w2_a.copy_(sd[pre + "lokr_w2_a"].cpu())
+                w.lokr_w2_b.copy_(sd[pre + "lokr_w2_b"].cpu())
+        for q in ref_bf.parameters():                    # frozen base: only the adapter factors train (peft's wrap)
+            q.requires_grad_(False)
+        mods = {n: m for n, m in ref_bf.named_modules() if isinstance(m, LoKrWrapped)}
+        for m in mods.values():
+            for q in (m.lokr_w1, m.lokr_w2_a, m.lokr_w2_b):
+                q.requires_grad_(True)
+        h = w_ = 32
+        lens = (120, 37)
+        latents = (torch.randn(len(lens), cfg.in_channels, h, w_, generator=g) * 0.5).to(BF)
+        embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in lens]
+
+        recipe = SanaRecipe(hip, pad_to=512, device=DEV)
+        hip.train()
+        loss, pred, _ = recipe.optimize(latents, embs, torch.Generator().manual_seed(3), return_pred=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        g_h = torch.cat([t.float().flatten().cpu() for e in ad.entries for t in ad._views(e, ad.flat_grad)])
+
+        def oracle(model, dtype):
+            t0 = time.time()
+            model.train()
+            l, p, _ = optimize_ref(model, RefSched(), latents, embs, torch.Generator().manual_seed(3), 512, dtype)
+            l.backward()
+            ms = {n: m for n, m in model.named_modules() if isinstance(m, LoKrWrapped)}
+            flat = torch.cat([t.grad.float().flatten() for e in ad.entries
+                              for t in (ms[e["module"]].lokr_w1, ms[e["module"]].lokr_w2_a, ms[e["module"]].lokr_w2_b)])
+            model.zero_grad(set_to_none=True)
+            print(f"[parity] lokr full depth: oracle {dtype} fwd+bwd {time.time() - t0:.1f} s")
+            return l.item(), p.detach(), flat
+
+        l_b, p_b, g_b = oracle(ref_bf, BF)
+        ref_32 = ref_bf.float()                          # (in place: the bf16 copy is not needed again)
+        l_t, p_t, g_t = oracle(ref_32, torch.float32)
+        del ref_32, ref_bf
+        l_h = loss.item()
+        print(f"[parity] lokr full depth: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
+        assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 2e-3 * abs(l_t)
+        e_h, e_b = rel(pred, p_t), rel(p_b, p_t)
+        print(f"[parity] lokr full depth: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={rel(pred, p_b):.3e}")
+        assert e_h <= 1.3 * e_b + 1e-3
+        e_h, e_b = rel(g_h, g_t), rel(g_b, g_t)
+        print(f"[parity] lokr full depth: adapter grads ({g_t.numel() / 1e6:.2f} M) hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e}")
+        assert torch.isfinite(g_h).all() and g_t.abs().max() > 0
+        assert e_h <= 1.3 * e_b + 2e-3
+    finally:
+        hip.adapters = None                              # the shared model goes back to full fine-tuning
+
+
 # ---- the bench step at its own width and batch, on every bench bucket, without the oracle: what bench.py times is
 # ``train_step_device`` with packed text rows, replayed launch plans and two forward chains at D = 2240, B = 8 on the buckets
 # 32x32 / 16x64 / 24x42 / 44x22 with prompts of 20..300 tokens (train_sana.py:163-219).  The oracle pins the padded path (tiny
