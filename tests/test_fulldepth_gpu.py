@@ -62,8 +62,9 @@ TEXT_SIDE = ("caption_projection", "caption_norm", "attn2.to_k", "attn2.to_v")
 # Third case: the batch the benchmark times -- B = 8 images of 32 x 32 latents, eight ragged prompts of 20..300 tokens -- so the
 # oracle is compared with exactly the launch shapes (M = 8192 token rows, packed text rows, both forward chains of four images)
 # that bench.py's timed region runs, not with a smaller batch of the same model (~60 GB of fp32 oracle activations on the host).
+# (16 x 64 and 44 x 22: the other two bench buckets -- their own depthwise-conv tile variants and row geometry -- two images each)
 @pytest.mark.parametrize("h,w,lens", [(32, 32, (300, 41)), (24, 42, (41, 233)),
-                                      (32, 32, (20, 300, 77, 155, 233, 41, 118, 264))])
+                                      (32, 32, (20, 300, 77, 155, 233, 41, 118, 264)), (16, 64, (190, 64)), (44, 22, (8, 277))])
 def test_full_depth_step_matches_oracle(full_models, h, w, lens):
     from oracle.recipe_ref import FlowMatchSchedule as RefSched, optimize_ref
     from yat_amd.recipe import SanaRecipe
