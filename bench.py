@@ -65,21 +65,9 @@ def log(msg):
 
 
 def usable_cores():
-    """Cores this process may actually use: min(affinity mask, cgroup cpu quota) -- os.cpu_count() reports the whole
-    host and oversubscribing OpenMP threads on a 16-core share makes the CPU leg crawl."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
+    """Cores this process may actually use (yat_amd/common/host.py: min(affinity mask, cgroup cpu quota))."""
+    from yat_amd.common.host import usable_cores as f
+    return f()
 
 
 def cpu_baseline(state_dict, cfg_layers=20):
@@ -181,7 +169,15 @@ def run_from_shards(args, rank, world, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace_every = int(os.environ.get("YAT_BENCH_TRACE_STEPS", "0"))      # diagnostic: wall time per N steps (adds a sync each time)
+
     def on_step(step):
+        if trace_every and step > args.warmup and (step - args.warmup) % trace_every == 0:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            log(f"trainer mode: steps {step - trace_every - args.warmup}..{step - args.warmup}: "
+                f"{1e3 * (now - clock.get('t_trace', clock['t0'])) / trace_every:.1f} ms/step")
+            clock["t_trace"] = now
         if step == args.warmup:
             barrier()
             clock["t0"] = time.perf_counter()
@@ -190,7 +186,41 @@ def run_from_shards(args, rank, world, local_rank):
             barrier()
             clock["t1"] = time.perf_counter()
     log(f"rank {rank}/{world}: trainer mode, {args.warmup} + {args.steps} steps from {len(paths)} shard(s) in {root}")
+    host = {}
+    if os.environ.get("YAT_BENCH_HOST_SPLIT", "0") != "0":       # diagnostic: where the trainer's host thread spends its time
+        def timed(name, fn):
+            def wrapped(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    host[name] = host.get(name, 0.0) + time.perf_counter() - t
+            return wrapped
+        trainer.optimize = timed("optimize (stage + enqueue fwd/bwd)", trainer.optimize)
+        from yat_amd import plan as _plan, recipe as _recipe
+        from yat_amd.optim import FlatAdamW as _Opt
+        from yat_amd.common.bucket_sampler import BucketSampler as _Sampler
+        _Opt.step = timed("optimizer.step", _Opt.step)
+        _plan.LaunchPlan.replay = timed("  of which plan replay", _plan.LaunchPlan.replay)
+        _recipe._Stager.begin = timed("  of which wait for a staging buffer", _recipe._Stager.begin)
+        samp_iter = _Sampler.__iter__
+
+        def iter_timed(self_):
+            it = samp_iter(self_)
+            while True:
+                t = time.perf_counter()
+                try:
+                    b = next(it)
+                except StopIteration:
+                    return
+                finally:
+                    host["sampler (next batch)"] = host.get("sampler (next batch)", 0.0) + time.perf_counter() - t
+                yield b
+        _Sampler.__iter__ = iter_timed
     trainer.run(on_step=on_step)
+    if host:
+        n = args.warmup + args.steps
+        log("trainer mode host split (ms per step, main thread): " + "; ".join(f"{k} {1e3 * v / n:.1f}" for k, v in host.items()))
     os.chdir(cwd)
     elapsed = clock["t1"] - clock["t0"]
     log(f"trainer mode: host enqueue time {1e3 * (clock['t_issue'] - clock['t0']) / args.steps:.1f} ms/step, "
@@ -270,6 +300,8 @@ def main():
     ap.add_argument("--phases", default=None, metavar="FILE",
                     help="after the timed region, time the phases of 6 steps with HIP events and write them to FILE")
     args = ap.parse_args()
+    from yat_amd.common.host import cap_host_threads
+    cap_host_threads()       # the host thread's small CPU ops on this rank's share of the usable CPUs, not on 256 OpenMP threads
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

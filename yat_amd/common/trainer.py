@@ -29,6 +29,7 @@ import torch
 import torch.distributed as dist
 
 from ..ddp import HipDDP
+from .host import cap_host_threads
 from ..optim import FlatAdamW
 from .aspect_ratios import ASPECT_RATIO_1024_BIN, ASPECT_RATIO_512_BIN
 
@@ -38,6 +39,7 @@ class HipAccelerator:
 
     def __init__(self, gradient_accumulation_steps=1, device=None, backend=None, timeout_s=3600):
         self.gradient_accumulation_steps = int(gradient_accumulation_steps or 1)
+        cap_host_threads()                               # (common/host.py: the OpenMP pool vs the CPUs this job really has)
         self.process_index = int(os.environ.get("RANK", "0"))
         self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
