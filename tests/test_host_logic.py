@@ -173,3 +173,43 @@ def test_empty_embedding_layout_is_checked_per_recipe():
         SD35Trainer.check_empty_embeddings(None, t, "e.pt")
     with pytest.raises(ValueError, match="e.pt"):
         SD35Trainer.check_empty_embeddings(None, [t], "e.pt")
+
+
+def test_host_draws_are_remembered_per_generator_state():
+    """SanaRecipe._draw_cached: the reference hands every step a fresh torch.Generator() (common/trainer.py:325), i.e. always
+    the same state; a generator arriving in a remembered state gets the remembered noise / timesteps and is left in the
+    remembered end state -- exactly what drawing again does; any other state draws."""
+    from yat_amd.recipe import SanaRecipe
+    from yat_amd.scheduler import FlowMatchSchedule
+    r = SanaRecipe.__new__(SanaRecipe)
+    r.scheduler = FlowMatchSchedule()
+    shape, B = (4, 8, 6, 10), 4
+
+    def draw(gen):
+        out = torch.empty(shape, dtype=torch.bfloat16)
+        t, s = r._draw_cached(shape, B, gen, out)
+        return out, t, s, torch.rand(3, generator=gen)          # the last item: where the generator was left
+
+    g = torch.Generator()
+    want_n = torch.randn(shape, generator=g, dtype=torch.bfloat16)
+    _, want_t, want_s = r.scheduler.sample(B, g)
+    want_next = torch.rand(3, generator=g)
+    for _ in range(3):                                           # first call draws, the others are remembered
+        n, t, s, nxt = draw(torch.Generator())
+        assert torch.equal(n, want_n) and torch.equal(t, want_t) and torch.equal(s, want_s) and torch.equal(nxt, want_next)
+    a, b, a2 = draw(torch.Generator().manual_seed(3)), draw(torch.Generator().manual_seed(4)), draw(torch.Generator().manual_seed(3))
+    assert not torch.equal(a[0], b[0]) and torch.equal(a[0], a2[0]) and torch.equal(a[3], a2[3])
+    g = torch.Generator()                                        # an advancing generator (exploration steps): no false hits
+    x, y = draw(g), draw(g)
+    assert not torch.equal(x[0], y[0])
+
+
+def test_host_thread_cap():
+    from yat_amd.common import host
+    n = host.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        assert host.cap_host_threads() <= max(1, min(before, n, 16)) or "OMP_NUM_THREADS" in os.environ
+    finally:
+        torch.set_num_threads(before)
