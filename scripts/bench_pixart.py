@@ -49,6 +49,8 @@ def main():
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU (the HIP path has no CPU fallback)")
+    from yat_amd.common.host import cap_host_threads
+    cap_host_threads()                    # as the trainer does (HipAccelerator): the OpenMP pool vs the CPUs this job really has
     dev = torch.device("cuda", 0)
     from yat_amd import ops
     from yat_amd.pixart import PixArtConfig, PixArtTransformer2DModelHIP
