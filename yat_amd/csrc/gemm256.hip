@@ -570,7 +570,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             if (EPI == 1) glu_bwd_store<8>(p, v, m, n);
                             else if (EPI == 3) act_bwd_store<8>(p, v, m, n);
-                            else gemm_epilogue_store8<EPI == 2>(p, v, m, n, m / rpb);
+                            else gemm_epilogue_store8<EPI == 2, A_T && B_T>(p, v, m, n, m / rpb);     // (weight-gradient layout: non-temporal result)
                         }
                     }
                 }

@@ -121,7 +121,9 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4&
 }
 
 // Same for 8 consecutive columns (16-B accesses; n % 8 == 0 and every leading dimension % 8 == 0).
-template <bool PRE = false>
+// NTC: the result is written non-temporally (weight gradients: next read by the all-reduce / the optimizer, milliseconds later);
+// the pre-activation copy (aux) always is -- it is kept for the backward only (common.hpp YAT_AUX_NT).
+template <bool PRE = false, bool NTC = false>
 __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[8], int m, int n, int b) {
     if (p.bias) {
         float bb[8];
@@ -139,7 +141,9 @@ __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]);
     }
-    if (p.aux) *reinterpret_cast<u32x4*>(p.aux + (int64_t)m * p.ldaux + n) = pack8(v);
+    if (p.aux) {
+        __builtin_nontemporal_store(pack8(v), reinterpret_cast<u32x4*>(p.aux + (int64_t)m * p.ldaux + n));
+    }
     if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
@@ -159,7 +163,8 @@ __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
-    *reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + n) = pack8(v);
+    if (NTC) __builtin_nontemporal_store(pack8(v), reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + n));
+    else *reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + n) = pack8(v);
 }
 
 // gemm256.hip
