@@ -213,3 +213,25 @@ def test_host_thread_cap():
         assert host.cap_host_threads() <= max(1, min(before, n, 16)) or "OMP_NUM_THREADS" in os.environ
     finally:
         torch.set_num_threads(before)
+
+
+def test_carried_loss_arithmetic_in_bf16():
+    """yat_amd/ddp.py on_loss / _harvest_loss: what survives of the logged loss when the slots and the reduction are bf16 --
+    eight ranks, losses around 2 (where bf16 alone resolves 0.016), difference to last step's mean in a head + remainder pair."""
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+    prev_mean = torch.tensor(2.031)
+    losses = 2.0 + 0.2 * torch.randn(8, generator=g)
+    y = losses - prev_mean
+    hi = y.to(BF)
+    lo = (y - hi.float()).to(BF)
+    acc_hi, acc_lo = torch.zeros((), dtype=BF), torch.zeros((), dtype=BF)
+    for r in range(8):                                   # a ring's running sums, rounded to bf16 at every hop
+        acc_hi, acc_lo = (acc_hi.float() + hi[r].float()).to(BF), (acc_lo.float() + lo[r].float()).to(BF)
+    got = prev_mean + (acc_hi.float() / 8).to(BF).float() + (acc_lo.float() / 8).to(BF).float()
+    want = losses.mean()
+    plain = torch.zeros((), dtype=BF)
+    for r in range(8):
+        plain = (plain.float() + losses[r].to(BF).float()).to(BF)
+    assert abs(got - want) < 2e-3 * want                 # 0.2 % of the loss
+    assert abs(got - want) < 0.5 * abs((plain.float() / 8) - want) + 1e-4        # and better than carrying the bf16 loss itself

@@ -118,8 +118,9 @@ class HipDDP:
         # and travels with the top bucket -- the first one the backward completes -- and ``wait()`` leaves the mean over
         # ranks in ``carried_loss``.  Without ``track_loss`` (bench.py) nothing of this runs.
         tail = getattr(model, "grad_tail", None)
-        self._tail = tail if (tail is not None and tail.numel() >= 1 and hasattr(model, "_grad_store")) else None
+        self._tail = tail if (tail is not None and tail.numel() >= 2 and hasattr(model, "_grad_store")) else None
         self._loss_acc, self._track, self._tail_armed, self._tail_sent = None, False, False, False
+        self._loss_offset = None             # previous step's carried mean (device scalar, the same on every rank)
         self.carried_loss = None
         if self._tail is not None:
             model.loss_ready = self.on_loss
@@ -143,7 +144,15 @@ class HipDDP:
         x = loss.detach().float().reshape(())
         if self._loss_acc is not None:
             x = x + self._loss_acc.detach().float().reshape(()).to(x.device)
-        self._tail[0:1].copy_(x.reshape(1))               # (rounds to the gradient buffer's dtype)
+        # The slots have the gradient buffer's dtype (bf16: 8 bits) and the reduction rounds in it; the reference's gathered
+        # loss is fp32 (train_sana.py:216).  So what travels is the DIFFERENCE to the previous step's mean (identical on
+        # every rank: it came out of the same all-reduce), split into a bf16 head and a bf16 remainder: the rounding of the
+        # reduction then scales with how far the ranks' losses are from last step's mean, not with the loss itself.
+        if self._loss_offset is not None:
+            x = x - self._loss_offset.to(x.device)
+        hi = x.to(self._tail.dtype)
+        lo = (x - hi.float()).to(self._tail.dtype)
+        self._tail[0:2].copy_(torch.stack([hi, lo]))
         self._tail_armed = True
 
     def bucket_ready(self, i):
@@ -250,8 +259,13 @@ class HipDDP:
             self._tail_armed = False
             return
         self._tail_sent = False
-        v = self._tail[0].float().clone()                 # (a copy: the slot is cleared below)
-        self.carried_loss = v if self.average else v / self.world
+        v = self._tail[0].float() + self._tail[1].float()       # (a new tensor: the slots are cleared below)
+        if not self.average:
+            v = v / self.world
+        if self._loss_offset is not None:
+            v = v + self._loss_offset.to(v.device)
+        self.carried_loss = v
+        self._loss_offset = v.detach().clone()
         self._tail.zero_()
 
     def all_reduce_scalar_mean(self, t):
