@@ -2,6 +2,7 @@
 """Headline benchmark: SANA-1.6B 1024 px bf16 training step, images/sec (whole job), on N MI355X.
 
     python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (no launcher around it: starts its own ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -265,14 +266,29 @@ def emit_json(obj):
 _JSON_OUT = None
 
 
-def main():
-    # stdout carries exactly one JSON line.  Libraries do not know that: RCCL prints its version block on stdout when the
-    # first communicator is built (seen with a forced one-rank group), which would land in front of the line the driver
-    # parses.  Keep a private handle on the real stdout for the JSON line and point fd 1 at stderr for everyone else.
-    global _JSON_OUT
+def self_launch(n):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the ranks ourselves.  The reference's
+    counterpart is ``accelerate launch`` (README.md:62; the process group it builds: common/trainer.py:31-37).  This parent
+    has made no GPU call (importing torch does not initialise HIP) and never will: it starts ``python -m
+    torch.distributed.run`` as a fresh CHILD process -- never an exec of the current one -- on a free loopback port, lets the
+    child inherit stdout / stderr (rank 0 prints the one JSON line there) and exits with the child's code."""
+    import socket
+    import subprocess
+    port = os.environ.get("YAT_BENCH_MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on these hosts (RCCL needs it across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...")
     sys.stdout.flush()
-    _JSON_OUT = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -300,6 +316,15 @@ def main():
     ap.add_argument("--phases", default=None, metavar="FILE",
                     help="after the timed region, time the phases of 6 steps with HIP events and write them to FILE")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))      # (before anything touches the GPU or rewires stdout)
+    # stdout carries exactly one JSON line.  Libraries do not know that: RCCL prints its version block on stdout when the
+    # first communicator is built (seen with a forced one-rank group), which would land in front of the line the driver
+    # parses.  Keep a private handle on the real stdout for the JSON line and point fd 1 at stderr for everyone else.
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     from yat_amd.common.host import cap_host_threads
     cap_host_threads()       # the host thread's small CPU ops on this rank's share of the usable CPUs, not on 256 OpenMP threads
 
@@ -308,7 +333,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # one process per GPU.  (Rehearsal of the N > 1 flow on a one-GPU box: YAT_DIST_BACKEND=gloo lets several ranks share
@@ -484,35 +509,66 @@ def main():
     # stream and around the compute stream's wait for it.  Every rank runs them (collectives), rank 0 reports.
     comm = None
     if ddp is not None:
-        try:
-            K = max(2, args.comm_steps)
-            base = args.warmup + args.steps + len(BUCKETS)
-            base += (-base) % len(BUCKETS)                     # every pass starts on the same bucket
+        # A failure on ONE rank must not leave the others inside a collective: every pass ends with an agreement (all-reduce MAX
+        # of a local error flag) and all ranks abandon the diagnostics together; the arithmetic on the harvested events is
+        # local and has its own guard.  (A rank that dies INSIDE a pass still strands its peers until the process-group
+        # timeout -- as in the reference, common/trainer.py:34 -- but an error raised at a pass boundary, e.g. by a HIP event
+        # or an allocation, no longer does.)
+        K = max(2, args.comm_steps)
+        base = args.warmup + args.steps + len(BUCKETS)
+        base += (-base) % len(BUCKETS)                     # every pass starts on the same bucket
+        state = {"err": None, "dry_started": False}
 
-            def timed_pass():
-                barrier()
-                tp = time.perf_counter()
+        def agreed_ok():
+            bad = 0 if state["err"] is None else 1
+            if world > 1:
+                f = torch.tensor([bad], dtype=torch.int32, device=dev)
+                dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                bad = int(f.item())
+            return bad == 0
+
+        def timed_pass():
+            barrier()
+            tp = time.perf_counter()
+            try:
                 for i in range(K):
                     step(base + i)
-                barrier()
-                dt = time.perf_counter() - tp
-                if world > 1:
-                    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dt = tt.item()
-                return 1e3 * dt / K
-            step(base)                                         # (plans of this bucket order are recorded by now; one settle step)
+            except Exception as e:                         # noqa: BLE001 -- reported in the comm object
+                state["err"] = e
+            barrier()
+            dt = time.perf_counter() - tp
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = tt.item()
+            return 1e3 * dt / K
+
+        ms_live = ms_dry = ms_timing = float("nan")
+        b0, n0 = ddp.bytes_reduced, ddp.buckets_reduced
+        try:
+            step(base)                                     # (plans of this bucket order are recorded by now; one settle step)
+        except Exception as e:                             # noqa: BLE001
+            state["err"] = e
+        ok = agreed_ok()
+        if ok:
             ms_live = timed_pass()
-            ddp.dryrun = True
+            ok = agreed_ok()
+        if ok:
+            ddp.dryrun, state["dry_started"] = True, True
             ms_dry = timed_pass()
             ddp.dryrun = False
-            if world > 1:
-                ddp.broadcast_parameters()                     # the dry steps did not average: bring the replicas back together
+            ok = agreed_ok()
+        if state["dry_started"] and world > 1:
+            ddp.broadcast_parameters()                     # the dry steps did not average: bring the replicas back together
+        if ok:
             ddp.timing, ddp.timed_buckets, ddp.timed_waits = True, [], []
             b0, n0 = ddp.bytes_reduced, ddp.buckets_reduced
             ms_timing = timed_pass()
             ddp.timing = False
-            torch.cuda.synchronize()
+            ok = agreed_ok()
+        ddp.dryrun = ddp.timing = False
+        torch.cuda.synchronize()
+        def comm_report():
             durs = sorted(e0.elapsed_time(e1) for _, _, e0, e1 in ddp.timed_buckets)
             sizes = [nb for _, nb, _, _ in ddp.timed_buckets]
             waits = [w0.elapsed_time(w1) for w0, w1 in ddp.timed_waits]
@@ -546,10 +602,17 @@ def main():
                 comm["adapter_bucket_bytes"] = sizes[0] if sizes else None
             log(f"data-parallel diagnostics: step {ms_live:.2f} ms, collective off {ms_dry:.2f} ms, comm stream {comm_ms:.2f} ms/step "
                 f"-> overlap {comm['overlap_frac']}")
-        except Exception as e:     # a reported side object: it must never sink the bench line (every rank takes the same path)
-            ddp.dryrun = ddp.timing = False
-            comm = {"error": repr(e)}
-            log(f"data-parallel diagnostics failed: {e!r}")
+            return comm
+
+        if not ok:
+            comm = {"error": repr(state["err"]) if state["err"] is not None else "another rank failed"}
+            log(f"data-parallel diagnostics abandoned on every rank: {comm['error']}")
+        else:
+            try:
+                comm = comm_report()
+            except Exception as e:     # local arithmetic on harvested events only (no collective inside): never sinks the bench line
+                comm = {"error": repr(e)}
+                log(f"data-parallel diagnostics failed: {e!r}")
 
     # ---- optional phase probe (after the timed region; nothing of it runs otherwise): GPU timestamps of the step's phases
     # from a handful of HIP events per step -- unlike a profiler's kernel trace it does not slow the host's enqueue, so the
