@@ -188,6 +188,44 @@ def test_gemm256_all_layouts(ops, variant, M, N, K):
         close(out, (xt.float().T @ w.float().T).to(BF), f"gemm256v{variant}_tt {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 384, 72, 136, 200, 520])
+def test_gemm256_deep_schedule_tile_counts(ops, variant, K):
+    """The k-strided-B layouts run the DEEP LDS-DMA schedule (csrc/gemm256.hip): a four-slot ring of 32-deep halves, counted
+    vmcnt waits, start-up batches that stand in for the iterations before the first.  Every K-tile count from 1 to 9 --
+    start-up only, the first counted iteration, the switch to the tail form -- and a ragged last K-tile, on ragged M / N."""
+    M, N = 520, 648
+    x, w = rnd(M, K, seed=180), rnd(K, N, scale=K ** -0.5, seed=181)                     # dgrad layout: A k-contiguous, B k-strided
+    out = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    ops.gemm(x, w, out, b_t=True, M=M, N=N, K=K, variant=variant)
+    close(out, (x.float() @ w.float()).to(BF), f"deep_nn v{variant} K={K}")
+    xt = x.T.contiguous()                                                                 # wgrad layout: both k-strided
+    out.fill_(float("nan"))
+    ops.gemm(xt, w, out, a_t=True, b_t=True, M=M, N=N, K=K, variant=variant)
+    close(out, (xt.float().T @ w.float()).to(BF), f"deep_tn v{variant} K={K}")
+
+
+@pytest.mark.parametrize("lay,M,N,K", [("nt", 8192, 5600, 2240), ("tt", 2240, 5600, 8192), ("nt", 4096, 2240, 11200)])
+def test_gemm256_deep_schedule_is_timing_independent(ops, lay, M, N, K):
+    """An LDS-DMA protocol error (a fragment read before its piece has landed, a refill before the last read) shows as
+    results that depend on memory latency.  The same launch right after itself (operands in the Infinity Cache) and right
+    after a 1 GiB fill (operands from HBM, several times the latency) must agree to the bit, over several rounds."""
+    a_t, b_t = lay[0] == "t", lay[1] == "t"
+    a = rnd(*((K, M) if a_t else (M, K)), seed=190)
+    b = rnd(*((K, N) if b_t else (N, K)), scale=K ** -0.5, seed=191)
+    junk = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+    outs = [torch.empty(M, N, dtype=BF, device=DEV) for _ in range(2)]
+    ops.gemm(a, b, outs[0], a_t=a_t, b_t=b_t, M=M, N=N, K=K)
+    ops.gemm(a, b, outs[0], a_t=a_t, b_t=b_t, M=M, N=N, K=K)                             # hot
+    ref = (a.float().T if a_t else a.float()) @ (b.float() if b_t else b.float().T)
+    close(outs[0], ref.to(BF), f"deep_hot {lay}")
+    for rnd_i in range(6):
+        junk.fill_(rnd_i)
+        outs[1].fill_(float("nan"))
+        ops.gemm(a, b, outs[1], a_t=a_t, b_t=b_t, M=M, N=N, K=K)                         # cold
+        assert torch.equal(outs[0], outs[1]), f"{lay}: cold launch {rnd_i} differs from the hot one"
+
+
 @pytest.mark.parametrize("variant", [4, 5, 6])
 def test_gemm256_epilogue_and_identity(ops, variant):
     n = 512
@@ -517,6 +555,9 @@ def test_sdpa_fwd_bwd(ops, B, N, T, H, dh, lens):
 
 @pytest.mark.parametrize("B,N,H,dh", [
     (2, 64, 1, 32), (2, 100, 2, 112), (1, 77, 3, 64), (2, 130, 2, 72), (1, 50, 2, 24), (2, 33, 1, 128), (1, 200, 2, 80),
+    # head dims between the models' own: 104 passes the argument checks and must NOT take the dh-112 row-sum form (its ones
+    # column would sit in another output tile: round-3 advisor finding), 88 / 96 fall between the ONES classes
+    (2, 90, 2, 104), (1, 70, 2, 88), (2, 65, 1, 96), (1, 130, 3, 40), (1, 64, 2, 56),
     # the 128- and 192-query workgroups (ceil(N/128 | 192) * H * B >= 1024) and the 32-key-per-wave dK/dV, ragged last tiles
     (8, 250, 64, 32), (16, 200, 32, 64), (16, 400, 32, 72), (8, 130, 64, 112), (16, 385, 32, 64), (8, 300, 64, 72)])
 def test_sdpa_without_bias_matches_zero_bias(ops, B, N, H, dh):

@@ -22,6 +22,23 @@
 // before its 4th barrier of iteration t; group 1 issues tile t+2 in COMPUTE(t,ks1) and waits for tile
 // t+1 before its 3rd barrier of iteration t -- both waits precede rendezvous 4t+4.
 //
+// DEEP schedule (round 4; layouts with a k-strided B operand: the input- and weight-gradient GEMMs).  The two-stage ring above
+// gives a piece 2..4 of the 4 segments of a K-tile to land: enough for the Infinity Cache, short for HBM under load (operands
+// from HBM cost the same launches +10..+25 % at the sustained clock, scripts/gemm_sustained_probe.py).  The LDS images are
+// unchanged, but a k-strided image is refilled per 32-deep HALF (k-rows 0..31 / 32..63 are contiguous: a four-slot ring of
+// halves in the same two stages) as soon as group 1 has read it, and the rows of a k-contiguous A image -- private to one
+// wave group -- are refilled by that group right after its own last read:
+//   u = 2 t + kk numbers the 32-deep sub-steps; group 0's LOAD(u) ends with rendezvous 2u+1, its COMPUTE(u) with 2u+2;
+//   group 1's with 2u+2 / 2u+3.  Half u is last read before rendezvous 2u+2 and half v first read after rendezvous 2v.
+//   group 0 issues its share of half u+3 in COMPUTE(u) (after 2u+1 > 2(u-1)+2) and waits for it at the end of COMPUTE(u+2)
+//           (before 2u+6) with two younger batches still in flight:  s_waitcnt vmcnt(n(u+1) + n(u+2));
+//   group 1 issues its share of half u+4 in COMPUTE(u) (after 2u+2) and waits at the end of LOAD(u+3) (before 2u+8), again
+//           past two younger batches;
+//   k-contiguous A (input gradient): group g issues its own 128 rows of tile t+2 in COMPUTE(t, ks1), first in the batch, and
+//           waits before the rendezvous that precedes its LOAD(t+2, ks0).
+// A piece now has 4..6 segments (1.0..1.5 K-tiles) to land instead of 2..4.  Same pieces, same LDS bytes, same fragment
+// reads, same MFMA order: results are bit-identical to the two-stage schedule (-DYAT_GEMM_DEEP=0).
+//
 // Operand layouts, swizzles, swapped-operand MFMA and epilogue are those of gemm.hip.
 #include "common.hpp"
 #include "gemm_common.hpp"
@@ -369,6 +386,204 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #endif
     constexpr bool DIC_G1 = DIC || YAT_GEMM_NT_G1C;   // group 1 alone may prefetch tile t+2 from COMPUTE(t,ks1)
 
+    // the fragment reads of sub-step kk of the tile in stage t & 1 (the LDS traffic of a LOAD segment)
+    auto load_frags = [&](auto grp_c, int t, int kk) {
+        constexpr int GRP = decltype(grp_c)::value;
+        const char* cur = smem + (t & 1) * G::STAGE;
+        const uint32_t st = lds0 + (t & 1) * G::STAGE;
+        if (A_T) {
+            const uint32_t a0 = a_tr[0] + st + GRP * 256;            // group's rows = columns 128 GRP.. of the image
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = frag_tr<BM>(a0 ^ (i << 5), kk);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = frag256<false, BM>(cur, GRP * 128 + i * 16, kk, lane);
+        }
+        if (B_T && NT == 4) {
+            const uint32_t b0 = b_tr[0] + st + G::A_BYTES;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b0 ^ (j << 5), kk);
+        } else if (B_T) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b_tr[j] + st + G::A_BYTES, kk);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = frag256<false, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
+        }
+    };
+
+#ifndef YAT_GEMM_DEEP
+#define YAT_GEMM_DEEP 1
+#endif
+#ifdef YAT_GEMM_STAMPS
+    uint32_t st_loop_begin = 0;
+    constexpr bool DEEP = false;                           // (the stamp slots describe the two-stage schedule)
+#else
+    constexpr bool DEEP = YAT_GEMM_DEEP && B_T;            // the DEEP schedule of the header comment: k-strided B (nt, tt)
+#endif
+    if constexpr (DEEP) {
+      auto deep_loop = [&](auto grp_c) {
+        constexpr int GRP = decltype(grp_c)::value;
+        constexpr int NB = (NT == 5 && GRP == 1) ? 3 : 2;    // B pieces per half and wave (320 columns: 20 = 4 x 2 + 4 x 3)
+        constexpr int NAH = A_T ? 2 : 0;                      // k-strided A: pieces per half and wave
+        constexpr int NAO = A_T ? 0 : 4;                      // k-contiguous A: pieces of the group's own 128 rows per tile and wave
+        // ---- this wave's pieces.  A piece index fixes both the 1 KiB of the LDS image it fills and (make_piece) the global
+        // bytes that belong there, so any assignment of pieces to waves fills the same image.  The pieces of one wave are
+        // chosen a whole number of swizzle periods apart (16 or 32 k-rows of a k-strided image, 32 rows of a k-contiguous
+        // one): their per-lane offsets then differ by a wave-uniform number of rows, so ONE per-lane offset per operand (two
+        // for the odd piece of group 1 in the 320-column image) serves them all and the row delta rides, with the K-tile
+        // advance, in the instruction's scalar offset -- 2..3 address registers where the two-stage schedule keeps 9.
+        //   k-strided 256-column image (A; B of the 256-wide tile): piece = wave + 8 i + 16 h   -> k-row delta 16 i + 32 h
+        //   k-strided 320-column image: 20 pieces per half = classes {q, q + 10}; group 0 wave wc: class wc; group 1 wave wc:
+        //                               class 4 + wc and one piece of classes 8 / 9 (8, 18, 9, 19)       -> deltas 16 i + 32 h
+        //   k-contiguous A, own rows:   piece = 16 GRP + wc + 4 j                                       -> row delta 32 j
+        const int pa0 = A_T ? wave : 16 * GRP + wc;
+        const int pb0 = NT == 4 ? wave : (GRP ? 4 + wc : wc);
+        const int pbx = 8 + (wc >> 1) + 10 * (wc & 1);                     // (320 columns, group 1: 8, 18, 9, 19)
+        const uint32_t va0 = make_piece<A_T, BM>(pa0, lane, p.lda, m0, p.M).voff;
+        const uint32_t vb0 = make_piece<true, G::BN>(pb0, lane, p.ldb, n0, p.N).voff;
+        const uint32_t vbx = NB == 3 ? make_piece<true, G::BN>(pbx, lane, p.ldb, n0, p.N).voff : 0;
+        const uint32_t a_row = (uint32_t)p.lda * 2, b_row = (uint32_t)p.ldb * 2;           // bytes per k-row (k-strided)
+        const uint32_t kchunk_a = swz128((uint32_t)pa0 * 8 + (lane >> 3), lane & 7);       // (k-contiguous A: the same for all 4)
+
+        // one piece: operand / image piece / source offset (per-lane + uniform) / target tile (local index tl)
+        auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, uint32_t delta, int tl) {
+            constexpr bool CHECKED = decltype(checked)::value;
+            const int t = kt0 + tl;
+            YAT_LDS void* dst = (YAT_LDS void*)(smem + (tl & 1) * G::STAGE + (is_a ? 0 : G::A_BYTES) + pi * 1024);
+            const uint32_t soff = (uint32_t)t * (is_a ? a_kstep : b_kstep) + delta;
+            if (CHECKED) {
+                uint32_t v = voff + soff;
+                if (is_a && !A_T && kchunk_a >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
+                lds_dma16(is_a ? ra : rb, dst, v);
+            } else {
+                lds_dma16s(is_a ? ra : rb, dst, voff, soff);
+            }
+        };
+        // piece i of half h of the k-strided images / own-row piece j of the k-contiguous A image
+        auto dma_ah = [&](auto checked, int h, int i, int tl) {
+            dma(checked, true, pa0 + 8 * i + 16 * h, va0, (uint32_t)(16 * i + 32 * h) * a_row, tl);
+        };
+        auto dma_ao = [&](auto checked, int j, int tl) { dma(checked, true, pa0 + 4 * j, va0, (uint32_t)(32 * j) * (uint32_t)p.lda * 2, tl); };
+        auto dma_bh = [&](auto checked, int h, int i, int tl) {
+            if (NT == 4) dma(checked, false, pb0 + 8 * i + 16 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
+            else if (i < 2) dma(checked, false, pb0 + 10 * i + 20 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
+            else dma(checked, false, pbx + 20 * h, vbx, (uint32_t)(32 * h) * b_row, tl);
+        };
+        // batch(u), u = 2 t + kk: piece j of [own A rows of tile t + 2 (kk = 1, k-contiguous A)] [A half] [B half] where the
+        // half is u + 3 + GRP: tile t + (c >> 1), half c & 1 with c = kk + 3 + GRP
+        auto batch_count = [](int kk) constexpr { return (NAO && kk == 1 ? NAO : 0) + NAH + NB; };
+        auto batch_piece = [&](auto kk_c, auto fast_c, int t, int j) {
+            constexpr int KK = decltype(kk_c)::value;
+            constexpr bool FAST = decltype(fast_c)::value;
+            constexpr int C = KK + 3 + GRP, HV = C & 1, NOWN = (NAO && KK == 1) ? NAO : 0;
+            const bool own = j < NOWN;
+            const int tl = own ? t + 2 : t + (C >> 1);
+            auto go = [&](auto checked) {
+                if (own) dma_ao(checked, j, tl);
+                else if (j < NOWN + NAH) dma_ah(checked, HV, j - NOWN, tl);
+                else dma_bh(checked, HV, j - NOWN - NAH, tl);
+            };
+            if (FAST) go(std::false_type{});
+            else if (tl < nt) {
+                if (is_tail(tl)) go(std::true_type{});
+                else go(std::false_type{});
+            }
+        };
+        // counted waits (FAST iterations: every batch of the window was issued in full; otherwise vmcnt(0))
+        constexpr int PER_TILE = NAO + 2 * NAH + 2 * NB;                   // pieces per wave and K-tile = two consecutive batches
+        auto wait_g0 = [&](auto fast_c) {                                  // end of COMPUTE(u): batch(u - 2) landed
+            if (decltype(fast_c)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto wait_g1 = [&](auto kk_c, auto fast_c) {                       // end of LOAD(u): batch(u - 3) landed, and the own
+            constexpr int KK = decltype(kk_c)::value;                      // A rows of batch(u - 2) when u is odd
+            constexpr int N = NAO ? (KK == 1 ? 2 * NB : 2 * NB + NAO) : PER_TILE;
+            if (decltype(fast_c)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto compute_deep = [&](auto kk_c, auto fast_c, int t) {
+            constexpr int KK = decltype(kk_c)::value;
+            constexpr int NP = batch_count(KK);
+            static_assert((8 * NT) / GAP >= NP, "not enough MFMA slots for the DMA pieces of a batch");
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
+                    const int idx = i * NT + j;
+                    if (idx % GAP == GAP - 1 && idx / GAP < NP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        batch_piece(kk_c, fast_c, t, idx / GAP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (EPI == 4 && idx == 8 * NT - 1 && rs_wave) {
+                        bf16x8 ones;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) racc[q] = mfma16(ones, af[q], racc[q]);
+                    }
+                    if (idx == 8 * NT - 1) {
+                        if (GRP == 0) wait_g0(fast_c);
+                        YAT_PHASE_BARRIER();
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto iteration_deep = [&](auto fast_c, int t) {
+            // ---- sub-step 0
+            load_frags(grp_c, t, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (GRP == 1) wait_g1(std::integral_constant<int, 0>{}, fast_c);
+            YAT_PHASE_BARRIER();
+            compute_deep(std::integral_constant<int, 0>{}, fast_c, t);
+            // ---- sub-step 1
+            load_frags(grp_c, t, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (GRP == 1) wait_g1(std::integral_constant<int, 1>{}, fast_c);
+            YAT_PHASE_BARRIER();
+            compute_deep(std::integral_constant<int, 1>{}, fast_c, t);
+        };
+
+        // prologue: tile 0 in full (every wave its own pieces), then the batches a running loop would have issued for tile 1:
+        // group 0 batch(-1); group 1 batch(-2) and batch(-1) -- the counted waits of the first iterations count on them
+        {
+            auto all_of_tile0 = [&](auto checked) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (A_T) dma_ah(checked, j >> 1, j & 1, 0);
+                    else dma_ao(checked, j, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) dma_bh(checked, h, i, 0);
+            };
+            if (is_tail(0)) all_of_tile0(std::true_type{});
+            else all_of_tile0(std::false_type{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
+        if (GRP == 1) {
+#pragma unroll
+            for (int j = 0; j < batch_count(0); ++j) batch_piece(std::integral_constant<int, 0>{}, std::false_type{}, -1, j);
+        }
+#pragma unroll
+        for (int j = 0; j < batch_count(1); ++j) batch_piece(std::integral_constant<int, 1>{}, std::false_type{}, -1, j);
+        if (GRP == 1) YAT_PHASE_BARRIER();         // stagger: group 1 runs one segment behind group 0
+
+        const int nfast = max(0, nt - 2 - (ragged && kt0 + nt == nt_all ? 1 : 0));
+        int t = 0;
+        for (; t < nfast; ++t) iteration_deep(std::true_type{}, t);
+        for (; t < nt; ++t) iteration_deep(std::false_type{}, t);
+      };
+      if (grp == 0) deep_loop(std::integral_constant<int, 0>{});
+      else deep_loop(std::integral_constant<int, 1>{});
+    } else {
+
     issue(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
@@ -439,28 +654,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #ifdef YAT_GEMM_LOADPRIO
             __builtin_amdgcn_s_setprio(YAT_GEMM_LOADPRIO);
 #endif
-            if (!YAT_ABL_SKIP_READS || t == 0) {
-                const uint32_t st = lds0 + (t & 1) * G::STAGE;
-                if (A_T) {
-                    const uint32_t a0 = a_tr[0] + st + GRP * 256;            // group's rows = columns 128 GRP.. of the image
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) af[i] = frag_tr<BM>(a0 ^ (i << 5), kk);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) af[i] = frag256<false, BM>(cur, GRP * 128 + i * 16, kk, lane);
-                }
-                if (B_T && NT == 4) {
-                    const uint32_t b0 = b_tr[0] + st + G::A_BYTES;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b0 ^ (j << 5), kk);
-                } else if (B_T) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b_tr[j] + st + G::A_BYTES, kk);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bfr[j] = frag256<false, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
-                }
-            }
+            if (!YAT_ABL_SKIP_READS || t == 0) load_frags(grp_c, t, kk);
             if (YAT_GEMM_NT_READS_FIRST && kk == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 nt_issue();
@@ -502,10 +696,11 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     };
 #ifdef YAT_GEMM_STAMPS
     st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
-    const uint32_t st_loop_begin = st_prev;
+    st_loop_begin = st_prev;
 #endif
     if (grp == 0) k_loop(std::integral_constant<int, 0>{});
     else k_loop(std::integral_constant<int, 1>{});
+    }   // (!DEEP)
 #ifdef YAT_GEMM_STAMPS
     const uint32_t st_loop_end = (uint32_t)__builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && lane == 0) {

@@ -766,6 +766,10 @@ int launch_fwd_qs(const SdpaP& p, int B, hipStream_t stream) {
 }
 template <int KS, int DT, bool NOBIAS, bool ONES>
 int launch_fwd_x(const SdpaP& p, int B, int wide, hipStream_t stream) {
+    // the ONES form reads the row sums from output tile DT - 1: the ones column (column dh of the V image) must lie in it
+    if constexpr (ONES) {
+        if (!((DT - 1) * 16 <= p.dh && p.dh < DT * 16)) return YAT_EINVAL;
+    }
     if constexpr (NOBIAS && ONES && KS <= 3) {
         if (wide == 3) return launch_fwd_qs<KS, DT, 4, NOBIAS, ONES>(p, B, stream);      // 256-query workgroups
     }
@@ -786,7 +790,8 @@ int launch_fwd_nobias(const SdpaP& p, int B, int wide, hipStream_t stream) {
     if (dh == 32) return launch_fwd_x<1, 3, true, true>(p, B, wide, stream);
     if (dh == 64) return launch_fwd_x<2, 5, true, true>(p, B, wide, stream);
     if (dh > 64 && dh < 80) return launch_fwd_x<3, 5, true, true>(p, B, wide, stream);
-    if (dh > 96 && dh <= 112) return launch_fwd_x<4, 8, true, true>(p, B, wide, stream);
+    if (dh == 112) return launch_fwd_x<4, 8, true, true>(p, B, wide, stream);
+    // (dh 104 would need <4, 7>: its ones column sits in output tile 6, not 7 -- not a head dim of any model here)
     return -100;            // no ONES instantiation: the caller falls back to the head-dim classes
 }
 template <int KS, int DT, int QS>
