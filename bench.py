@@ -701,8 +701,8 @@ def main():
         }
         if comm is not None:
             res["comm"] = comm
-        if ops.ABLATE:                     # diagnostic run with kernel families skipped: NOT a measurement of the workload
-            res["invalid"] = f"YAT_ABLATE={','.join(sorted(ops.ABLATE))}: kernels skipped, wrong results, timing diagnostic only"
+        if getattr(ops, "DIAGNOSTIC_INVALID", None):   # set only by scripts/step_ablation.py (kernel families skipped): NOT a
+            res["invalid"] = ops.DIAGNOSTIC_INVALID     # measurement of the workload
         if timer:
             gf = sum(t[0] for t in timer)
             gms = sum(t[1].elapsed_time(t[2]) for t in timer)

@@ -92,6 +92,42 @@ def _ddp_worker(rank, world, port, tmp):
         assert abs(ddp_l.carried_loss.item() - want) < 1e-6 and torch.all(real.flat_grad == 1.5)
         assert torch.all(real.grad_tail == 0)
         ddp_l.carried_loss = None
+    # one rank's loss spikes to inf for ONE step: that step's logged mean is inf (as the reference's gather would show), and
+    # the next steps' are finite again -- the offset that travels only ever follows finite means (round-3 advisor finding)
+    for loss, want in ((float("inf") if rank == 1 else 0.5, float("inf")), (0.25 + rank, 0.75), (1.0, 1.0)):
+        real.flat_grad[:] = 1.0
+        ddp_l.track_loss(None)
+        real.loss_ready(torch.tensor([loss]))
+        for i in (3, 2, 1, 0):
+            real.grad_ready(i)
+        ddp_l.wait()
+        got = ddp_l.carried_loss.item()
+        assert (got == want) if want == float("inf") else abs(got - want) < 1e-6, (got, want)
+        ddp_l.carried_loss = None
+    assert torch.isfinite(ddp_l._loss_offset).all()
+    # a diagnostic pass that does not reduce (bench.py's dry pass) must not leave a per-rank offset behind
+    ddp_l.dryrun = True
+    real.flat_grad[:] = 1.0
+    ddp_l.track_loss(None)
+    real.loss_ready(torch.tensor([5.0 + rank]))
+    for i in (3, 2, 1, 0):
+        real.grad_ready(i)
+    ddp_l.wait()
+    ddp_l.dryrun, ddp_l.carried_loss = False, None
+    assert ddp_l._loss_offset is None
+    # YAT_LOSS_GATHER=1: the reference's own fp32 gather -- nothing is armed, mean_loss gathers
+    ddp_l.loss_gather = True
+    real.flat_grad[:] = 1.0
+    ddp_l.track_loss(None)
+    real.loss_ready(torch.tensor([2.0 + rank]))
+    for i in (3, 2, 1, 0):
+        real.grad_ready(i)
+    ddp_l.wait()
+    assert ddp_l.carried_loss is None and torch.all(real.grad_tail == 0)
+    acc_g = HipAccelerator(1, device="cpu")
+    acc_g.ddp = ddp_l
+    assert acc_g.mean_loss(torch.tensor(2.0 + rank)).item() == 2.5
+    ddp_l.loss_gather = False
     real.flat_grad[:] = 1.0                                   # not armed (bench.py): plain buckets, nothing carried
     real.loss_ready(torch.tensor([3.0]))
     for i in (3, 2, 1, 0):

@@ -235,3 +235,92 @@ def test_carried_loss_arithmetic_in_bf16():
         plain = (plain.float() + losses[r].to(BF).float()).to(BF)
     assert abs(got - want) < 2e-3 * want                 # 0.2 % of the loss
     assert abs(got - want) < 0.5 * abs((plain.float() / 8) - want) + 1e-4        # and better than carrying the bf16 loss itself
+
+
+def test_rescale_adapter_scale_and_the_whitelist_call_sites():
+    """common/trainer.py:270-281,385-397: `rescale_adapter_scale` is peft's context manager; the reference calls it bare, which
+    rescales nothing.  The helper itself must scale and restore; the trainer's call sites keep the reference's effective
+    behaviour by default and switch the adapter per timestep with YAT_ADAPTER_RESCALE=1."""
+    import types
+    from yat_amd.common import trainer as T
+    ad = types.SimpleNamespace(scale=0.5, _gate=torch.full((4,), 0.5))
+    with T.rescale_adapter_scale(ad, 0.0):
+        assert ad.scale == 0.0 and torch.all(ad._gate == 0.0)
+    assert ad.scale == 0.5 and torch.all(ad._gate == 0.5)
+    with pytest.raises(TypeError):
+        with T.rescale_adapter_scale(ad, "1"):
+            pass
+    with pytest.raises(ValueError):
+        with T.rescale_adapter_scale(None, 1.0):
+            pass
+    m = types.SimpleNamespace(adapters=ad, timesteps=[0, 500], _rescale_live=False, _rescale_cm=None)
+    m._set_adapter_scale = types.MethodType(T.Model._set_adapter_scale, m)
+    m._set_adapter_scale(0.0)
+    assert ad.scale == 0.5                                   # the reference's bare call: no effect
+    m._rescale_live = True
+    m._set_adapter_scale(0.0)
+    assert ad.scale == 0.0 and torch.all(ad._gate == 0.0)
+    m._set_adapter_scale(1.0)
+    assert ad.scale == 0.5 and m._rescale_cm is None
+    m._set_adapter_scale(0.0)
+    m._set_adapter_scale(0.0)                                # twice in a row: still the trained scaling times zero, restorable
+    m._set_adapter_scale(1.0)
+    assert ad.scale == 0.5 and torch.all(ad._gate == 0.5)
+
+
+def test_legacy_cache_files_written_by_the_reference(tmp_path):
+    """The two ``cache/{idx}.npy`` files under tests/golden/legacy_cache/ were written by the REFERENCE's own
+    CacheLoadFeatures.run (common/cache.py:54-85; tests/golden/make_legacy_cache_golden.py) -- a 7-row prompt and one that fills
+    all 300 rows.  This repo's reader must hand back exactly the inputs (tests/golden/legacy_cache_inputs.py), and its writer
+    must produce the tuple layout the reference produced."""
+    import gzip
+    import shutil
+    import sys
+    from yat_amd.common.shards import iter_legacy_cache, read_legacy_sample, write_legacy_sample
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    try:
+        from legacy_cache_inputs import sample
+    finally:
+        sys.path.remove(gold)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    for idx in (0, 1):
+        with gzip.open(os.path.join(gold, "legacy_cache", f"{idx}.npy.gz"), "rb") as f, open(cache / f"{idx}.npy", "wb") as g:
+            shutil.copyfileobj(f, g)
+    got = list(iter_legacy_cache(str(cache)))
+    assert [s["__key__"] for s in got] == ["0", "1"]
+    for idx, s in enumerate(got):
+        ratio, lat, rows = sample(idx)
+        emb = torch.cat(rows)                                                    # [L, 2304] bf16, small integers
+        assert s["ratio"] == pytest.approx(float(ratio)) and isinstance(s["ratio"], float)
+        assert s["latent.pt"].dtype == torch.bfloat16 and torch.equal(s["latent.pt"], lat[0])
+        assert s["emb.pt"].shape == emb.shape and torch.equal(s["emb.pt"].to(torch.bfloat16), emb)
+        # what the reference wrote, field by field: fp32 embeddings zero-padded to 300 rows, a float mask, the squeezed latent
+        r_ref, l_ref, (e_ref, m_ref) = torch.load(str(cache / f"{idx}.npy"), weights_only=False)
+        assert e_ref.shape == (300, 2304) and e_ref.dtype == torch.float32 and m_ref.shape == (300,) and m_ref.dtype == torch.float32
+        assert int(m_ref.sum()) == emb.shape[0] and l_ref.shape == lat.shape[1:]
+        # ... and this repo's writer produces the same tuple for the same sample (padding, mask, latent; embeddings in the
+        # dtype it is handed: the reference's zero buffer makes them fp32)
+        write_legacy_sample(str(tmp_path / "mine.npy"), float(ratio), lat[0], emb.float())
+        r2, l2, (e2, m2) = torch.load(str(tmp_path / "mine.npy"), weights_only=False)
+        assert torch.equal(e2, e_ref) and torch.equal(m2, m_ref) and torch.equal(l2, l_ref) and float(r2) == pytest.approx(float(r_ref))
+    assert read_legacy_sample(str(cache / "1.npy"))["emb.pt"].shape[0] == 300
+
+
+def test_reference_nccl_environment_is_not_inherited():
+    """utils/set_nccl_vars.py exports six NCCL_* variables (tests/golden/nccl_vars.json: produced by importing the reference's
+    module); yat_amd/ddp.py states for each why this build does not inherit it, and nothing in the package sets one."""
+    import json
+    import subprocess
+    import sys
+    from yat_amd.ddp import REFERENCE_NCCL_ENV_NOT_INHERITED as table
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "nccl_vars.json")) as f:
+        ref = json.load(f)
+    assert set(ref) == set(table) and ref["NCCL_P2P_DISABLE"] == "1"
+    code = ("import os, sys; sys.path.insert(0, %r); import yat_amd.ddp, yat_amd.common.trainer as T; "
+            "T.HipAccelerator(1, device='cpu'); print(sorted(k for k in os.environ if k.startswith('NCCL_')))" % root)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("NCCL_")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.strip().splitlines()[-1] == "[]"

@@ -38,6 +38,33 @@ def _hipcc() -> str:
 
 PLAN_GEN_VERSION = "1"
 
+# Sources whose device assembly is kept (-save-temps) for a structural check after the compile.
+ASM_CHECKED = {"dwconv_glu.hip"}
+
+
+def check_dwconv_stream_asm(asm_path: str, sseg: int = 4) -> None:
+    """csrc/dwconv_tile_fwd.inc, dwglu_stream_kernel: the LDS-DMA prefetch of the next rows is awaited with ``s_waitcnt
+    vmcnt(3*SSEG)`` -- correct only while every wave issues EXACTLY 3*SSEG vector-memory operations (the u / y stores) after
+    the prefetch in every step.  A compiler that spills, splits or merges a store, or adds any other vector-memory
+    operation to the loop would make the wait return early and the kernel read stale ring rows without any test on this
+    toolchain noticing (round-3 advisor finding).  Fail the BUILD instead: the kernel must contain exactly 3*SSEG buffer
+    stores, the counted wait, no scratch / flat operation, and no plain load after the first LDS-DMA."""
+    text = open(asm_path).read().split("\n")
+    start = next((i for i, l in enumerate(text) if re.match(r"^_Z\S*dwglu_stream_kernel\S*:", l)), None)
+    if start is None:
+        raise RuntimeError("dwglu_stream_kernel not found in " + asm_path)
+    end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])
+    ins = [l.strip() for l in text[start:end] if l.strip() and not l.strip().startswith((";", "."))]
+    stores = [l for l in ins if re.match(r"(buffer|global)_store", l)]
+    bad = [l for l in ins if l.startswith(("scratch_", "flat_")) or re.match(r"(buffer|global)_atomic", l)]
+    first_dma = next((i for i, l in enumerate(ins) if l.startswith("buffer_load") and " lds" in l), None)
+    late_loads = [l for l in ins[first_dma:] if re.match(r"(buffer|global)_load", l) and " lds" not in l] if first_dma is not None else ["<no LDS-DMA>"]
+    waits = [l for l in ins if re.match(rf"s_waitcnt vmcnt\({3 * sseg}\)", l)]
+    if len(stores) != 3 * sseg or bad or late_loads or len(waits) != 1:
+        raise RuntimeError(f"dwglu_stream_kernel no longer matches its `s_waitcnt vmcnt({3 * sseg})`: {len(stores)} stores "
+                           f"(want {3 * sseg}), {len(waits)} counted wait(s) (want 1), scratch/flat/atomic ops {bad[:3]}, loads after "
+                           f"the first LDS-DMA {late_loads[:3]} -- fix the kernel or fall back to vmcnt(0) there")
+
 
 def generate_plan_dispatch(out_path: str) -> None:
     """include/yat_hip.h -> build/plan_dispatch.inc: one trampoline per int-returning entry point that unpacks a
@@ -87,6 +114,7 @@ def _digest() -> str:
             with open(path, "rb") as f:
                 h.update(f.read())
     h.update(PLAN_GEN_VERSION.encode())
+    h.update(repr(sorted(ASM_CHECKED)).encode())
     h.update(" ".join(FLAGS).encode())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
@@ -109,11 +137,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # -Rpass-analysis=kernel-resource-usage: per-kernel VGPRs / spills / scratch as compiler remarks (free), kept in
         # build/resources.json.  A kernel that silently starts using scratch (an innocent-looking epilogue branch did that
         # to every 256x320 GEMM once: +11 ms per step) fails the build instead of the benchmark.
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+        temps = os.path.join(objdir, "temps_" + src.replace(".hip", ""))
+        keep_asm = src in ASM_CHECKED
+        if keep_asm:
+            os.makedirs(temps, exist_ok=True)
+            obj_out = os.path.join(temps, src.replace(".hip", ".o"))       # (-save-temps=obj: the temporaries land beside it)
+        else:
+            obj_out = obj
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-Rpass-analysis=kernel-resource-usage",
+               *(["-save-temps=obj"] if keep_asm else []), "-c", os.path.join(CSRC, src), "-o", obj_out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if keep_asm:
+            import shutil
+            asm = [f for f in os.listdir(temps) if f.endswith(".s") and "amdgcn" in f]
+            if len(asm) != 1:
+                raise RuntimeError(f"{src}: expected one device assembly file in {temps}, found {asm}")
+            if src == "dwconv_glu.hip":
+                check_dwconv_stream_asm(os.path.join(temps, asm[0]))
+            shutil.copyfile(obj_out, obj)
+            shutil.rmtree(temps, ignore_errors=True)
         cur = None
         for line in r.stderr.splitlines():
             m = re.search(r"remark:\s+Function Name: (\S+)", line)

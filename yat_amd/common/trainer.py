@@ -34,6 +34,30 @@ from ..optim import FlatAdamW
 from .aspect_ratios import ASPECT_RATIO_1024_BIN, ASPECT_RATIO_512_BIN
 
 
+@contextlib.contextmanager
+def rescale_adapter_scale(adapters, multiplier):
+    """``peft.helpers.rescale_adapter_scale(model, multiplier)`` [RECALL: a ``@contextmanager``]: inside the ``with`` block every
+    adapter's scaling is multiplied by ``multiplier``; the original scaling comes back on exit.  ``adapters`` is this build's
+    adapter set (yat_amd/lora.py, lokr.py, loha.py, dora.py: they read ``.scale`` at every launch; LoRA also keeps it in a
+    device vector for the GEMM epilogue).  Like peft it refuses a model without adapters and a non-numeric multiplier."""
+    if not isinstance(multiplier, (float, int)):
+        raise TypeError(f"Argument multiplier should be of type float, got {type(multiplier)}")
+    if adapters is None or not hasattr(adapters, "scale"):
+        raise ValueError("scaling is only supported for models with adapters")
+    original = adapters.scale
+
+    def put(v):
+        adapters.scale = v
+        gate = getattr(adapters, "_gate", None)
+        if gate is not None:
+            gate.fill_(v)
+    put(original * multiplier)
+    try:
+        yield
+    finally:
+        put(original)
+
+
 class HipAccelerator:
     """The slice of accelerate.Accelerator the reference trainer touches, natively."""
 
@@ -165,6 +189,21 @@ class Model:
                 idx = [random.choice(self.timesteps) for _ in range(batch_size)]
                 return self.scheduler.timesteps[idx].to(self.accelerator.device)
             self.get_timesteps = get_timesteps_from_list
+        # :270-281 -- with a timestep whitelist the samplers get a per-step callback that is MEANT to switch the adapter on for
+        # the whitelisted timesteps only.  In the reference the body is ``rescale_adapter_scale(self.model, 1.0 | 0.0)`` as a
+        # bare call: peft's helper is a context manager, a bare call builds the manager and drops it, nothing is rescaled --
+        # and of the entry points only train_sdxl.py:107 hands the callback to its pipeline at all.  This build keeps the
+        # reference's EFFECTIVE behaviour by default (same call sites, same no-op) and does what the code meant with
+        # YAT_ADAPTER_RESCALE=1 (the multiplier then stays in force until the next call, as a setter would).
+        self._rescale_live = os.environ.get("YAT_ADAPTER_RESCALE", "0") != "0"
+        self._rescale_cm = None
+        self.validation_step_callback = None
+        if self.timesteps:
+            def step_callback(pipe, step, timestep, callback_kwargs):
+                t = timestep.item() if hasattr(timestep, "item") else timestep
+                self._set_adapter_scale(1.0 if t in self.timesteps else 0.0)
+                return callback_kwargs
+            self.validation_step_callback = step_callback
         # per-rank shard range (:66-84)
         n = params.num_shards
         if getattr(params, "dreambooth_dataset_folder", None) is None and n is not None and n >= self.num_processes:
@@ -401,6 +440,18 @@ class Model:
         self.flush_log()
         self.finalize()
 
+    def _set_adapter_scale(self, multiplier):
+        """The reference's ``rescale_adapter_scale(self.model, multiplier)`` call sites (:274, :276, :388, :390, :397)."""
+        cm = rescale_adapter_scale(getattr(self, "adapters", None), multiplier) if getattr(self, "adapters", None) is not None \
+            else None
+        if not self._rescale_live or cm is None:
+            return                                          # the reference: the manager is built and dropped, nothing changes
+        if self._rescale_cm is not None:
+            self._rescale_cm.__exit__(None, None, None)     # back to the trained scaling before the next multiplier applies
+        self._rescale_cm = cm if multiplier != 1.0 else None
+        if self._rescale_cm is not None:
+            self._rescale_cm.__enter__()
+
     def flush_log(self):
         """:362-369 -- ``add_scalar('train/loss' | 'train/lr', v, step)``; one device->host copy for the whole queue."""
         queue, self._log_queue = self._log_queue, []
@@ -430,10 +481,14 @@ class Model:
                 if opt.ema_shadow is not None:
                     stored = trained.flat_param.clone()
                     trained.flat_param.copy_(opt.ema_shadow)
+                if self.timesteps:                          # :385-390 the first inference step's setting
+                    self._set_adapter_scale(1.0 if 0 in self.timesteps else 0.0)
                 try:
                     self.validate()
                 except NotImplementedError:
                     pass
+                if self.timesteps:                          # :396-397
+                    self._set_adapter_scale(1.0)
                 self.save_model()
                 if stored is not None:
                     trained.flat_param.copy_(stored)

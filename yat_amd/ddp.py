@@ -22,6 +22,21 @@ import torch
 import torch.distributed as dist
 
 
+# What the reference exports before it builds its process group (utils/set_nccl_vars.py:4-9, imported by its launch scripts;
+# common/trainer.py:27-28 sets the first two again) and what this build does with each: NONE is inherited.  The values were
+# chosen for the author's two PCIe RTX 4070s; on an MI355X node every one of them is wrong or pointless.
+# tests/test_host_logic.py holds this table to the variables the reference module really sets (tests/golden/nccl_vars.json).
+REFERENCE_NCCL_ENV_NOT_INHERITED = {
+    "NCCL_P2P_DISABLE": "xGMI IS the peer-to-peer path: with it off RCCL stages every gradient bucket through host memory",
+    "NCCL_IB_DISABLE": "one node, no InfiniBand in the data path; left to the site's own environment",
+    "NCCL_SOCKET_IFNAME": "'eth0' need not exist; the bootstrap runs over loopback (MASTER_ADDR 127.0.0.1)",
+    "NCCL_BLOCKING_WAIT": "would make every collective block the host thread: the bucket all-reduces are enqueued on a side "
+                          "stream and overlap the backward (async_op=True), which blocking waits defeat",
+    "NCCL_ASYNC_ERROR_HANDLING": "a deprecated alias; torch's own default error handling for the process group stays in force",
+    "NCCL_DEBUG": "INFO makes RCCL print on stdout, where bench.py's one JSON line lives",
+}
+
+
 class NativeComm:
     """The C-ABI transport (include/yat_hip.h, communication section): one RCCL communicator owned by libyat_hip.so.
     Rendezvous: rank 0 draws the 128-byte id and ships it over the launcher's process group (any backend) -- or nowhere in
@@ -121,6 +136,10 @@ class HipDDP:
         self._tail = tail if (tail is not None and tail.numel() >= 2 and hasattr(model, "_grad_store")) else None
         self._loss_acc, self._track, self._tail_armed, self._tail_sent = None, False, False, False
         self._loss_offset = None             # previous step's carried mean (device scalar, the same on every rank)
+        # which value train/loss shows under data parallel: the carried one (default: bf16 head + remainder of the difference
+        # to the previous mean, ~1e-4 relative at eight ranks) or, with YAT_LOSS_GATHER=1, exactly the reference's fp32
+        # gather(avg_loss).mean() at the price of its per-step collective
+        self.loss_gather = os.environ.get("YAT_LOSS_GATHER", "0") != "0"
         self.carried_loss = None
         if self._tail is not None:
             model.loss_ready = self.on_loss
@@ -135,7 +154,10 @@ class HipDDP:
 
     def track_loss(self, running_sum=None):
         """Arm the piggyback for the coming micro-step; ``running_sum``: the window's earlier micro-step losses (device
-        scalar) that ``gather(avg_loss)`` would have included, or None."""
+        scalar) that ``gather(avg_loss)`` would have included, or None.  ``YAT_LOSS_GATHER=1`` keeps the reference's own
+        fp32 collective instead (common/trainer.py:359): nothing is armed and ``HipAccelerator.mean_loss`` gathers."""
+        if self.loss_gather:
+            return
         self._loss_acc, self._track = running_sum, True
 
     def on_loss(self, loss):
@@ -151,7 +173,7 @@ class HipDDP:
         if self._loss_offset is not None:
             x = x - self._loss_offset.to(x.device)
         hi = x.to(self._tail.dtype)
-        lo = (x - hi.float()).to(self._tail.dtype)
+        lo = torch.where(torch.isfinite(hi.float()), x - hi.float(), torch.zeros_like(x)).to(self._tail.dtype)   # (inf - inf)
         self._tail[0:2].copy_(torch.stack([hi, lo]))
         self._tail_armed = True
 
@@ -265,8 +287,21 @@ class HipDDP:
         if self._loss_offset is not None:
             v = v + self._loss_offset.to(v.device)
         self.carried_loss = v
-        self._loss_offset = v.detach().clone()
+        if self.dryrun:
+            # the tail was not reduced: v is this rank's own value, and an offset taken from it would differ between ranks
+            self._loss_offset = None
+        else:
+            # A non-finite loss must not poison every later step (inf - inf = nan in the difference that travels): the offset
+            # only ever follows finite means -- the reference's gather(avg_loss).mean() recovers on the next step, so does
+            # this.  On the device, no host sync; every rank sees the same reduced v and takes the same branch.
+            prev = self._loss_offset.to(v.device) if self._loss_offset is not None else torch.zeros_like(v)
+            self._loss_offset = torch.where(torch.isfinite(v), v, prev).detach().clone()
         self._tail.zero_()
+
+    def reset_loss_offset(self):
+        """Forget the previous step's mean (checkpoint resume, a diagnostic pass that did not reduce): the next carried loss
+        travels as the plain value again.  Must be called on every rank at the same step."""
+        self._loss_offset = None
 
     def all_reduce_scalar_mean(self, t):
         """accelerator.gather(avg_loss).mean() (trainer.py:359) as one tiny all-reduce."""

@@ -49,6 +49,10 @@ def compute_stream(device):
 GRAD_TAIL = 8        # 16 bytes: the flat gradient buffer stays a whole number of 16-byte vectors
 
 
+# diagnostic hook (scripts/step_ablation.py): called on every new arena buffer; None in a product run
+ARENA_INIT = None
+
+
 class FlatParamModule(nn.Module):
     def _alloc_flat(self, specs, device):
         """``specs``: [(diffusers key, shape)] in forward-execution order."""
@@ -143,8 +147,8 @@ class FlatParamModule(nn.Module):
             if t is not None:
                 self._plans.clear()       # a buffer moves: every recorded plan may hold its old address
             t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
-            if os.environ.get("YAT_ARENA_FILL") and t.is_floating_point():      # diagnostic runs that skip kernels (ops.ABLATE):
-                t.normal_(0.0, 0.5)                                             # realistic operand statistics, no NaNs
+            if ARENA_INIT is not None:                                          # (scripts/step_ablation.py only)
+                ARENA_INIT(t)
             self._arena[name] = t
         return t[:n].view(shape)
 

@@ -69,15 +69,6 @@ class Recorder:
 
 RECORDER = None
 
-# Diagnostic only (scripts/gpu_step_ablation.sh): YAT_ABLATE=name,name skips whole kernel families -- WRONG results, only the
-# step time is read -- to see how much of the step each family's chip time is worth on this schedule (a kernel made x us
-# faster alone buys anything between 0 and x in the step: they run beside GEMMs of another stream).  Never set in a product run.
-ABLATE = frozenset(x for x in os.environ.get("YAT_ABLATE", "").split(",") if x)
-if ABLATE:
-    import sys as _sys
-    print(f"[yat_amd] YAT_ABLATE={','.join(sorted(ABLATE))}: these kernel families are SKIPPED -- results are wrong, timing diagnostic only",
-          file=_sys.stderr, flush=True)
-
 # Packed text rows (yat_amd/sana.py forward_impl, kv_off): the number of text rows changes from batch to batch, and a launch
 # plan must not be keyed by it (every new (bucket, row count) pair would be a fresh recording).  Inside ``with
 # text_rows(n):`` the wrappers below mark the argument that carries the row count -- M of a forward / dgrad GEMM, K of a
@@ -438,8 +429,6 @@ def ln_modulate_fwd(x2d, shift, scale, mod_ld, rows_per_batch, eps, y=None, mean
     y = y if y is not None else torch.empty_like(x2d)
     mean = mean if mean is not None else torch.empty(M, dtype=torch.float32, device=dev)
     rstd = rstd if rstd is not None else torch.empty(M, dtype=torch.float32, device=dev)
-    if "ln" in ABLATE:
-        return y, mean, rstd
     rc = _lib().yat_ln_modulate_fwd(M, D, rows_per_batch, eps, _p(x2d), _p(shift), _p(scale), mod_ld, _p(y), _p(mean),
                                     _p(rstd), _stream())
     _l.check(rc, "yat_ln_modulate_fwd")
@@ -454,8 +443,6 @@ def ln_modulate_bwd(x2d, mean, rstd, scale, mod_ld, rows_per_batch, dy, dres, dx
                     workspace, parts=3):
     """parts: 1 = dx only, 2 = dshift/dscale accumulators only, 3 = both (see include/yat_hip.h)."""
     M, D = x2d.shape
-    if "ln" in ABLATE:
-        return dx
     rc = _lib().yat_ln_modulate_bwd(M, D, rows_per_batch, _p(x2d), _p(mean), _p(rstd), _p(scale), mod_ld, _p(dy),
                                     _p(dres), _p(dx), _p(dshift_acc), _p(dscale_acc), acc_ld, _p(workspace), parts,
                                     _stream())
@@ -485,8 +472,6 @@ def gate_bwd(dout, lin, gate, gate_ld, rows_per_batch, dlin, dgate_acc, acc_ld, 
              accumulate_bias=False):
     """dlin = gate * dout, dgate += sum dout * lin; ``dbias`` (optional) (+)= column sum of dlin in the same pass."""
     M, D = dout.shape
-    if "gate" in ABLATE:
-        return
     rc = _lib().yat_gate_bwd(M, D, rows_per_batch, _p(dout), _p(lin), _p(gate), gate_ld, _p(dlin), _p(dgate_acc), acc_ld,
                              _p(dbias), int(accumulate_bias), _p(workspace), _stream())
     _l.check(rc, "yat_gate_bwd")
@@ -498,8 +483,6 @@ def linear_attn_workspace_bytes(B, N, H):
 
 
 def linear_attn_fwd(qkv2d, B, N, H, k_off, v_off, out, workspace):
-    if "la" in ABLATE:
-        return out
     rc = _lib().yat_linear_attn_fwd(B, N, H, _p(qkv2d), qkv2d.stride(0), k_off, v_off, _p(out), out.stride(0),
                                     _p(workspace), _stream())
     _l.check(rc, "yat_linear_attn_fwd")
@@ -507,8 +490,6 @@ def linear_attn_fwd(qkv2d, B, N, H, k_off, v_off, out, workspace):
 
 
 def linear_attn_bwd(qkv2d, B, N, H, k_off, v_off, dout, dqkv, workspace, state=None):
-    if "la" in ABLATE:
-        return dqkv
     rc = _lib().yat_linear_attn_bwd(B, N, H, _p(qkv2d), qkv2d.stride(0), k_off, v_off, _p(dout), dout.stride(0),
                                     _p(dqkv), dqkv.stride(0), _p(state), _p(workspace), _stream())
     _l.check(rc, "yat_linear_attn_bwd")
@@ -521,8 +502,6 @@ def sdpa_fwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, lse, k
     (include/yat_hip.h: yat_sdpa_fwd_packed).  ``key_bias`` None (then ``kv_len`` None too): plain attention over all T
     keys -- self-attention; same result as a zero bias, on the kernels' no-bias instantiations."""
     assert k2d.stride(0) == v2d.stride(0)
-    if "sdpa" in ABLATE:
-        return out
     if key_bias is None and (kv_len is not None or kv_off is not None):
         raise ValueError("sdpa: no key bias means every key of every image attends (no kv_len, no packed keys)")
     if kv_off is not None:
@@ -550,8 +529,6 @@ def sdpa_bwd(q2d, k2d, v2d, B, N, T, H, dh, scale, key_bias, kv_len, out, dout, 
     ``sdpa_fwd`` (dk / dv share the packed row layout; rows outside the images' ranges are left alone).  ``key_bias`` None:
     as in ``sdpa_fwd``."""
     assert k2d.stride(0) == v2d.stride(0) and dk.stride(0) == dv.stride(0)
-    if "sdpa" in ABLATE:
-        return
     if key_bias is None and (kv_len is not None or kv_off is not None or work is not None):
         raise ValueError("sdpa: no key bias means every key of every image attends (no kv_len, no work list, no packed keys)")
     if kv_off is not None:
@@ -613,8 +590,6 @@ def joint_rows(joint, img, txt, B, N, T, to_joint):
 def dwconv_glu_fwd(s, B, h, w, Hc, wdw, bdw, y, u_out=None):
     """s = bf16(SiLU(conv_inverted output)) as written by the GEMM epilogue; ``u_out`` (optional [M, 2Hc]) keeps the conv
     output for the backward (see ``linear_dgrad_glu`` / ``dwconv_glu_bwd(du=...)``)."""
-    if "dwfwd" in ABLATE:
-        return y
     rc = _lib().yat_dwconv_glu_fwd(B, h, w, Hc, _p(s), _p(wdw), _p(bdw), _p(y), _p(u_out), _stream())
     _l.check(rc, "yat_dwconv_glu_fwd")
     return y
@@ -627,8 +602,6 @@ def dwconv_glu_bwd_workspace_bytes(B, h, w, Hc):
 def dwconv_glu_bwd(s, z, B, h, w, Hc, wdw, bdw, dy, dz, dwdw, dbdw, workspace, accumulate=False, dz_colsum=None, du=None):
     """``dz_colsum`` (optional, [2Hc]) (+)= column sum of dz (the conv_inverted bias gradient) in the same pass.
     ``du`` (optional [M, 2Hc]): the GLU backward already applied (``linear_dgrad_glu``); ``dy`` may then be None."""
-    if "dwbwd" in ABLATE:
-        return
     rc = _lib().yat_dwconv_glu_bwd(B, h, w, Hc, _p(s), _p(z), _p(wdw), _p(bdw), _p(dy), _p(dz), _p(dwdw), _p(dbdw),
                                    _p(dz_colsum), int(accumulate), _p(workspace), _p(du), _stream())
     _l.check(rc, "yat_dwconv_glu_bwd")
@@ -781,8 +754,6 @@ def gradnorm_workspace_bytes(n, nseg):
 
 def gradnorm_clip(grad_flat, seg_start_i64, max_norm, norm_out, clip_coef, workspace):
     nseg = seg_start_i64.numel() - 1
-    if "adamw" in ABLATE:
-        return
     rc = _lib().yat_gradnorm_clip(grad_flat.numel(), _p(grad_flat), nseg, _p(seg_start_i64), max_norm, _p(norm_out),
                                   _p(clip_coef), _p(workspace), _stream())
     _l.check(rc, "yat_gradnorm_clip")
@@ -790,8 +761,6 @@ def gradnorm_clip(grad_flat, seg_start_i64, max_norm, norm_out, clip_coef, works
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, clip_coef, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True,
                ema_shadow=None, ema_decay=0.0, background=0):
-    if "adamw" in ABLATE:
-        return
     rc = _lib().yat_adamw_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(clip_coef), lr, beta1,
                                beta2, eps, weight_decay, step, int(zero_grad), _p(ema_shadow), ema_decay, int(background),
                                _stream())

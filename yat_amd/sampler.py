@@ -33,9 +33,11 @@ def inference_schedule(sched: FlowMatchSchedule, num_inference_steps: int):
 @torch.no_grad()
 def sample_latents(model, prompt_embeds, prompt_mask, negative_embeds, negative_mask, height, width, *,
                    num_inference_steps=20, guidance_scale=5.0, generator=None, schedule: FlowMatchSchedule | None = None,
-                   latents=None):
+                   latents=None, callback_on_step_end=None):
     """prompt_embeds / negative_embeds: [B, T, C] bf16, masks [B, T] (1 keep); height, width in latent pixels.
-    Returns latents [B, C_in, height, width] (bf16, on the model's device)."""
+    Returns latents [B, C_in, height, width] (bf16, on the model's device).  ``callback_on_step_end(pipe, step, timestep,
+    callback_kwargs)`` is the diffusers pipelines' hook of the same name, called after every step (the trainer's
+    ``validation_step_callback``, common/trainer.py:270-281; of the reference's entry points only train_sdxl.py:107 passes it)."""
     sched = schedule or FlowMatchSchedule()
     dev = model.device
     B = prompt_embeds.shape[0]
@@ -59,6 +61,8 @@ def sample_latents(model, prompt_embeds, prompt_mask, negative_embeds, negative_
             v_u, v_c = v.float().chunk(2)
             v = (v_u + guidance_scale * (v_c - v_u)).to(BF16)       # the pipeline combines in the model dtype
         latents = (latents.float() + (float(sigmas[i + 1]) - float(sigmas[i])) * v.float()).to(BF16)
+        if callback_on_step_end is not None:
+            callback_on_step_end(None, i, timesteps[i], {})
     return latents
 
 
