@@ -415,11 +415,15 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #ifndef YAT_GEMM_DEEP
 #define YAT_GEMM_DEEP 1
 #endif
+#ifndef YAT_GEMM_DEEP_NN
+#define YAT_GEMM_DEEP_NN 0          // measured (profiles/r04_c_*): cold operands -2 %, the step +0.4 % (76.6 -> 76.9 ms): off
+#endif
 #ifdef YAT_GEMM_STAMPS
     uint32_t st_loop_begin = 0;
-    constexpr bool DEEP = false;                           // (the stamp slots describe the two-stage schedule)
+    constexpr bool DEEP = false, DEEP_NN = false;          // (the stamp slots describe the two-stage schedule)
 #else
     constexpr bool DEEP = YAT_GEMM_DEEP && B_T;            // the DEEP schedule of the header comment: k-strided B (nt, tt)
+    constexpr bool DEEP_NN = YAT_GEMM_DEEP_NN && !A_T && !B_T;
 #endif
     if constexpr (DEEP) {
       auto deep_loop = [&](auto grp_c) {
@@ -436,11 +440,19 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         //   k-strided 256-column image (A; B of the 256-wide tile): piece = wave + 8 i + 16 h   -> k-row delta 16 i + 32 h
         //   k-strided 320-column image: 20 pieces per half = classes {q, q + 10}; group 0 wave wc: class wc; group 1 wave wc:
         //                               class 4 + wc and one piece of classes 8 / 9 (8, 18, 9, 19)       -> deltas 16 i + 32 h
-        //   k-contiguous A, own rows:   piece = 16 GRP + wc + 4 j                                       -> row delta 32 j
+        //   k-contiguous A, own rows:   piece = 16 GRP + wc + 4 j                                       -> own offsets (below)
         const int pa0 = A_T ? wave : 16 * GRP + wc;
         const int pb0 = NT == 4 ? wave : (GRP ? 4 + wc : wc);
         const int pbx = 8 + (wc >> 1) + 10 * (wc & 1);                     // (320 columns, group 1: 8, 18, 9, 19)
         const uint32_t va0 = make_piece<A_T, BM>(pa0, lane, p.lda, m0, p.M).voff;
+        // (k-contiguous A: the pieces of a wave are 32 ROWS of M apart, and a scalar-offset delta is outside the buffer range
+        // check -- past the last row of a ragged M it would read beyond the operand.  They keep their own per-lane offsets,
+        // each with make_piece's row check.)
+        uint32_t vao[A_T ? 1 : 4];
+        if (!A_T) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vao[j] = j == 0 ? va0 : make_piece<false, BM>(pa0 + 4 * j, lane, p.lda, m0, p.M).voff;
+        }
         const uint32_t vb0 = make_piece<true, G::BN>(pb0, lane, p.ldb, n0, p.N).voff;
         const uint32_t vbx = NB == 3 ? make_piece<true, G::BN>(pbx, lane, p.ldb, n0, p.N).voff : 0;
         const uint32_t a_row = (uint32_t)p.lda * 2, b_row = (uint32_t)p.ldb * 2;           // bytes per k-row (k-strided)
@@ -464,7 +476,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         auto dma_ah = [&](auto checked, int h, int i, int tl) {
             dma(checked, true, pa0 + 8 * i + 16 * h, va0, (uint32_t)(16 * i + 32 * h) * a_row, tl);
         };
-        auto dma_ao = [&](auto checked, int j, int tl) { dma(checked, true, pa0 + 4 * j, va0, (uint32_t)(32 * j) * (uint32_t)p.lda * 2, tl); };
+        auto dma_ao = [&](auto checked, int j, int tl) { dma(checked, true, pa0 + 4 * j, vao[A_T ? 0 : j], 0u, tl); };
         auto dma_bh = [&](auto checked, int h, int i, int tl) {
             if (NT == 4) dma(checked, false, pb0 + 8 * i + 16 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
             else if (i < 2) dma(checked, false, pb0 + 10 * i + 20 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
@@ -582,6 +594,90 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
       };
       if (grp == 0) deep_loop(std::integral_constant<int, 0>{});
       else deep_loop(std::integral_constant<int, 1>{});
+    } else if constexpr (DEEP_NN) {
+      // Both operands k-contiguous (the forward GEMMs): a 128-B row carries both 32-deep halves, so nothing can be refilled
+      // per half.  What the two-stage ring still allows: the pieces of tile t+1 go out at the top of LOAD(t, ks0) as before, but
+      //   * a group loads its OWN 128 rows of A (nobody else reads them), so their wait moves from the end of LOAD(t, ks1) to
+      //     the end of COMPUTE(t, ks1) -- the rendezvous right before the group's first read;
+      //   * group 0, whose COMPUTE(t, ks1) ends with the rendezvous that precedes every first read of tile t+1, waits for ALL
+      //     its pieces there and takes 7 of every 10 B pieces; group 1 keeps the earlier wait for its 3 (B first, counted).
+      // 60 of a tile's 72 pieces get 4 segments to land instead of 3; images, reads and MFMA order unchanged (bit-identical).
+      auto nn_loop = [&](auto grp_c) {
+        constexpr int GRP = decltype(grp_c)::value;
+        constexpr int NB0 = NT == 5 ? 7 : 6, NB1 = NT == 5 ? 3 : 2, NBW = GRP == 0 ? NB0 : NB1;
+        static_assert(4 * NB0 + 4 * NB1 == G::B_BYTES / 1024, "B pieces per tile");
+        const int pa0 = 16 * GRP + wc, pb0 = (GRP ? 4 * NB0 : 0) + wc;
+        uint32_t vao[4], vbw[NBW];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vao[j] = make_piece<false, BM>(pa0 + 4 * j, lane, p.lda, m0, p.M).voff;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) vbw[j] = make_piece<false, G::BN>(pb0 + 4 * j, lane, p.ldb, n0, p.N).voff;
+        const uint32_t kch = swz128((uint32_t)wc * 8 + (lane >> 3), lane & 7);      // (the same for every piece above)
+        auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, int tl) {
+            constexpr bool CHECKED = decltype(checked)::value;
+            const int t = kt0 + tl;
+            YAT_LDS void* dst = (YAT_LDS void*)(smem + (tl & 1) * G::STAGE + (is_a ? 0 : G::A_BYTES) + pi * 1024);
+            if (CHECKED) {
+                uint32_t v = voff + (uint32_t)t * (uint32_t)(BK * 2);
+                if (kch >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
+                lds_dma16(is_a ? ra : rb, dst, v);
+            } else {
+                lds_dma16s(is_a ? ra : rb, dst, voff, (uint32_t)t * (uint32_t)(BK * 2));
+            }
+        };
+        auto issue_tile = [&](auto checked, int tl) {           // B first: group 1 waits for them one segment earlier
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) dma(checked, false, pb0 + 4 * j, vbw[j], tl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma(checked, true, pa0 + 4 * j, vao[j], tl);
+        };
+        auto compute_nn = [&](bool wait_all) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
+                    if (i * NT + j == 8 * NT - 1) {
+                        if (wait_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        YAT_PHASE_BARRIER();
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto iteration_nn = [&](auto fast_c, int t) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            if (FAST) issue_tile(std::false_type{}, t + 1);
+            else if (t + 1 < nt) {
+                if (is_tail(t + 1)) issue_tile(std::true_type{}, t + 1);
+                else issue_tile(std::false_type{}, t + 1);
+            }
+            load_frags(grp_c, t, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            YAT_PHASE_BARRIER();
+            compute_nn(false);
+            load_frags(grp_c, t, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (GRP == 1) {                                      // its B pieces of tile t+1 (issued first) have landed
+                if (FAST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            YAT_PHASE_BARRIER();
+            compute_nn(true);                                    // everything of tile t+1 this wave issued has landed
+        };
+        if (is_tail(0)) issue_tile(std::true_type{}, 0);
+        else issue_tile(std::false_type{}, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
+        if (GRP == 1) YAT_PHASE_BARRIER();         // stagger: group 1 runs one segment behind group 0
+        const int nfast = max(0, nt - 1 - (ragged && kt0 + nt == nt_all ? 1 : 0));
+        int t = 0;
+        for (; t < nfast; ++t) iteration_nn(std::true_type{}, t);
+        for (; t < nt; ++t) iteration_nn(std::false_type{}, t);
+      };
+      if (grp == 0) nn_loop(std::integral_constant<int, 0>{});
+      else nn_loop(std::integral_constant<int, 1>{});
     } else {
 
     issue(0, smem);
