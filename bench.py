@@ -338,7 +338,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # one process per GPU.  (Rehearsal of the N > 1 flow on a one-GPU box: YAT_DIST_BACKEND=gloo lets several ranks share
     # cuda:0 -- RCCL refuses two ranks on one device -- so everything but the transport is exercised.)
-    backend = os.environ.get("YAT_DIST_BACKEND", "nccl")
+    # YAT_COMM=native: gradients go through the library's own RCCL communicator (yat_comm_*, csrc/comm.hip); the process group is
+    # then only rendezvous / barrier / max-over-ranks and is built over gloo, so the process holds ONE RCCL communicator
+    from yat_amd.ddp import group_backend
+    backend = group_backend()
     ndev = torch.cuda.device_count()
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)

@@ -324,3 +324,23 @@ def test_reference_nccl_environment_is_not_inherited():
     env = {k: v for k, v in os.environ.items() if not k.startswith("NCCL_")}
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
     assert out.strip().splitlines()[-1] == "[]"
+
+
+def test_default_transport_and_group_backend(monkeypatch):
+    """yat_amd/ddp.py: on a GPU the gradients go through the library's own communicator and the launcher-level group is gloo
+    (one RCCL communicator per process); an explicit YAT_COMM / YAT_DIST_BACKEND wins; CPU jobs use torch.distributed."""
+    from yat_amd import ddp
+    for k in ("YAT_COMM", "YAT_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    assert ddp.default_transport() == "torch" and ddp.group_backend(on_gpu=False) == "gloo"
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    assert ddp.default_transport() == "native" and ddp.group_backend() == "gloo"
+    monkeypatch.setenv("YAT_COMM", "torch")
+    assert ddp.default_transport() == "torch" and ddp.group_backend() == "nccl"
+    monkeypatch.delenv("YAT_COMM")
+    monkeypatch.setenv("YAT_DIST_BACKEND", "gloo")                 # several ranks on one GPU: RCCL cannot be used at all
+    assert ddp.default_transport() == "torch" and ddp.group_backend() == "gloo"
+    monkeypatch.setenv("YAT_COMM", "native")
+    monkeypatch.setenv("YAT_DIST_BACKEND", "nccl")
+    assert ddp.default_transport() == "native" and ddp.group_backend() == "nccl"

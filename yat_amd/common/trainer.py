@@ -79,7 +79,11 @@ class HipAccelerator:
             torch.cuda.set_device(self.device)
         if self.num_processes > 1 and not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            backend = backend or os.environ.get("YAT_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
+            # native transport (the default on a GPU, yat_amd/ddp.py default_transport): the gradients travel through the
+            # library's own RCCL communicator (yat_comm_*); the process group is then only the rendezvous / barrier /
+            # consensus channel and is built over gloo -- no second RCCL communicator with its streams beside the library's
+            from ..ddp import group_backend
+            backend = backend or group_backend(on_gpu=self.device.type == "cuda")
             dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s))
         self.is_main_process = self.process_index == 0
         self.sync_gradients = True

@@ -128,18 +128,36 @@ __global__ __launch_bounds__(256) void lokr_small_wgrad_kernel(int64_t rows, int
     for (int64_t ck = blockIdx.x; ck < nchunk; ck += gridDim.x) {
         const int64_t r0 = ck * CH;
         const int nr = (int)(rows - r0 < CH ? rows - r0 : CH);
-        __syncthreads();                                     // previous chunk fully consumed (and the zero fill done)
-        for (int v = threadIdx.x; v < CH * VPR; v += 256) {
+        // Stage the chunk with every global load in flight before the first LDS store: as a plain loop (runtime trip count,
+        // load -> store per iteration) the compiler serialised up to 16 dependent round trips to memory per chunk and the
+        // kernel ran at 0.9 TB/s of its 168 MB (round 4; the rank-8, in_n = 56 adapter gradients of BASELINE config 5).
+        u32x4 xv[16], av[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int v = threadIdx.x + 256 * i;
             const int r = v / VPR, c = v - r * VPR;
-            u32x4 val = u32x4{0u, 0u, 0u, 0u};               // rows past the end contribute zeros (never stale LDS bits)
-            if (r < nr) val = *reinterpret_cast<const u32x4*>(X + (r0 + r) * ldx + n0 + c * 8);
-            *reinterpret_cast<u32x4*>(ximg + r * 256 + ((c ^ sw_swz(r)) << 4)) = val;
+            xv[i] = u32x4{0u, 0u, 0u, 0u};                   // rows past the end contribute zeros (never stale LDS bits)
+            if (v < CH * VPR && r < nr) xv[i] = *reinterpret_cast<const u32x4*>(X + (r0 + r) * ldx + n0 + c * 8);
         }
-        for (int v = threadIdx.x; v < CH * (R >> 3); v += 256) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = threadIdx.x + 256 * i;
             const int r = v / (R >> 3), c = v - r * (R >> 3);
-            u32x4 val = u32x4{0u, 0u, 0u, 0u};
-            if (r < nr) val = *reinterpret_cast<const u32x4*>(A + (r0 + r) * R + c * 8);
-            *reinterpret_cast<u32x4*>(aimg + r * 32 + c * 16) = val;
+            av[i] = u32x4{0u, 0u, 0u, 0u};
+            if (v < CH * (R >> 3) && r < nr) av[i] = *reinterpret_cast<const u32x4*>(A + (r0 + r) * R + c * 8);
+        }
+        __syncthreads();                                     // previous chunk fully consumed (and the zero fill done)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int v = threadIdx.x + 256 * i;
+            const int r = v / VPR, c = v - r * VPR;
+            if (v < CH * VPR) *reinterpret_cast<u32x4*>(ximg + r * 256 + ((c ^ sw_swz(r)) << 4)) = xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = threadIdx.x + 256 * i;
+            const int r = v / (R >> 3), c = v - r * (R >> 3);
+            if (v < CH * (R >> 3)) *reinterpret_cast<u32x4*>(aimg + r * 32 + c * 16) = av[i];
         }
         __syncthreads();
 #pragma unroll

@@ -37,6 +37,34 @@ REFERENCE_NCCL_ENV_NOT_INHERITED = {
 }
 
 
+def default_transport():
+    """Which transport a data-parallel job uses when nothing is said: ``YAT_COMM`` = torch | native wins; a job whose process
+    group was forced onto another backend (``YAT_DIST_BACKEND=gloo``: several ranks sharing one GPU in a rehearsal, where RCCL
+    cannot be used at all) sends its buckets through that group; otherwise on a GPU the library's own communicator
+    (``native``) -- since round 4 the faster configuration: with the rendezvous group on gloo the process holds ONE RCCL
+    communicator, and the forced one-rank rehearsal runs 79.3 ms per step against 85.5 ms through torch.distributed's group
+    (77.0 ms plain; profiles/r04_d_*).  Called in rank processes only (it may initialise the GPU)."""
+    env = os.environ.get("YAT_COMM")
+    if env:
+        return env
+    forced = os.environ.get("YAT_DIST_BACKEND")
+    if forced and forced != "nccl":
+        return "torch"
+    return "native" if torch.cuda.is_available() else "torch"
+
+
+def group_backend(on_gpu=True):
+    """Backend of the launcher-level process group: ``YAT_DIST_BACKEND`` if given; gloo when the gradients travel through the
+    native transport (the group is then rendezvous / barrier / consensus only -- no second RCCL communicator and its streams
+    beside the library's: that pairing cost the step 23 ms in round 3); nccl (= RCCL) otherwise on a GPU."""
+    env = os.environ.get("YAT_DIST_BACKEND")
+    if env:
+        return env
+    if not on_gpu:
+        return "gloo"
+    return "gloo" if default_transport() == "native" else "nccl"
+
+
 class NativeComm:
     """The C-ABI transport (include/yat_hip.h, communication section): one RCCL communicator owned by libyat_hip.so.
     Rendezvous: rank 0 draws the 128-byte id and ships it over the launcher's process group (any backend) -- or nowhere in
@@ -103,14 +131,39 @@ class HipDDP:
         self.sync = True
         self.on_gpu = model.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=model.flat_grad.device) if self.on_gpu else None
-        transport = transport or os.environ.get("YAT_COMM") or ("torch" if dist.is_initialized() else "native")
+        transport = transport or default_transport()
         if transport not in ("torch", "native"):
             raise ValueError(f"transport {transport!r}: torch | native")
         self.native = None
         if transport == "native" and self.on_gpu and (self.world > 1 or force):
             if not average:
                 raise ValueError("the native transport reduces to the mean (DDP semantics)")
-            self.native = NativeComm.get(process_group)
+            # Every rank must end up on the same transport: build the communicator, agree on the outcome over the process
+            # group, and if ANY rank failed (no librccl, a communicator error) all of them fall back to torch.distributed's
+            # RCCL group -- created here, collectively, when the launcher-level group is gloo.
+            err = None
+            try:
+                self.native = NativeComm.get(process_group)
+            except Exception as e:      # noqa: BLE001 -- reported below, after the ranks have agreed
+                err = e
+            ok = 0 if err is not None else 1
+            if dist.is_initialized() and self.world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32)
+                if dist.get_backend(process_group) == "nccl":
+                    flag = flag.to(model.flat_grad.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+                ok = int(flag.item())
+            if not ok:
+                import warnings
+                warnings.warn(f"HipDDP: the native transport is not available on every rank ({err!r}); falling back to "
+                              f"torch.distributed's RCCL group")
+                if self.native is not None:
+                    self.native.destroy()
+                    self.native = None
+                if not dist.is_initialized():
+                    raise err
+                if dist.get_backend(process_group) != "nccl":
+                    self.pg = dist.new_group(backend="nccl")          # (collective: every rank is here)
         self._works = []
         self.bytes_reduced = 0
         # diagnostics (bench.py's `comm` object; off in the timed region).  ``dryrun``: the whole machinery -- hooks, events,
