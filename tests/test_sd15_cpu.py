@@ -5,6 +5,7 @@ the SD1.5 layout at a tiny width (diffusers is absent offline)."""
 import os
 import sys
 
+import pytest
 import torch
 
 BF = torch.bfloat16
@@ -59,3 +60,82 @@ def test_sd15_cpu_plumbing_10_steps(tmp_path, monkeypatch):
     import pytest
     with pytest.raises(NotImplementedError, match="CPU plumbing"):
         SD15Model(params, accelerator=_Acc(), unet=unet)
+
+
+TINY = dict(in_channels=4, out_channels=4, block_out_channels=[32, 64], layers_per_block=1, cross_attention_dim=32,
+            attention_head_dim=4, norm_num_groups=8, down_block_types=["CrossAttnDownBlock2D", "DownBlock2D"],
+            up_block_types=["UpBlock2D", "CrossAttnUpBlock2D"])
+
+
+def _to_oracle_keys(sd):
+    """diffusers key names (yat_amd/sd15.py) -> the oracle restatement's own attribute names"""
+    out = {}
+    for k, v in sd.items():
+        k = k.replace("mid_block.resnets.", "mid_resnets.").replace("mid_block.attentions.0.", "mid_attention.")
+        k = k.replace("downsamplers.0.conv.", "downsamplers.0.").replace("upsamplers.0.conv.", "upsamplers.0.")
+        k = k.replace(".ff.net.", ".ff.")
+        out[k] = v
+    return out
+
+
+def test_product_unet_matches_the_oracle_restatement(tmp_path):
+    """yat_amd/sd15.py (the module train_sd15.py loads from a diffusers-layout directory) against oracle/sd15_ref.py, two
+    independent statements of the SD1.5 UNet layout: same weights -> the same output and gradients, in fp32 and bf16, and the
+    directory round-trips through config.json + diffusion_pytorch_model.safetensors."""
+    sys.path.insert(0, ROOT)
+    from oracle.sd15_ref import UNet2DConditionRef
+    from yat_amd.sd15 import UNet2DConditionCPU
+    torch.manual_seed(3)
+    mine = UNet2DConditionCPU(**TINY)
+    mine.save_pretrained(str(tmp_path / "unet"))
+    assert sorted(os.listdir(tmp_path / "unet")) == ["config.json", "diffusion_pytorch_model.safetensors"]
+    again = UNet2DConditionCPU.from_pretrained(str(tmp_path / "unet"))
+    assert all(torch.equal(v, again.state_dict()[k]) for k, v in mine.state_dict().items())
+    ref = UNet2DConditionRef(block_out_channels=(32, 64), layers_per_block=1, cross_attention_dim=32, heads=4, groups=8,
+                             cross=(True, False))
+    ref.load_state_dict(_to_oracle_keys(mine.state_dict()), strict=True)
+    g = torch.Generator().manual_seed(5)
+    x, t, ctx = torch.randn(2, 4, 16, 16, generator=g), torch.tensor([417]), torch.randn(2, 7, 32, generator=g)
+    for dt in (torch.float32, BF):
+        a, b = mine.to(dt), ref.to(dt)
+        ya, yb = a(x.to(dt), t, ctx.to(dt)), b(x.to(dt), t, ctx.to(dt))
+        assert ya.shape == (2, 4, 16, 16) and torch.equal(ya, yb), dt
+        ya.float().square().mean().backward()
+        yb.float().square().mean().backward()
+        ga, gb = a.conv_in.weight.grad, b.conv_in.weight.grad
+        assert torch.equal(ga, gb)
+        a.zero_grad(); b.zero_grad()
+    with pytest.raises(FileNotFoundError):
+        UNet2DConditionCPU.from_pretrained(str(tmp_path / "nowhere"))
+
+
+def test_train_sd15_cli_runs_10_steps_from_a_local_unet_directory(tmp_path):
+    """BASELINE config 1 through its own entry point: `python train_sd15.py --config config.yaml` as a subprocess --
+    config -> local diffusers-layout UNet directory -> 16-sample shard -> sampler -> 10 steps on the host -> checkpoints."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    from safetensors.torch import load_file
+    from yat_amd.common.shards import write_shard
+    from yat_amd.sd15 import UNet2DConditionCPU
+    torch.manual_seed(11)
+    UNet2DConditionCPU(**TINY).save_pretrained(str(tmp_path / "unet"))
+    g = torch.Generator().manual_seed(0)
+    samples = [dict(__key__=f"{i:07d}", ratio="1.0", latent=(torch.randn(4, 32, 32, generator=g) * 0.5).to(BF),
+                    emb=torch.randn(1, 77, 32, generator=g).to(BF)) for i in range(16)]
+    shard = str(tmp_path / "shard-000000.tar")
+    write_shard(shard, samples)
+    (tmp_path / "config.yaml").write_text("\n".join([
+        "urls:", "  - unused", "local_shard_paths:", f"  - {shard}", "num_shards: 1", "dataset_seed: 1", "batch_size: 1",
+        "learning_rate: 1e-3", "steps: 10", "num_steps_per_validation: 5", "validation_prompts:", "  - x", "bfloat16: true",
+        "aspect_ratio: 512", "warmup_steps: 3", f"pretrained_model_path: {tmp_path / 'unet'}", ""]))
+    env = dict(os.environ, YAT_TENSORBOARD="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_sd15.py"), "--config", str(tmp_path / "config.yaml")],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "train_sd15: 10 steps" in r.stdout
+    assert sorted(os.listdir(tmp_path / "models")) == ["0", "5"]                       # save cadence :371,398
+    w0 = load_file(str(tmp_path / "models" / "0" / "diffusion_pytorch_model.safetensors"))
+    w5 = load_file(str(tmp_path / "models" / "5" / "diffusion_pytorch_model.safetensors"))
+    assert set(w0) == set(UNet2DConditionCPU(**TINY).state_dict()) and any(not torch.equal(w0[k], w5[k]) for k in w0)
+    assert os.path.isfile(tmp_path / "models" / "5" / "config.json")                   # a loadable diffusers-layout directory
+    UNet2DConditionCPU.from_pretrained(str(tmp_path / "models" / "5"))

@@ -5,12 +5,13 @@ backward -> clip(1.0) -> AdamW, a few steps at batch 1 on the host.
 
 Scope: *plumbing only*.  The UNet is diffusers' ``UNet2DConditionModel``, which is
 neither vendored in the reference nor installed here, and the reference defines no GPU work for this config -- so there is no
-HIP UNet.  ``SD15Model`` takes the UNet as an ``nn.Module`` (any module with the call contract
-``model(noisy, timestep, encoder_hidden_states)`` -> sample); tests inject the restatement of oracle/sd15_ref.py.  The step
-runs through the SAME trainer loop, sampler, shard format and YAML reader as the HIP recipes; only the arithmetic is stock
-torch on the host (``torch.optim.AdamW`` + ``clip_grad_norm_``, which is literally what the reference calls,
-common/trainer.py:246-248,347-348).  On a GPU device this entry point refuses to run: a CPU arithmetic path next to the HIP
-kernels is not something this build ships.
+HIP UNet.  The entry point loads the UNet from a LOCAL diffusers-layout directory (``pretrained_model_path``, or
+``<pretrained_pipe_path>/unet``: ``config.json`` + ``diffusion_pytorch_model.safetensors``, train_sd15.py:20-28) into
+yat_amd/sd15.py's host module; ``SD15Model`` also accepts any ``nn.Module`` with the call contract ``model(noisy, timestep,
+encoder_hidden_states)`` -> sample.  The step runs through the SAME trainer loop, sampler, shard format and YAML reader as the
+HIP recipes; only the arithmetic is stock torch on the host (``torch.optim.AdamW`` + ``clip_grad_norm_``, which is literally
+what the reference calls, common/trainer.py:246-248,347-348).  On a GPU device the model refuses to run: a CPU arithmetic path
+next to the HIP kernels is not something this build ships, so ``python train_sd15.py --config ...`` pins the run to the host.
 
 Reference quirks handled: ``optimize(self, ratio, latents, embeddings)`` (:140) has three of the five arguments
 ``Model.run`` passes (common/trainer.py:337) -- TypeError at HEAD; the 512 px aspect table is hard-coded (:36), BASELINE's
@@ -50,9 +51,16 @@ class SD15Model(Model):
         if self.accelerator.device.type != "cpu":
             raise NotImplementedError("train_sd15.py is BASELINE's CPU plumbing config: the SD1.5 UNet has no HIP path in this "
                                       "build (SURVEY.md 8 row a24); run it on the host")
-        if unet is None:
-            raise NotImplementedError("no UNet: diffusers is not available offline -- pass an nn.Module "
-                                      "(oracle/sd15_ref.UNet2DConditionRef restates the SD1.5 layout)")
+        if unet is None:                                                       # :20-28
+            import os
+            from yat_amd.sd15 import UNet2DConditionCPU
+            path = params.pretrained_model_path
+            if path is None and params.pretrained_pipe_path is not None:
+                path = os.path.join(params.pretrained_pipe_path, "unet")      # the pipeline directory's own UNet
+            if path is None:
+                raise NotImplementedError("no UNet: set pretrained_model_path (a local diffusers-layout UNet directory) or "
+                                          "pretrained_pipe_path; single-file checkpoints and hub names are not supported offline")
+            unet = UNet2DConditionCPU.from_pretrained(path)
         self.model = unet.to(torch.bfloat16)                                   # :39
         self.scheduler = DDPMSchedule(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")   # :30-31 [RECALL]
         self.aspect_ratios = ASPECT_RATIO_512_BIN                              # :36
@@ -73,6 +81,9 @@ class SD15Model(Model):
 
     def save_model(self):
         import os
+        if hasattr(self.model, "save_pretrained"):                             # common/trainer.py:295-296
+            self.model.save_pretrained(f"models/{self.global_step}")
+            return
         from safetensors.torch import save_file
         os.makedirs(f"models/{self.global_step}", exist_ok=True)
         save_file({k: v.detach().contiguous() for k, v in self.model.state_dict().items()},
@@ -100,5 +111,11 @@ if __name__ == "__main__":
     args = parser.parse_args()
     params = TrainingParameters()
     params.read_yaml(args.config)
-    raise SystemExit("train_sd15.py needs a UNet module: diffusers' UNet2DConditionModel is not available offline and this build "
-                     "ships no HIP UNet (BASELINE config 1 is CPU plumbing -- see tests/test_sd15_cpu.py for the wired run)")
+    if params.extract_features:                                                # :175-181 needs the VAE and the text encoder
+        raise SystemExit("extract_features: VAE / text encoding are outside the hot-path scope; train from cached-feature shards")
+    from yat_amd.common.trainer import HipAccelerator
+    # BASELINE config 1 is defined on the host ("10 steps on CPU ... no GPU"): the accelerator is pinned to the CPU
+    trainer = SD15Model(params, accelerator=HipAccelerator(params.gradient_accumulation_steps, device="cpu"))
+    trainer.run()
+    print(f"train_sd15: {trainer.global_step} steps, last losses "
+          f"{[round(float(l), 4) for l in list(trainer.loss_history)[-3:]]}")
