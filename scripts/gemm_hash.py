@@ -59,6 +59,24 @@ def main():
     print(f"wgrad + rowsum   {sha(dw)} {sha(db)}")
     ops.linear_wgrad(dy, x, dw, accumulate=True, bias_grad=db)
     print(f"wgrad accumulate {sha(dw)} {sha(db)}")
+    # the forward layout's fused epilogue: bias, pre-gate copy, per-image gate, residual (and the SiLU + pre-activation form)
+    B_, rows, D_, K_ = 4, 1024, 2240, 2240
+    M_ = B_ * rows
+    xx = (torch.randn(M_, K_, device=dev, generator=g) * 0.5).to(BF)
+    ww = (torch.randn(D_, K_, device=dev, generator=g) * 0.02).to(BF)
+    bias = torch.randn(D_, device=dev, generator=g).to(BF)
+    mod = torch.randn(B_, 6, D_, device=dev, generator=g).to(BF)
+    res = torch.randn(M_, D_, device=dev, generator=g).to(BF)
+    lin, o = torch.empty(M_, D_, dtype=BF, device=dev), torch.empty(M_, D_, dtype=BF, device=dev)
+    for variant in (4, 5):
+        ops.gemm(xx, ww, o, M=M_, N=D_, K=K_, bias=bias, aux_out=lin, gate=mod[:, 2], ld_gate=6 * D_, residual=res,
+                 rows_per_batch=rows, variant=variant)
+        print(f"gate+res+aux v{variant} {sha(o)} {sha(lin)}")
+        ops.gemm(xx, ww, o, M=M_, N=D_, K=K_, bias=bias, aux_out=lin, activation="silu", variant=variant)
+        print(f"silu+aux     v{variant} {sha(o)} {sha(lin)}")
+        dx = torch.empty(M_, K_, dtype=BF, device=dev)
+        ops.gemm(o, ww, dx, b_t=True, M=M_, N=K_, K=D_, residual=res, variant=variant)          # dgrad + accumulate into a residual
+        print(f"dgrad+res    v{variant} {sha(dx)}")
     torch.cuda.synchronize()
     print(f"wrong results: {bad}")
     return 1 if bad else 0

@@ -834,35 +834,73 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         constexpr int CPR = WCOLS / 8;             // 8-column chunks per row
         float* slab = reinterpret_cast<float*>(smem) + wave * (32 * LDW);
         const int g4 = lane >> 4, li = lane & 15;
+        // The epilogue's own global INPUTS (residual, pre_add, GLU u, activation input z) are loaded one pass of 32 rows
+        // ahead of their use, into the registers the pass before has just emptied: read where they are consumed, each of the
+        // four passes of a tile paid an HBM round trip behind its slab round trip (the gated-residual and GLU-backward GEMMs
+        // ran 714 .. 990 TFLOP/s in the step).  Same loads, same arithmetic, same stores: bit-identical.
+#ifndef YAT_GEMM_EPI_PREFETCH
+#define YAT_GEMM_EPI_PREFETCH 1
+#endif
+        constexpr int UPL = (32 * CPR + 63) / 64;          // 8-column units per lane and pass
+        constexpr bool HAS_IN = YAT_GEMM_EPI_PREFETCH && (EPI == 1 || EPI == 2 || EPI == 3 || EPI == 0 || EPI == 4);
+        const bool pre_on = HAS_IN && !split && (EPI == 1 || EPI == 3 || EPI == 2 || p.res != nullptr);
+        // one input stream (residual | z): a whole pass ahead, double-buffered; two streams (GLU u_a + u_g, residual + pre_add):
+        // the registers do not hold two passes of both -- loaded at the top of their own pass, before its slab round trip
+        constexpr bool AHEAD = EPI != 1 && EPI != 2;
+        EpiIn ein[AHEAD ? 2 : 1][UPL];
+        auto unit = [&](int pass, int k, int& row, int& ch, int& m, int& n) {
+            const int u = lane + 64 * k;
+            row = u / CPR;
+            ch = u % CPR;
+            m = m0 + grp * 128 + pass * 32 + row;
+            n = n0 + wc * WCOLS + ch * 8;
+            return u < 32 * CPR && m < p.M && n < p.N;
+        };
+        auto prefetch = [&](int pass, EpiIn (&in)[UPL]) {
+#pragma unroll
+            for (int k = 0; k < UPL; ++k) {
+                int row, ch, m, n;
+                if (!unit(pass, k, row, ch, m, n)) continue;
+                if (EPI == 1) {
+                    const bf16_t* up = p.glu_u + (int64_t)m * p.ld_glu + n;
+                    in[k].a = *reinterpret_cast<const u32x4*>(up);
+                    in[k].b = *reinterpret_cast<const u32x4*>(up + p.N);
+                } else if (EPI == 3) {
+                    in[k].a = *reinterpret_cast<const u32x4*>(p.dact_z + (int64_t)m * p.ld_z + n);
+                } else {
+                    if (p.res) in[k].a = *reinterpret_cast<const u32x4*>(p.res + (int64_t)m * p.ldr + n);
+                    if (EPI == 2) in[k].b = *reinterpret_cast<const u32x4*>(p.pre_add + (int64_t)m * p.ld_pre + n);
+                }
+            }
+        };
+        if (pre_on && AHEAD) prefetch(0, ein[0]);
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
+            if (pre_on && !AHEAD) prefetch(pass, ein[0]);
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     *reinterpret_cast<f32x4*>(slab + (ii * 16 + li) * LDW + j * 16 + 4 * g4) = acc[pass * 2 + ii][j];
+            if (pre_on && AHEAD && pass + 1 < 4) prefetch(pass + 1, ein[(pass + 1) & 1]);       // (into the registers this pass freed)
             // wave-private slab: the wave's own LDS writes are ordered before its reads by lgkmcnt; no barrier needed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int k = 0; k < (32 * CPR + 63) / 64; ++k) {
-                const int u = lane + 64 * k;
-                if (u < 32 * CPR) {
-                    const int row = u / CPR, ch = u % CPR;
-                    const int m = m0 + grp * 128 + pass * 32 + row;
-                    const int n = n0 + wc * WCOLS + ch * 8;
-                    if (m < p.M && n < p.N) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8 + 4);
-                        if (split) {               // fp32 partial slab [ksl][m][n]; epilogue runs in the reduce kernel
-                            float* dst = p.partial + ((int64_t)ksl * p.M + m) * p.N + n;
-                            *reinterpret_cast<f32x4*>(dst) = lo;
-                            *reinterpret_cast<f32x4*>(dst + 4) = hi;
-                        } else {
-                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            if (EPI == 1) glu_bwd_store<8>(p, v, m, n);
-                            else if (EPI == 3) act_bwd_store<8>(p, v, m, n);
-                            else gemm_epilogue_store8<EPI == 2, A_T && B_T>(p, v, m, n, m / rpb);     // (weight-gradient layout: non-temporal result)
-                        }
+            for (int k = 0; k < UPL; ++k) {
+                int row, ch, m, n;
+                if (unit(pass, k, row, ch, m, n)) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8 + 4);
+                    if (split) {               // fp32 partial slab [ksl][m][n]; epilogue runs in the reduce kernel
+                        float* dst = p.partial + ((int64_t)ksl * p.M + m) * p.N + n;
+                        *reinterpret_cast<f32x4*>(dst) = lo;
+                        *reinterpret_cast<f32x4*>(dst + 4) = hi;
+                    } else {
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const EpiIn* pin = pre_on ? &ein[AHEAD ? (pass & 1) : 0][k] : nullptr;
+                        if (EPI == 1) glu_bwd_store<8>(p, v, m, n, pin);
+                        else if (EPI == 3) act_bwd_store<8>(p, v, m, n, pin);
+                        else gemm_epilogue_store8<EPI == 2, A_T && B_T>(p, v, m, n, m / rpb, pin);     // (weight-gradient layout: non-temporal result)
                     }
                 }
             }

@@ -31,13 +31,17 @@ struct GemmP {
 // -- exactly the arithmetic of the depthwise kernel's backward pass 1, which this replaces.
 // Compiled only into the GLU instantiation of gemm256 (as a runtime branch of the shared epilogue it pushed the
 // accumulators of every 256x320 kernel into scratch: +11 ms per step).
+// Epilogue inputs of one 8-column unit, loaded AHEAD of the unit's slab round trip (gemm256: one pass of 32 rows ahead) so
+// that their HBM latency is not paid four times per tile: a = residual | GLU u_a | activation input z, b = pre_add | GLU u_g.
+struct EpiIn { u32x4 a, b; };
+
 template <int W>
-__device__ __forceinline__ void glu_bwd_store(const GemmP& p, const float (&v)[W], int m, int n) {
+__device__ __forceinline__ void glu_bwd_store(const GemmP& p, const float (&v)[W], int m, int n, const EpiIn* pre = nullptr) {
     float ua[W], ug[W], da[W], dg[W];
     const bf16_t* up = p.glu_u + (int64_t)m * p.ld_glu + n;
     if (W == 8) {
-        unpack8(*reinterpret_cast<const u32x4*>(up), ua);
-        unpack8(*reinterpret_cast<const u32x4*>(up + p.N), ug);
+        unpack8(pre ? pre->a : *reinterpret_cast<const u32x4*>(up), ua);
+        unpack8(pre ? pre->b : *reinterpret_cast<const u32x4*>(up + p.N), ug);
     } else {
         unpack4(*reinterpret_cast<const u32x2*>(up), ua);
         unpack4(*reinterpret_cast<const u32x2*>(up + p.N), ug);
@@ -62,10 +66,10 @@ __device__ __forceinline__ void glu_bwd_store(const GemmP& p, const float (&v)[W
 // bf16 like the Linear's output): dz = d * act'(z) -- the arithmetic of ew_kernel<1> (yat_act_bwd), which this replaces.
 // Its own template instantiation of gemm256 (EPI = 3), like the GLU one.
 template <int W>
-__device__ __forceinline__ void act_bwd_store(const GemmP& p, const float (&v)[W], int m, int n) {
+__device__ __forceinline__ void act_bwd_store(const GemmP& p, const float (&v)[W], int m, int n, const EpiIn* pre = nullptr) {
     float z[W], o[W];
     const bf16_t* zp = p.dact_z + (int64_t)m * p.ld_z + n;
-    if (W == 8) unpack8(*reinterpret_cast<const u32x4*>(zp), z);
+    if (W == 8) unpack8(pre ? pre->a : *reinterpret_cast<const u32x4*>(zp), z);
     else unpack4(*reinterpret_cast<const u32x2*>(zp), z);
 #pragma unroll
     for (int e = 0; e < W; ++e) o[e] = rbf(v[e]) * (p.act == 1 ? dsilu_f(z[e]) : dgelu_tanh_f(z[e]));
@@ -124,7 +128,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmP& p, const f32x4&
 // NTC: the result is written non-temporally (weight gradients: next read by the all-reduce / the optimizer, milliseconds later);
 // the pre-activation copy (aux) always is -- it is kept for the backward only (common.hpp YAT_AUX_NT).
 template <bool PRE = false, bool NTC = false>
-__device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[8], int m, int n, int b) {
+__device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[8], int m, int n, int b, const EpiIn* pre = nullptr) {
     if (p.bias) {
         float bb[8];
         unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bb);
@@ -133,7 +137,7 @@ __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[
     }
     if (PRE) {
         float pa[8];
-        unpack8(*reinterpret_cast<const u32x4*>(p.pre_add + (int64_t)m * p.ld_pre + n), pa);
+        unpack8(pre ? pre->b : *reinterpret_cast<const u32x4*>(p.pre_add + (int64_t)m * p.ld_pre + n), pa);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]) + pa[e];
     }
@@ -159,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue_store8(const GemmP& p, float (&v)[
     }
     if (p.res) {
         float r[8];
-        unpack8(*reinterpret_cast<const u32x4*>(p.res + (int64_t)m * p.ldr + n), r);
+        unpack8(pre ? pre->a : *reinterpret_cast<const u32x4*>(p.res + (int64_t)m * p.ldr + n), r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
