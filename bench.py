@@ -762,6 +762,9 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": usable_cores(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
         emit_json(res)
+    if ddp is not None and ddp.native is not None:
+        torch.cuda.synchronize()
+        ddp.native.destroy()               # the library's communicator goes before the process does (no RCCL teardown at exit)
     if world > 1:
         dist.destroy_process_group()
 
