@@ -251,7 +251,7 @@ __device__ __forceinline__ uint32_t q_off(uint32_t row, uint32_t byte) {
 
 // ------------------------------------------------------------------------------------------ backward apply (q side)
 // grid (nchunks, H, B).  Per wave: 64 tokens.  dS partial slab per workgroup.
-__global__ __launch_bounds__(256) void la_bwd_q_kernel(int N, int H, const bf16_t* qkv, int ld, const bf16_t* dout, int ld_do,
+__global__ __launch_bounds__(256, 3) void la_bwd_q_kernel(int N, int H, const bf16_t* qkv, int ld, const bf16_t* dout, int ld_do,
                                                        const float* S_all, bf16_t* dqkv, int ld_dq, float* dS_part) {
     // wave-private: dU hi and lo images [32 tokens][64 c'] bf16 (128-B rows) + q image [32 tokens][32 c] bf16 (64-B rows)
     // (the workgroup's final reduction reuses the images' bytes: 40 KB instead of 64 KB per workgroup = three workgroups per CU
