@@ -196,6 +196,26 @@ def test_forced_ddp_native_transport_is_bit_identical():
     assert lib.yat_comm_world() == 0
 
 
+def test_native_transport_failure_falls_back_to_the_process_group(one_rank_group, monkeypatch):
+    """HipDDP builds the library's communicator, the ranks agree on the outcome, and if it failed anywhere every rank uses
+    torch.distributed's RCCL group instead (yat_amd/ddp.py): same gradients and parameters as the plain step, a warning says so."""
+    import warnings
+    from yat_amd import ddp as D
+
+    def boom(cls, process_group=None):
+        raise RuntimeError("no librccl on this rank")
+    monkeypatch.setattr(D.NativeComm, "get", classmethod(boom))
+    g0, p0, _, n = _two_steps(None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        g1, p1, reduced, _ = _two_steps("native")
+    assert any("falling back" in str(x.message) for x in w)
+    assert reduced == 2 * 2 * n
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert torch.equal(p0, p1)
+
+
 def _world2_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
