@@ -464,7 +464,7 @@ def main():
 
     # The step runs on a stream of the compute-stream set (high priority level, one hardware queue each) rather than on the
     # default stream, which shares its hardware queue with whatever else the process creates -- with a process group around
-    # that was the weight-gradient and optimizer streams, and the step lost 16 ms ("hardware queues").
+    # that was the weight-gradient and optimizer streams, and the step lost 16 ms (profiles/LOG_r01_r03.md section 6, "hardware queues").
     from yat_amd.flat import compute_stream, isolate_streams
     if os.environ.get("YAT_HP_MAIN", "1") != "0" and isolate_streams():      # (only with a process group around)
         hp = compute_stream(dev)
@@ -724,7 +724,7 @@ def main():
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "traffic_unit": "bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE: requests of the L2s to the fabric -- "
                                                "re-reads served by the 256 MB Infinity Cache are counted, so this bounds the HBM "
-                                               "bytes from above; DESIGN.md section 14, item 6b)",
+                                               "bytes from above; profiles/LOG_r01_r03.md section 14, item 6b)",
                                "traffic_source": traffic_src, "algorithmic_operand_bytes_per_launch": alg_bytes,
                                "mode": f"serialized-stream pass of {args.roofline_steps} steps after the timed region",
                                "launches": len(timer), "avg_launch_us": 1e3 * gms / len(timer),
