@@ -23,6 +23,8 @@ SHAPES = [("tt", 2240, 5600, 8192), ("tt", 6720, 2240, 8192), ("tt", 11200, 2240
           ("nt", 8192, 2240, 6720), ("nt", 8192, 2240, 2240)]
 if os.environ.get("PROBE_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["PROBE_SHAPES"].split(",")]
+if os.environ.get("PROBE_CUSTOM"):               # "nn:32768:2240:320,nt:32768:320:2240"
+    SHAPES = [(c.split(":")[0], *map(int, c.split(":")[1:])) for c in os.environ["PROBE_CUSTOM"].split(",")]
 VARIANT = int(os.environ.get("PROBE_VARIANT", "0"))
 WARM_S, TIME_S = float(os.environ.get("PROBE_WARM_S", "1.0")), float(os.environ.get("PROBE_TIME_S", "0.5"))
 

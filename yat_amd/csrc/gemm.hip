@@ -164,7 +164,11 @@ namespace {
 double est_time_128(int M, int N, int K) {
     const double tiles = (double)((M + 127) / 128) * ((N + 127) / 128);
     const double rounds = ceil(tiles / 512.0);
-    return rounds * 2.0 * (2.0 * 128 * 128 * (double)K) / 3.4e12;
+    // per-round fixed cost: the kernel alone runs 32768 x 2240 x 320 in 85 us (9 rounds of 6.2 us of MFMA work) and
+    // 32768 x 11200 x 320 in 401 us (44 rounds) -- ~3 us a round that the rate does not cover, and what made the policy
+    // keep short-K products on this kernel that the 256 x 320 tile runs 7..16 % faster (profiles/r04_k_*)
+    static const double fixed = YAT_TUNE_F64("YAT_GEMM_FIXED_128", 3e-6);
+    return rounds * (2.0 * (2.0 * 128 * 128 * (double)K) / 3.4e12 + fixed);
 }
 // ``streams``: the caller's per-call hint (policy word of yat_gemm_bf16_ex): independent GEMM streams sharing the chip
 double est_time_256(int M, int N, int K, int BNv, int ksplit, int streams) {
