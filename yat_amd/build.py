@@ -26,7 +26,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-va
 # Per-source additions.  sdpa.hip: keep the MFMA accumulators in ordinary VGPRs -- the softmax reads every score and rescales
 # every output accumulator between MFMAs, and with the default AGPR form that was ~150 v_accvgpr_read/write moves per key tile
 # per wave (more VALU cycles than the softmax itself); gfx950's MFMA takes VGPR operands directly.
-EXTRA_FLAGS = {"sdpa.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# sdpa.hip, -fno-slp-vectorize: the SLP vectorizer pairs the per-score f32 multiplies / adds of the softmax loops into v_pk_*
+# instructions (dearer than two plain ones beside MFMAs: MI355X_MICROARCH.md) and then shuffles the pairs back for the bf16 packs
+EXTRA_FLAGS = {"sdpa.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

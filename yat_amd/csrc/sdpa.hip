@@ -21,6 +21,49 @@
 #include "common.hpp"
 #include "../../include/yat_hip.h"
 
+// Diagnostic build -DYAT_SDPA_STAMPS (scripts/sdpa_stamps.py): the waves of one workgroup sum, per loop segment, the s_memtime
+// ticks they spent there (backward kernels); the product build contains none of this.
+#ifdef YAT_SDPA_STAMPS
+__device__ unsigned int yat_sdpa_stamp_buf[8 * 16 + 8];
+#define SD_STAMP(slot)                                                  \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();   \
+        st_sum[slot] += now_ - st_prev;                                 \
+        st_prev = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#define SD_STAMP_BEGIN() uint32_t st_sum[16] = {}; uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime(); int st_n = 0
+#define SD_STAMP_END(cond)                                                                  \
+    do {                                                                                    \
+        if ((cond) && lane == 0) {                                                          \
+            for (int i_ = 0; i_ < 16; ++i_) yat_sdpa_stamp_buf[wave * 16 + i_] = st_sum[i_];  \
+            yat_sdpa_stamp_buf[128] = (unsigned)st_n;                                        \
+        }                                                                                   \
+    } while (0)
+#else
+#define SD_STAMP(slot) do {} while (0)
+#define SD_STAMP_BEGIN() do {} while (0)
+#define SD_STAMP_END(cond) do {} while (0)
+#endif
+
+// Wave priority by loop phase (s_setprio): raised while a wave issues its MFMA phases, dropped for its softmax.  Two workgroups
+// share a CU and their waves a SIMD at unrelated points of the same loop; with the priority the wave that has matrix work
+// gets the issue slots first and the partner's exponentials fill the gaps (and the s_setprio keeps the compiler from mixing
+// the phases).  Measured at N = T = 4096 (scripts/gpu_attn_libs.sh, profiles/r04_l_*): dK/dV kernel 1.43 -> 1.36 ms (dh 72) and
+// 1.88 -> 1.80 ms (dh 64); forward 1.02 -> 0.98 ms at dh 64, level at dh 72; the dQ kernel 1 % slower with it -> not there.
+// The opposite assignment (softmax high) costs the forward 3..7 %.
+#ifndef YAT_SDPA_PRIO_DKV
+#define YAT_SDPA_PRIO_DKV 1
+#endif
+#ifndef YAT_SDPA_PRIO_DQ
+#define YAT_SDPA_PRIO_DQ 0
+#endif
+#ifndef YAT_SDPA_PRIO_FWD
+#define YAT_SDPA_PRIO_FWD 1
+#endif
+#define SD_PRIO(on, level) do { if (on) __builtin_amdgcn_s_setprio(level); } while (0)
+
 namespace {
 
 constexpr int TILE = 16384;  // one [64][128] bf16 image
@@ -271,6 +314,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
         const char* Vs = cur + TILE;
         const float* bias_s = reinterpret_cast<const float*>(cur + 2 * TILE);
 
+        SD_PRIO(YAT_SDPA_PRIO_FWD, 1);
         f32x4 s[QS][4];
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj) {
@@ -303,6 +347,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
                     for (int r = 0; r < 4; ++r) s[qs][nj][r] = __builtin_fmaf(s[qs][nj][r], p.scale, bv[r]);
             }
         }
+        SD_PRIO(YAT_SDPA_PRIO_FWD, 0);
         // tile maxima; does any row of this wave outrun its reference by more than the threshold?
         float mx[QS];
         bool grow = false;
@@ -346,6 +391,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
             pf0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
             pf1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
         }
+        SD_PRIO(YAT_SDPA_PRIO_FWD, 1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const bf16x8 v0 = frag_tr_acc(Vs, 0, dt * 16, lane), v1 = frag_tr_acc(Vs, 32, dt * 16, lane);
@@ -424,7 +470,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 
     bf16x8 qf[QS][KS], dof[QS][KS];
     float dl[QS], nlse2[QS];                     // nlse2 = -lse * log2e (queries past N: -1e30 -> P = 0)
-    f32x4 acc[QS][DT];
+    f32x4 ndl[QS];                               // -delta in every component: the dP accumulators START there (dP - delta
+    f32x4 acc[QS][DT];                           // without a subtraction per score: the MFMA's C operand, no copy)
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         const int qi = q0 + qs * 16 + li;
@@ -439,6 +486,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
             for (int e = 0; e < 8; ++e) d_ += (float)dof[qs][ks][e] * (float)of[e];
         }
         dl[qs] = group_sum(d_);
+        ndl[qs] = f32x4{-dl[qs], -dl[qs], -dl[qs], -dl[qs]};
         nlse2[qs] = qi < p.N ? -p.lse[((int64_t)b * p.H + h) * p.N + qi] * LOG2E : -1e30f;
         if (qi < p.N && g == 0) p.delta[((int64_t)b * p.H + h) * p.N + qi] = dl[qs];
 #pragma unroll
@@ -446,11 +494,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     }
 
     int it = 0;
+    SD_STAMP_BEGIN();
     for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
         char* cur = smem + (it & 1) * DQ_STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        SD_STAMP(0);
         if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * DQ_STAGE);
+        SD_STAMP(1);
+        SD_PRIO(YAT_SDPA_PRIO_DQ, 1);
         if constexpr (!NOBIAS) mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
         const char* Kt = cur;
         const char* Vs = cur + TILE;
@@ -462,7 +514,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 #pragma unroll
             for (int qs = 0; qs < QS; ++qs) {
                 s[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[qs][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[qs][nj] = ndl[qs];
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -474,6 +526,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
                 }
             }
         }
+        SD_STAMP(2);
+        SD_PRIO(YAT_SDPA_PRIO_DQ, 0);
         bf16x8 f0[QS], f1[QS];
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
@@ -485,12 +539,14 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
                 for (int r = 0; r < 4; ++r) {
                     const float pr = NOBIAS ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qs][nj][r], ce, nlse2[qs]))
                                             : exp_sub(__builtin_fmaf(s[qs][nj][r], p.scale, bv[r]), nlse2[qs]);
-                    s[qs][nj][r] = pr * (dp[qs][nj][r] - dl[qs]);   // dS (w.r.t. the scaled logits)
+                    s[qs][nj][r] = pr * dp[qs][nj][r];              // dS (w.r.t. the scaled logits); dp = dP - delta
                 }
             }
             f0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
             f1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
         }
+        SD_STAMP(3);
+        SD_PRIO(YAT_SDPA_PRIO_DQ, 1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const bf16x8 k0f = frag_tr_acc(Kt, 0, dt * 16, lane), k1f = frag_tr_acc(Kt, 32, dt * 16, lane);
@@ -500,7 +556,13 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
                 acc[qs][dt] = mfma16(k1f, f1[qs], acc[qs][dt]);
             }
         }
+        SD_STAMP(4);
+        SD_PRIO(YAT_SDPA_PRIO_DQ, 0);
+#ifdef YAT_SDPA_STAMPS
+        ++st_n;
+#endif
     }
+    SD_STAMP_END(bx == 3 && h == 1 && b == 0);
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         const int qi = q0 + qs * 16 + li;
@@ -518,8 +580,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
+// where the S accumulators of queries [q, q+4) start: -lse / scale (raw-score units)
+__device__ __forceinline__ f32x4 score_start(const float* lse_s, int q, float inv_scale) {
+    const f32x4 l = *reinterpret_cast<const f32x4*>(lse_s + q);
+    return f32x4{-l[0] * inv_scale, -l[1] * inv_scale, -l[2] * inv_scale, -l[3] * inv_scale};
+}
+// (two waves per SIMD asked for where the kernel fits them -- head dims up to 96; the allocator otherwise lands the dh-72 dense
+//  instantiation at 260 registers, one wave per SIMD: 1.41 -> 1.96 ms when that happened in round 3)
 template <int KS, int DT, int KB, int NW, bool NOBIAS>
-__global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
+__global__ __launch_bounds__(64 * NW, (KS <= 3 && NW == 4) ? 2 : 1) void sdpa_bwd_dkv_kernel(SdpaP p) {
     // NOBIAS: as in the dQ kernel (the scale folded into the exp's FMA); keys past T need no mask -- their dK / dV rows are
     // not stored and no other key's result depends on them.
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -570,6 +639,12 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
     const uint64_t stat_bytes = p.stat_bytes;
     const __amdgpu_buffer_rsrc_t rlse = make_rsrc(p.lse, stat_bytes), rdel = make_rsrc(p.delta, stat_bytes);
     const int64_t kvr0 = kv_row0(p, b), klimrow = kv_row_limit(p, kvr0, klim);
+    // The per-score arithmetic is P = exp2(ce * a), dS' = P * d with the accumulators STARTED at what used to be subtracted:
+    //   a = (bias - lse) / scale + q.k      (the S chain's C operand; ce * a = (scale q.k + bias - lse) log2e)
+    //   d = delta + dO.(-V) = -(dP - delta) (the dP chain's C operand = the delta quad straight from LDS, V negated once)
+    // so dS' = -dS, undone by the -scale of the dK store: two multiplies and the exponential per score instead of two FMAs, a
+    // subtraction and a multiply, and no lse / delta operand live in the softmax.
+    const float inv_scale = 1.0f / p.scale;
     bf16x8 kf[KB][KS], vf[KB][KS];
     float kb_[KB];
     bool kvalid[KB];
@@ -582,9 +657,15 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
         for (int ks = 0; ks < KS; ++ks) {
             kf[kb][ks] = frag_global(p.k, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
             vf[kb][ks] = frag_global(p.v, krow, klimrow, p.ldkv, col0, p.dh, ks, lane);
+            {                                                               // -V (sign bits; exact): see below
+                u32x4 t = __builtin_bit_cast(u32x4, vf[kb][ks]);
+                t ^= u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+                vf[kb][ks] = __builtin_bit_cast(bf16x8, t);
+            }
         }
         kvalid[kb] = krow < klimrow;                // padded layout: key < T; packed: key < kv_len (the next row is another image's)
-        kb_[kb] = NOBIAS ? 0.f : (key < p.T ? p.bias[(int64_t)b * p.T + key] : -1e30f);   // keys past T: P = exp2(-huge) = 0
+        // key bias in the units of the RAW scores (the accumulator's); keys past T: P = exp2(-huge) = 0
+        kb_[kb] = NOBIAS ? 0.f : (key < p.T ? p.bias[(int64_t)b * p.T + key] * inv_scale : -1e30f);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { adk[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
@@ -606,11 +687,15 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
         }
     };
     stage_q(0, smem);
+    SD_STAMP_BEGIN();
     for (int q0 = 0, it = 0; q0 < p.N; q0 += 64, ++it) {
         char* cur = smem + (it & 1) * DKV_STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // tile `it` landed everywhere; every wave is done with the other stage
+        SD_STAMP(0);
         if (q0 + 64 < p.N) stage_q(q0 + 64, smem + ((it + 1) & 1) * DKV_STAGE);
+        SD_STAMP(1);
+        SD_PRIO(YAT_SDPA_PRIO_DKV, 1);
         const char* Qt = cur;
         const char* Ot = cur + TILE;
         const float* lse_s = reinterpret_cast<const float*>(cur + 2 * TILE);
@@ -620,10 +705,12 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             f32x4 s[KB][4], dp[KB][4];
 #pragma unroll
             for (int nq = 0; nq < 4; ++nq) {
+                const f32x4 s0 = score_start(lse_s, nq * 16 + 4 * g, inv_scale);
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(del_s + nq * 16 + 4 * g);
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
-                    s[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    dp[kb][nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s[kb][nq] = NOBIAS ? s0 : s0 + kb_[kb];
+                    dp[kb][nq] = d0;
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -636,22 +723,15 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
                 }
             }
             bf16x8 pf0[KB], pf1[KB], sf0[KB], sf1[KB];
-            float nl2[4][4];
-#pragma unroll
-            for (int nq = 0; nq < 4; ++nq)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nl2[nq][r] = -lse_s[nq * 16 + 4 * g + r] * LOG2E;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
                 for (int nq = 0; nq < 4; ++nq)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int ql = nq * 16 + 4 * g + r;
-                        const float pr = NOBIAS ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][nq][r], ce, nl2[nq][r]))
-                                                : exp_sub(__builtin_fmaf(s[kb][nq][r], p.scale, kb_[kb]), nl2[nq][r]);
+                        const float pr = __builtin_amdgcn_exp2f(s[kb][nq][r] * ce);
                         s[kb][nq][r] = pr;                                      // P
-                        dp[kb][nq][r] = pr * (dp[kb][nq][r] - del_s[ql]);       // dS
+                        dp[kb][nq][r] = pr * dp[kb][nq][r];                     // -dS
                     }
                 pf0[kb] = acc_to_frag(s[kb][0], s[kb][1]); pf1[kb] = acc_to_frag(s[kb][2], s[kb][3]);
                 sf0[kb] = acc_to_frag(dp[kb][0], dp[kb][1]); sf1[kb] = acc_to_frag(dp[kb][2], dp[kb][3]);
@@ -679,10 +759,12 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
                     const int nq = 2 * half + hq;
+                    const f32x4 s0 = score_start(lse_s, nq * 16 + 4 * g, inv_scale);
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(del_s + nq * 16 + 4 * g);
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) {
-                        s[kb][hq] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        dp[kb][hq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        s[kb][hq] = NOBIAS ? s0 : s0 + kb_[kb];
+                        dp[kb][hq] = d0;
                     }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
@@ -694,6 +776,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
                         }
                     }
                 }
+                SD_STAMP(2 + 3 * half);
+                SD_PRIO(YAT_SDPA_PRIO_DKV, 0);
                 bf16x8 pf[KB], sf[KB];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
@@ -702,18 +786,15 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // the same arithmetic as the 16-key branch: dense and work-list launches agree bit for bit
-                            const int ql = (2 * half + hq) * 16 + 4 * g + r;
-                            // (NOBIAS keeps this form with kb_ = 0 for head dims past 64: folding the scale into the exp's FMA here moved the
-                            //  register allocation of the <3, 5> instantiation from 235 to > 256 -- one wave per SIMD,
-                            //  1.41 -> 1.96 ms at N = T = 4096 -- for 16 of this loop's 166 vector instructions)
-                            const float pr = (NOBIAS && KS <= 2) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][hq][r], ce, -lse_s[ql] * LOG2E))
-                                                                 : exp_sub(__builtin_fmaf(s[kb][hq][r], p.scale, kb_[kb]), -lse_s[ql] * LOG2E);
+                            const float pr = __builtin_amdgcn_exp2f(s[kb][hq][r] * ce);
                             s[kb][hq][r] = pr;                                  // P
-                            dp[kb][hq][r] = pr * (dp[kb][hq][r] - del_s[ql]);   // dS
+                            dp[kb][hq][r] = pr * dp[kb][hq][r];                 // -dS
                         }
                     pf[kb] = acc_to_frag(s[kb][0], s[kb][1]);
                     sf[kb] = acc_to_frag(dp[kb][0], dp[kb][1]);
                 }
+                SD_STAMP(3 + 3 * half);
+                SD_PRIO(YAT_SDPA_PRIO_DKV, 1);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const bf16x8 of = frag_tr_acc(Ot, 32 * half, dt * 16, lane), qf_ = frag_tr_acc(Qt, 32 * half, dt * 16, lane);
@@ -723,10 +804,14 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
                         adk[kb][dt] = mfma16(qf_, sf[kb], adk[kb][dt]);
                     }
                 }
+                SD_STAMP(4 + 3 * half);
             }
-    
         }
+#ifdef YAT_SDPA_STAMPS
+        ++st_n;
+#endif
     }
+    SD_STAMP_END(tile == 3 && h == 1 && b == 0);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         if (!kvalid[kb]) continue;
@@ -738,8 +823,9 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dkv_kernel(SdpaP p) {
             const int d = dt * 16 + 4 * g;
             if (d < p.dh) {
                 *reinterpret_cast<u32x2*>(dvp + d) = pack4(adv[kb][dt][0], adv[kb][dt][1], adv[kb][dt][2], adv[kb][dt][3]);
-                *reinterpret_cast<u32x2*>(dkp + d) = pack4(adk[kb][dt][0] * p.scale, adk[kb][dt][1] * p.scale,
-                                                           adk[kb][dt][2] * p.scale, adk[kb][dt][3] * p.scale);
+                const float ns = -p.scale;                   // the accumulators hold -dS^T Q
+                *reinterpret_cast<u32x2*>(dkp + d) = pack4(adk[kb][dt][0] * ns, adk[kb][dt][1] * ns, adk[kb][dt][2] * ns,
+                                                           adk[kb][dt][3] * ns);
             }
         }
     }
@@ -961,3 +1047,9 @@ int yat_sdpa_bwd_packed(int B, int N, int T, int H, int dh, float scale, const v
 }
 
 }  // extern "C"
+
+#ifdef YAT_SDPA_STAMPS
+extern "C" int yat_debug_sdpa_stamps(unsigned int* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(yat_sdpa_stamp_buf), sizeof(unsigned int) * 136);
+}
+#endif
