@@ -11,6 +11,7 @@ lib = L.load()
 fn = lib.yat_debug_sdpa_stamps
 fn.argtypes = [ctypes.c_void_p]
 buf = (ctypes.c_uint32 * 136)()
+FWD = ["wait+bar", "stage", "S mfma", "softmax", "PV mfma"]
 DQ = ["wait+bar", "stage", "S,dP mfma", "softmax", "dQ mfma"]
 DKV = ["wait+bar", "stage", "S,dP h0", "softmax h0", "dV,dK h0", "S,dP h1", "softmax h1", "dV,dK h1"]
 for name, B, N, H, dh in (("pixart", 8, 4096, 16, 72), ("sd3.5", 8, 4429, 24, 64)):
@@ -24,13 +25,16 @@ for name, B, N, H, dh in (("pixart", 8, 4096, 16, 72), ("sd3.5", 8, 4429, 24, 64
     sc = 1 / math.sqrt(dh)
     ops.sdpa_fwd(q, k, v, B, N, N, H, dh, sc, None, None, out, lse)
     a = (q, k, v, B, N, N, H, dh, sc, None, None, out, dout, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
-    for part, names in ((1, DQ), (2, DKV)):
+    for part, names in ((0, FWD), (1, DQ), (2, DKV)):
         for _ in range(3):
-            ops.sdpa_bwd(*a, parts=part)
+            if part == 0:
+                ops.sdpa_fwd(q, k, v, B, N, N, H, dh, sc, None, None, out, lse)
+            else:
+                ops.sdpa_bwd(*a, parts=part)
         torch.cuda.synchronize()
         assert fn(ctypes.addressof(buf)) == 0
         n = buf[128]
         for w in range(4):
             per = [buf[w * 16 + i] / n for i in range(len(names))]
-            print(f"{name} {'dq ' if part == 1 else 'dkv'} wave {w} tiles {n}: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, per))
+            print(f"{name} {('fwd', 'dq ', 'dkv')[part]} wave {w} tiles {n}: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, per))
                   + f"  | total {sum(per):6.0f}", flush=True)

@@ -304,11 +304,14 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     const float lazy = LAZY_LOG2 / ce;              // the threshold in the units of m
 
     int it = 0;
+    SD_STAMP_BEGIN();
     for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
         char* cur = smem + (it & 1) * FWD_STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // tile `it` landed for every wave; stage (it+1)&1 is free
+        SD_STAMP(0);
         if (k0 + 64 < klim) stage(k0 + 64, smem + ((it + 1) & 1) * FWD_STAGE);
+        SD_STAMP(1);
         if constexpr (!NOBIAS) mask_tail_bias(cur + 2 * TILE, k0, p.T, wave, lane);
         const char* Ks = cur;
         const char* Vs = cur + TILE;
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
                     for (int r = 0; r < 4; ++r) s[qs][nj][r] = __builtin_fmaf(s[qs][nj][r], p.scale, bv[r]);
             }
         }
+        SD_STAMP(2);
         SD_PRIO(YAT_SDPA_PRIO_FWD, 0);
         // tile maxima; does any row of this wave outrun its reference by more than the threshold?
         float mx[QS];
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
             pf0[qs] = acc_to_frag(s[qs][0], s[qs][1]);
             pf1[qs] = acc_to_frag(s[qs][2], s[qs][3]);
         }
+        SD_STAMP(3);
         SD_PRIO(YAT_SDPA_PRIO_FWD, 1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -401,7 +406,12 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
                 o[qs][dt] = mfma16(v1, pf1[qs], o[qs][dt]);
             }
         }
+        SD_STAMP(4);
+#ifdef YAT_SDPA_STAMPS
+        ++st_n;
+#endif
     }
+    SD_STAMP_END(bx == 3 && h == 1 && b == 0);
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         if constexpr (ONES) {
@@ -831,7 +841,11 @@ __global__ __launch_bounds__(64 * NW, (KS <= 3 && NW == 4) ? 2 : 1) void sdpa_bw
     }
 }
 
+#ifdef YAT_SDPA_ONE_WG            // diagnostic: LDS padded so that one workgroup fits a CU (a wave alone on its SIMD)
+constexpr int FWD_LDS = 100 * 1024, DQ_LDS = 100 * 1024, DKV_LDS = 100 * 1024;
+#else
 constexpr int FWD_LDS = 2 * FWD_STAGE, DQ_LDS = 2 * DQ_STAGE, DKV_LDS = 2 * DKV_STAGE;
+#endif
 
 // The LDS images stay 128 columns wide (columns past dh are zero-filled by the DMA range check); what the head dim decides
 // is how many of the 32-wide k-steps (KS) and 16-wide output tiles (DT) carry data.  Instantiations: dh <= 32 (SANA's
