@@ -27,11 +27,20 @@ int main() {
     float* out; unsigned* ticks; unsigned h[2];
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&ticks, 8);
     const int n = 10000;
-    for (int r = 0; r < 2; ++r) {
-        hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, out, ticks, n);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.f;
+    for (int r = 0; r < 3; ++r) {
         hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, out, ticks, n);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k<0>, dim3(1024), dim3(256), 0, 0, out, ticks, 20 * n);       // 4 workgroups per CU: every SIMD 4 waves deep
+        hipEventRecord(e1, 0);
         hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
     }
+    hipMemcpy(h, ticks, 8, hipMemcpyDeviceToHost);
+    printf("loaded chip: %u s_memtime ticks in a %.3f ms kernel = %.3f ticks per ns\n", h[0], ms, h[0] / (ms * 1e6));
+    hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, out, ticks, n);
+    hipDeviceSynchronize();
     hipMemcpy(h, ticks, 8, hipMemcpyDeviceToHost);
     printf("16x16x32: %.2f ticks per MFMA   16x16x16: %.2f ticks per MFMA\n", h[0] / (4.0 * n), h[1] / (4.0 * n));
     return 0;

@@ -34,6 +34,7 @@ for name, B, N, H, dh in (("pixart", 8, 4096, 16, 72), ("sd3.5", 8, 4429, 24, 64
         torch.cuda.synchronize()
         assert fn(ctypes.addressof(buf)) == 0
         n = buf[128]
+        print(f"{name} part {part}: loop {buf[129]} s_memtime ticks in {buf[130]} ticks of the 100 MHz clock -> {buf[129] / max(buf[130], 1) / 10:.3f} GHz", flush=True)
         for w in range(4):
             per = [buf[w * 16 + i] / n for i in range(len(names))]
             print(f"{name} {('fwd', 'dq ', 'dkv')[part]} wave {w} tiles {n}: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, per))

@@ -33,12 +33,15 @@ __device__ unsigned int yat_sdpa_stamp_buf[8 * 16 + 8];
         st_prev = now_;                                                 \
         __builtin_amdgcn_sched_barrier(0);                              \
     } while (0)
-#define SD_STAMP_BEGIN() uint32_t st_sum[16] = {}; uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime(); int st_n = 0
+#define SD_STAMP_BEGIN() uint32_t st_sum[16] = {}; uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime(); int st_n = 0; \
+    const uint32_t st_t0 = st_prev; const uint32_t st_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime()
 #define SD_STAMP_END(cond)                                                                  \
     do {                                                                                    \
         if ((cond) && lane == 0) {                                                          \
             for (int i_ = 0; i_ < 16; ++i_) yat_sdpa_stamp_buf[wave * 16 + i_] = st_sum[i_];  \
             yat_sdpa_stamp_buf[128] = (unsigned)st_n;                                        \
+            if (wave == 0) { yat_sdpa_stamp_buf[129] = (uint32_t)__builtin_amdgcn_s_memtime() - st_t0;       \
+                             yat_sdpa_stamp_buf[130] = (uint32_t)__builtin_amdgcn_s_memrealtime() - st_r0; } \
         }                                                                                   \
     } while (0)
 #else
@@ -447,8 +450,9 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
 // Stage = K (TR-swizzled image: read row-wise for S = Q K^T and transposed for dQ = dS K), V (ROW image), key bias.
 // Two stages, one barrier per key tile, as in the forward.
 constexpr int DQ_STAGE = 2 * TILE + 256;
-template <int KS, int DT, int QS, bool NOBIAS>
-__global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
+template <int KS, int DT, int QS, bool NOBIAS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void sdpa_bwd_dq_kernel(SdpaP p) {
+    // NW waves: the workgroup covers 16 * NW * QS queries and shares each key tile's LDS-DMA among them
     // NOBIAS (no key bias, every key attends): P = exp2(s * (scale log2e) - lse log2e) in one FMA + exp, no bias tile.  Keys
     // past T in the last tile need no mask here: their K rows are zero-filled, so whatever dS they get multiplies zeros.
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     int bx, h, b;
     if (p.xcd_remap) xcd_contiguous3(bx, h, b);
     else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
-    const int q0 = bx * (64 * QS) + wave * (16 * QS);               // QS 16-query sub-tiles per wave, as in the forward
+    const int q0 = bx * (16 * NW * QS) + wave * (16 * QS);               // QS 16-query sub-tiles per wave, as in the forward
     const int kvl = (!NOBIAS && p.kv_len) ? p.kv_len[b] : 0;
     const int klim = kvl > 0 ? kvl : p.T;
     const int col0 = h * p.dh;
@@ -466,10 +470,10 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_kernel(SdpaP p) {
     const float ce = p.scale * LOG2E;
 
     const int64_t kvr0 = kv_row0(p, b), kvrl = kv_row_limit(p, kvr0, klim);
-    const TileSrc<> src_k = tile_src<IMG_TR>(p.ldkv, p.dh, wave, lane), src_v = tile_src<IMG_ROW>(p.ldkv, p.dh, wave, lane);
+    const TileSrc<NW> src_k = tile_src<IMG_TR, NW>(p.ldkv, p.dh, wave, lane), src_v = tile_src<IMG_ROW, NW>(p.ldkv, p.dh, wave, lane);
     auto stage = [&](int k0, char* base) {
-        stage_tile(tile_rsrc(p.k, kvr0 + k0, kvrl, p.ldkv, col0), base, src_k, wave);
-        stage_tile(tile_rsrc(p.v, kvr0 + k0, kvrl, p.ldkv, col0), base + TILE, src_v, wave);
+        stage_tile<NW>(tile_rsrc(p.k, kvr0 + k0, kvrl, p.ldkv, col0), base, src_k, wave);
+        stage_tile<NW>(tile_rsrc(p.v, kvr0 + k0, kvrl, p.ldkv, col0), base + TILE, src_v, wave);
         if (!NOBIAS && wave == 0) {
             const int key = k0 + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (YAT_LDS void*)(base + 2 * TILE), 4,
@@ -894,17 +898,21 @@ int launch_fwd_nobias(const SdpaP& p, int B, int wide, hipStream_t stream) {
     // (dh 104 would need <4, 7>: its ones column sits in output tile 6, not 7 -- not a head dim of any model here)
     return -100;            // no ONES instantiation: the caller falls back to the head-dim classes
 }
+#ifndef YAT_SDPA_DQ_NW
+#define YAT_SDPA_DQ_NW 4
+#endif
 template <int KS, int DT, int QS>
 int launch_dq_qs(const SdpaP& p, int B, hipStream_t stream) {
-    const void* fn = p.bias ? (const void*)sdpa_bwd_dq_kernel<KS, DT, QS, false> : (const void*)sdpa_bwd_dq_kernel<KS, DT, QS, true>;
+    constexpr int NW = QS >= 2 ? YAT_SDPA_DQ_NW : 4;
+    const void* fn = p.bias ? (const void*)sdpa_bwd_dq_kernel<KS, DT, QS, false, NW> : (const void*)sdpa_bwd_dq_kernel<KS, DT, QS, true, NW>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[p.bias ? 0 : 1]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS) != hipSuccess) return YAT_EINVAL;
         attr_set[p.bias ? 0 : 1] = true;
     }
-    const dim3 grid((p.N + 64 * QS - 1) / (64 * QS), p.H, B);
-    if (p.bias) hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS, false>), grid, dim3(256), DQ_LDS, stream, p);
-    else hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS, true>), grid, dim3(256), DQ_LDS, stream, p);
+    const dim3 grid((p.N + 16 * NW * QS - 1) / (16 * NW * QS), p.H, B);
+    if (p.bias) hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS, false, NW>), grid, dim3(64 * NW), DQ_LDS, stream, p);
+    else hipLaunchKernelGGL((sdpa_bwd_dq_kernel<KS, DT, QS, true, NW>), grid, dim3(64 * NW), DQ_LDS, stream, p);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
