@@ -25,6 +25,19 @@
 // ticks they spent there (backward kernels); the product build contains none of this.
 #ifdef YAT_SDPA_STAMPS
 __device__ unsigned int yat_sdpa_stamp_buf[8 * 16 + 8];
+// per workgroup: 100 MHz time at kernel entry, loop entry, loop exit, kernel exit; HW_ID; XCC_ID (wave 0 writes)
+__device__ unsigned int yat_sdpa_wg_times[4096 * 6];
+#define SD_WG_T(slot)                                                                                              \
+    do {                                                                                                            \
+        const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                        \
+        if (wg_ < 4096 && threadIdx.x == 0) {                                                                       \
+            yat_sdpa_wg_times[wg_ * 6 + slot] = (uint32_t)__builtin_amdgcn_s_memrealtime();                         \
+            if (slot == 0) {                                                                                        \
+                yat_sdpa_wg_times[wg_ * 6 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                         \
+                yat_sdpa_wg_times[wg_ * 6 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                        \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
 #define SD_STAMP(slot)                                                  \
     do {                                                                \
         __builtin_amdgcn_sched_barrier(0);                              \
@@ -45,6 +58,7 @@ __device__ unsigned int yat_sdpa_stamp_buf[8 * 16 + 8];
         }                                                                                   \
     } while (0)
 #else
+#define SD_WG_T(slot) do {} while (0)
 #define SD_STAMP(slot) do {} while (0)
 #define SD_STAMP_BEGIN() do {} while (0)
 #define SD_STAMP_END(cond) do {} while (0)
@@ -240,6 +254,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     // long-sequence variant (self-attention over thousands of keys); QS = 1 keeps more workgroups for short key loops.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SD_WG_T(0);
     const int g = lane >> 4, li = lane & 15;
     // the query blocks of one (image, head) read the same K / V: give them to one XCD (one L2) instead of all eight
     int bx, h, b;
@@ -307,6 +322,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     const float lazy = LAZY_LOG2 / ce;              // the threshold in the units of m
 
     int it = 0;
+    SD_WG_T(1);
     SD_STAMP_BEGIN();
     for (int k0 = 0; k0 < klim; k0 += 64, ++it) {
         char* cur = smem + (it & 1) * FWD_STAGE;
@@ -415,6 +431,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
 #endif
     }
     SD_STAMP_END(bx == 3 && h == 1 && b == 0);
+    SD_WG_T(2);
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         if constexpr (ONES) {
@@ -439,6 +456,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
             if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.N + qi] = m[qs] * (NOBIAS ? p.scale : 1.0f) + __logf(l[qs]);
         }
     }
+    SD_WG_T(3);
 }
 
 // (A software-pipelined forward for the long no-bias key loops -- the Q K^T product of tile t+1 issued beside the exponentials
@@ -1071,6 +1089,9 @@ int yat_sdpa_bwd_packed(int B, int N, int T, int H, int dh, float scale, const v
 }  // extern "C"
 
 #ifdef YAT_SDPA_STAMPS
+extern "C" int yat_debug_sdpa_wg_times(unsigned int* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(yat_sdpa_wg_times), sizeof(unsigned int) * 4096 * 6);
+}
 extern "C" int yat_debug_sdpa_stamps(unsigned int* host_dst) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(yat_sdpa_stamp_buf), sizeof(unsigned int) * 136);
 }
