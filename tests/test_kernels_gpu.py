@@ -604,6 +604,46 @@ def test_sdpa_without_bias_matches_zero_bias(ops, B, N, H, dh):
     assert (lse - res["zero"][1]).abs().max().item() <= 3e-3
 
 
+@pytest.mark.parametrize("B,N,T,H,dh,masked", [(2, 130, 130, 2, 64, False), (2, 200, 200, 2, 72, False), (8, 300, 300, 64, 72, False),
+                                               (2, 100, 140, 2, 112, True), (2, 96, 70, 2, 72, True)])
+def test_sdpa_backward_with_sharp_logits(ops, B, N, T, H, dh, masked):
+    """Logits of +-40 and row log-sum-exps of 20..45: the backward kernels start their S accumulators at -lse / scale (plus
+    the key bias / scale) and their dP accumulators at -delta, so a large lse sits in the accumulator beside the dot product it is
+    subtracted from -- the gradients must still be as good as torch's bf16 kernel measured from the fp32 truth, with and without
+    a masking key bias, on the dense 32-key-per-wave dK/dV (H * B * ceil(T/128) >= 1024) and the work-list path."""
+    D = H * dh
+    scale = 1.0 / math.sqrt(dh)
+    q = rnd(B * N, D, scale=3.5, seed=61)
+    kv = rnd(B * T, 2 * D, scale=3.5, seed=62)
+    kv[:, D:] = rnd(B * T, D, seed=63)
+    k, v = kv[:, :D], kv[:, D:]
+    dout = rnd(B * N, D, seed=64)
+    lens = [T - 37 * (b % 3) for b in range(B)] if masked else [T] * B
+    mask = torch.zeros(B, T)
+    for b, L in enumerate(lens):
+        mask[b, :L] = 1
+    bias = rb((1 - mask.to(BF).float()) * -10000.0).to(DEV) if masked else None
+    kvl = torch.tensor(lens, dtype=torch.int32, device=DEV) if masked else None
+    out, lse = torch.empty(B * N, D, dtype=BF, device=DEV), torch.empty(B, H, N, device=DEV)
+    ops.sdpa_fwd(q, k, v, B, N, T, H, dh, scale, bias, kvl, out, lse)
+    assert lse.max().item() > 20.0                                   # the case this test is about
+    dq, dkv = torch.empty_like(q), torch.full_like(kv, float("nan"))
+    ops.sdpa_bwd(q, k, v, B, N, T, H, dh, scale, bias, kvl, out, dout, lse, torch.empty(B, H, N, device=DEV), dq, dkv[:, :D],
+                 dkv[:, D:], work=ops.kv_work_list(lens, T, DEV) if masked else None)
+
+    def torch_path(dt):
+        heads = lambda x, L: x.to(dt).reshape(B, L, H, dh).transpose(1, 2).clone().requires_grad_(True)
+        qh, kh, vh = heads(q, N), heads(k, T), heads(v, T)
+        mb = None if bias is None else bias.to(dt)[:, None, None, :].expand(B, H, 1, T)
+        o = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mb).transpose(1, 2).reshape(B * N, D)
+        o.backward(dout.to(dt))
+        return [o.detach()] + [t.grad.transpose(1, 2).reshape(-1, D) for t in (qh, kh, vh)]
+    t32, tbf = torch_path(torch.float32), torch_path(BF)
+    as_good_as(out, tbf[0], t32[0], f"sdpa_sharp_fwd dh={dh}")
+    for name, mine, i in (("dq", dq, 1), ("dk", dkv[:, :D], 2), ("dv", dkv[:, D:], 3)):
+        as_good_as(mine, tbf[i], t32[i], f"sdpa_sharp_{name} dh={dh} masked={masked}", tol_flow=2e-2)
+
+
 # ------------------------------------------------------------------------------------------------ GLUMBConv middle
 def _glu_ref(z, wdw, bdw, B, h, w, Hc):
     zi = z.float().view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
