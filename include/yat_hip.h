@@ -428,17 +428,23 @@ int yat_plan_replay(const yat_plan_entry* entries, int n, int* failed_index);
  * buffers and decides WHEN a bucket is ready (the backward schedule, yat_amd/sana.py) -- bucket scheduling is host logic
  * tied to the model's launch order, so it stays with the launch order; this is the transport.  RCCL is bound at run time
  * (the copy the process already holds, else the system librccl.so.1), so the library loads without it.
+ *   yat_comm_available : YAT_OK when RCCL can be bound in this process (no communicator, no socket, no GPU call): lets every
+ *       rank agree that the transport exists BEFORE the collective yat_comm_init, which a missing rank would hang
  *   yat_comm_unique_id : rank 0 draws the 128-byte rendezvous id; the caller ships it to the other ranks (env, store, file)
  *   yat_comm_init      : collective over all `world` ranks; one communicator per process
  *   yat_comm_broadcast : in-place broadcast of `nbytes` from `root` on `stream` (parameters at start-up)
  *   yat_bucket_allreduce_async : records an event on producer_stream, makes comm_stream wait for it, enqueues the in-place
  *       all-reduce(mean) of nbytes/2 bf16 gradients on comm_stream and records the bucket's completion event; returns at
  *       once.  producer_stream == comm_stream skips the first event.  bucket_id in [0, 256).
+ *   yat_comm_allreduce : in-place all-reduce of `count` elements on `stream`, stream-ordered like any kernel; dtype 0 = bf16,
+ *       1 = f32; op 0 = mean, 1 = sum.  For the bulk collectives outside the bucket schedule (the EMA mean over ranks before
+ *       validation, common/trainer.py:374-377), so that they too use the library's one communicator
  *   yat_comm_wait      : compute_stream waits (on the device; the host does not block) for bucket_id, or for every
  *       outstanding bucket when bucket_id < 0
  *   yat_comm_destroy   : releases the communicator and the events
  * ------------------------------------------------------------------------------------------ */
 #define YAT_COMM_ID_BYTES 128
+int yat_comm_available(void);
 int yat_comm_unique_id(void* id_out_128);
 int yat_comm_init(int rank, int world, const void* unique_id_128);
 int yat_comm_world(void);                /* 0 before yat_comm_init */
@@ -446,6 +452,7 @@ int yat_comm_rank(void);                 /* -1 before yat_comm_init */
 int yat_comm_broadcast(void* ptr, uint64_t nbytes, int root, yat_stream_t stream);
 int yat_bucket_allreduce_async(void* ptr, uint64_t nbytes, int bucket_id, yat_stream_t producer_stream,
                                yat_stream_t comm_stream);
+int yat_comm_allreduce(void* ptr, uint64_t count, int dtype, int op, yat_stream_t stream);
 int yat_comm_wait(int bucket_id, yat_stream_t compute_stream);
 int yat_comm_destroy(void);
 const char* yat_comm_last_error(void);

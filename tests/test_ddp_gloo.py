@@ -181,3 +181,80 @@ def test_world2_gloo(tmp_path):
     for r in range(2):
         (tmp_path / f"r{r}").mkdir()
     mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+class _FakeCommLib:
+    """The four entry points NativeComm's rendezvous touches; ``fail_on``: {rank: entry point that returns YAT_ENOCOMM}."""
+
+    def __init__(self, rank, fail_on):
+        self.calls, self._bad = [], fail_on.get(rank)
+
+    def _rc(self, name):
+        self.calls.append(name)
+        return -2 if self._bad == name else 0
+
+    def yat_comm_available(self):
+        return self._rc("available")
+
+    def yat_comm_unique_id(self, buf):
+        return self._rc("unique_id")
+
+    def yat_comm_init(self, rank, world, ident):
+        assert ident is not None and len(ident) == 128
+        return self._rc("init")
+
+    def yat_comm_destroy(self):
+        return self._rc("destroy")
+
+    def yat_comm_last_error(self):
+        return b"stub"
+
+
+def _rendezvous_worker(rank, world, port):
+    """Round-4 advisor: a rank that cannot build the native communicator must take every OTHER rank to the fallback with it,
+    without a hang (rank 0 used to raise before the id broadcast its peers were blocked in) and without anybody entering the
+    collective yat_comm_init alone."""
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from yat_amd import ddp
+    for fail_on in ({0: "available"}, {1: "available"}, {0: "unique_id"}):
+        fake = _FakeCommLib(rank, fail_on)
+        try:
+            ddp.NativeComm(None, lib=fake)
+            raised = False
+        except Exception:       # noqa: BLE001
+            raised = True
+        assert raised, f"rank {rank} built a communicator although {fail_on} failed"
+        assert "init" not in fake.calls                       # nobody entered the collective
+    fake = _FakeCommLib(rank, {})
+    comm = ddp.NativeComm(None, lib=fake)                     # the healthy case: rank 0 drew the id, both initialised
+    assert (comm.rank, comm.world) == (rank, 2) and fake.calls[-1] == "init"
+    assert ("unique_id" in fake.calls) == (rank == 0)
+
+    # HipDDP's agreement on the outcome (negotiate_native): a communicator that fails to build on ONE rank, in yat_comm_init
+    # itself or anywhere else, leaves no rank on the native transport, and the one that was built is destroyed again
+    class _Stub:
+        destroyed = False
+
+        def destroy(self):
+            type(self).destroyed = True
+
+    for bad_rank in (0, 1):
+        _Stub.destroyed = False
+
+        def factory(pg, bad_rank=bad_rank):
+            if rank == bad_rank:
+                raise RuntimeError("no librccl here")
+            return _Stub()
+        native, err = ddp.negotiate_native(None, None, factory)
+        assert native is None
+        assert (err is not None) == (rank == bad_rank) and _Stub.destroyed == (rank != bad_rank)
+    native, err = ddp.negotiate_native(None, None, lambda pg: _Stub())
+    assert isinstance(native, _Stub) and err is None
+    assert ddp.agree(True) and not ddp.agree(rank == 0)
+    dist.destroy_process_group()
+
+
+def test_native_rendezvous_failure_on_one_rank_reaches_every_rank():
+    mp.spawn(_rendezvous_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -327,14 +327,17 @@ def test_reference_nccl_environment_is_not_inherited():
 
 
 def test_default_transport_and_group_backend(monkeypatch):
-    """yat_amd/ddp.py: on a GPU the gradients go through the library's own communicator and the launcher-level group is gloo
-    (one RCCL communicator per process); an explicit YAT_COMM / YAT_DIST_BACKEND wins; CPU jobs use torch.distributed."""
+    """yat_amd/ddp.py: a multi-rank job sends its gradient buckets through torch.distributed's group (nccl on a GPU, gloo on
+    the CPU) unless YAT_COMM=native asks for the library's own communicator -- never run at N > 1, so opt-in (round-4
+    advisor) -- in which case the launcher-level group is gloo (one RCCL communicator per process); YAT_DIST_BACKEND wins."""
     from yat_amd import ddp
     for k in ("YAT_COMM", "YAT_DIST_BACKEND"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
     assert ddp.default_transport() == "torch" and ddp.group_backend(on_gpu=False) == "gloo"
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    assert ddp.default_transport() == "torch" and ddp.group_backend() == "nccl"
+    monkeypatch.setenv("YAT_COMM", "native")
     assert ddp.default_transport() == "native" and ddp.group_backend() == "gloo"
     monkeypatch.setenv("YAT_COMM", "torch")
     assert ddp.default_transport() == "torch" and ddp.group_backend() == "nccl"

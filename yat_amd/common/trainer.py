@@ -79,9 +79,9 @@ class HipAccelerator:
             torch.cuda.set_device(self.device)
         if self.num_processes > 1 and not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            # native transport (the default on a GPU, yat_amd/ddp.py default_transport): the gradients travel through the
-            # library's own RCCL communicator (yat_comm_*); the process group is then only the rendezvous / barrier /
-            # consensus channel and is built over gloo -- no second RCCL communicator with its streams beside the library's
+            # backend of the launcher-level group (yat_amd/ddp.py group_backend): nccl (= RCCL) on a GPU; gloo when the
+            # gradients were asked to travel through the library's own communicator (YAT_COMM=native) -- the group is then
+            # only the rendezvous / barrier / consensus channel, no second RCCL communicator beside the library's
             from ..ddp import group_backend
             backend = backend or group_backend(on_gpu=self.device.type == "cuda")
             dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s))
@@ -478,8 +478,15 @@ class Model:
             trained = opt.model                            # the transformer, or its adapter set
             trained.join_pending_update()                  # the overlapped AdamW/EMA update must have landed
             if opt.ema_shadow is not None and self.accelerator.num_processes > 1:
-                dist.all_reduce(opt.ema_shadow)            # one flat all-reduce instead of ~600 per-tensor calls
-                opt.ema_shadow /= self.accelerator.num_processes
+                # one flat all-reduce instead of ~600 per-tensor calls, through the transport the gradient buckets use (the
+                # library's communicator when it is the transport: the launcher group is then gloo and would stage 3 GB
+                # through the host)
+                ddp = self.accelerator.ddp
+                if ddp is not None:
+                    ddp.allreduce_bulk(opt.ema_shadow, mean=True)
+                else:
+                    dist.all_reduce(opt.ema_shadow)
+                    opt.ema_shadow /= self.accelerator.num_processes
             if self.accelerator.is_main_process:
                 stored = None
                 if opt.ema_shadow is not None:

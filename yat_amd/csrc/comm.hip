@@ -101,6 +101,8 @@ extern "C" {
 
 const char* yat_comm_last_error(void) { return g.last_error; }
 
+int yat_comm_available(void) { return bind_rccl(g.api); }
+
 int yat_comm_unique_id(void* id_out) {
     if (!id_out) return YAT_EINVAL;
     if (int rc = bind_rccl(g.api)) return rc;
@@ -132,6 +134,13 @@ int yat_comm_broadcast(void* ptr, uint64_t nbytes, int root, yat_stream_t stream
     if (!g.comm) return YAT_ENOCOMM;
     if (!ptr || !nbytes || root < 0 || root >= g.world) return YAT_EINVAL;
     return nccl_rc(g.api.Broadcast(ptr, ptr, nbytes, ncclUint8, root, g.comm, (hipStream_t)stream), "ncclBroadcast");
+}
+
+int yat_comm_allreduce(void* ptr, uint64_t count, int dtype, int op, yat_stream_t stream) {
+    if (!g.comm) return YAT_ENOCOMM;
+    if (!ptr || !count || dtype < 0 || dtype > 1 || op < 0 || op > 1) return YAT_EINVAL;
+    return nccl_rc(g.api.AllReduce(ptr, ptr, count, dtype == 0 ? ncclBfloat16 : ncclFloat32, op == 0 ? ncclAvg : ncclSum, g.comm,
+                                   (hipStream_t)stream), "ncclAllReduce");
 }
 
 int yat_bucket_allreduce_async(void* ptr, uint64_t nbytes, int bucket_id, yat_stream_t producer_stream,

@@ -386,6 +386,31 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #endif
     constexpr bool DIC_G1 = DIC || YAT_GEMM_NT_G1C;   // group 1 alone may prefetch tile t+2 from COMPUTE(t,ks1)
 
+#ifndef YAT_GEMM_DEEP
+#define YAT_GEMM_DEEP 1
+#endif
+#ifndef YAT_GEMM_PIN_WAIT
+#define YAT_GEMM_PIN_WAIT 1
+#endif
+#ifndef YAT_GEMM_DEEP_KH
+#define YAT_GEMM_DEEP_KH 1          // the DEEP schedule for a k-contiguous B operand too (round 5: half-major B image, below)
+#endif
+#ifdef YAT_GEMM_STAMPS
+    constexpr bool DEEP = false;                           // (the stamp slots describe the two-stage schedule)
+#else
+    constexpr bool DEEP = YAT_GEMM_DEEP && (B_T || YAT_GEMM_DEEP_KH);
+#endif
+    // B image of a DEEP kernel with a k-contiguous B operand (the forward GEMMs: B = W[N, K]).  The row image of the two-stage
+    // schedule keeps both 32-deep halves of a column in one 128-B row, so no half can be refilled before the other has been
+    // read.  Here the image is HALF-MAJOR: [half h][column n][4 chunks of 16 B] -- 64-B rows, half h at h * 64 * BN bytes --
+    // which makes it piece for piece the shape of the k-strided image (1 KiB = 16 columns of one half; BN / 16 pieces per
+    // half), so the DEEP loop, its batches and its counted waits carry over unchanged.  Chunk c of column n sits at slot
+    // c ^ kh_perm((n >> 2) & 3): the 16 lanes one ds_read_b128 services together (MI355X_MICROARCH.md, LDS) read columns
+    // {0..3, 12..15} of one chunk and {4..11} of its neighbour and land on 16 distinct 16-B slots of the 256-B bank row.
+    constexpr bool B_KH = DEEP && !B_T;
+    auto kh_perm = [](uint32_t x) { return (0x78u >> (2 * x)) & 3u; };          // 0, 2, 3, 1
+    const uint32_t kh_lane = ((uint32_t)(lane & 15) * 64) + ((((uint32_t)lane >> 4) ^ kh_perm((lane & 15) >> 2)) << 4);
+
     // the fragment reads of sub-step kk of the tile in stage t & 1 (the LDS traffic of a LOAD segment)
     auto load_frags = [&](auto grp_c, int t, int kk) {
         constexpr int GRP = decltype(grp_c)::value;
@@ -406,24 +431,18 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         } else if (B_T) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) bfr[j] = frag_tr<G::BN>(b_tr[j] + st + G::A_BYTES, kk);
+        } else if (B_KH) {
+            const char* b0 = cur + G::A_BYTES + kk * (G::B_BYTES / 2) + wc * (16 * NT * 64) + kh_lane;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = lds_read8(b0, j * 1024);
         } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j) bfr[j] = frag256<false, G::BN>(cur + G::A_BYTES, wc * 16 * NT + j * 16, kk, lane);
         }
     };
 
-#ifndef YAT_GEMM_DEEP
-#define YAT_GEMM_DEEP 1
-#endif
-#ifndef YAT_GEMM_DEEP_NN
-#define YAT_GEMM_DEEP_NN 0          // measured (profiles/r04_c_*): cold operands -2 %, the step +0.4 % (76.6 -> 76.9 ms): off
-#endif
 #ifdef YAT_GEMM_STAMPS
     uint32_t st_loop_begin = 0;
-    constexpr bool DEEP = false, DEEP_NN = false;          // (the stamp slots describe the two-stage schedule)
-#else
-    constexpr bool DEEP = YAT_GEMM_DEEP && B_T;            // the DEEP schedule of the header comment: k-strided B (nt, tt)
-    constexpr bool DEEP_NN = YAT_GEMM_DEEP_NN && !A_T && !B_T;
 #endif
     if constexpr (DEEP) {
       auto deep_loop = [&](auto grp_c) {
@@ -453,13 +472,28 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) vao[j] = j == 0 ? va0 : make_piece<false, BM>(pa0 + 4 * j, lane, p.lda, m0, p.M).voff;
         }
-        const uint32_t vb0 = make_piece<true, G::BN>(pb0, lane, p.ldb, n0, p.N).voff;
-        const uint32_t vbx = NB == 3 ? make_piece<true, G::BN>(pbx, lane, p.ldb, n0, p.N).voff : 0;
+        const uint32_t vb0 = B_KH ? 0 : make_piece<true, G::BN>(pb0, lane, p.ldb, n0, p.N).voff;
+        const uint32_t vbx = (NB == 3 && !B_KH) ? make_piece<true, G::BN>(pbx, lane, p.ldb, n0, p.N).voff : 0;
+        // half-major k-contiguous B image (B_KH): piece q of half h = the 64-B half rows of columns 16 q .. 16 q + 15.  The
+        // pieces of a wave are 128 or 160 COLUMNS of N apart, and a scalar-offset delta is outside the buffer range check (past
+        // the last column of a ragged N it would read beyond the operand): each keeps its own per-lane offset with its own column
+        // check; only the half (+ 64 B inside a valid row) and the K-tile advance ride in the scalar offset.
+        constexpr int PH = G::BN / 16;                                                      // pieces per half
+        const uint32_t kchunk_b = ((uint32_t)lane & 3) ^ kh_perm(((uint32_t)lane >> 4) & 3);  // source chunk of a B_KH lane
+        auto kh_q = [&](int i) { return NT == 4 ? pb0 + 8 * i : (i < 2 ? pb0 + 10 * i : pbx); };
+        uint32_t vbk[B_KH ? NB : 1];
+        if (B_KH) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int col = n0 + 16 * kh_q(i) + (lane >> 2);
+                vbk[i] = col < p.N ? (uint32_t)(((int64_t)col * p.ldb + kchunk_b * 8) * 2) : YAT_OOB;
+            }
+        }
         const uint32_t a_row = (uint32_t)p.lda * 2, b_row = (uint32_t)p.ldb * 2;           // bytes per k-row (k-strided)
         const uint32_t kchunk_a = swz128((uint32_t)pa0 * 8 + (lane >> 3), lane & 7);       // (k-contiguous A: the same for all 4)
 
         // one piece: operand / image piece / source offset (per-lane + uniform) / target tile (local index tl)
-        auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, uint32_t delta, int tl) {
+        auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, uint32_t delta, int tl, int kh_half = 0) {
             constexpr bool CHECKED = decltype(checked)::value;
             const int t = kt0 + tl;
             YAT_LDS void* dst = (YAT_LDS void*)(smem + (tl & 1) * G::STAGE + (is_a ? 0 : G::A_BYTES) + pi * 1024);
@@ -467,6 +501,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
             if (CHECKED) {
                 uint32_t v = voff + soff;
                 if (is_a && !A_T && kchunk_a >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
+                if (!is_a && B_KH && kchunk_b + 4 * kh_half >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
                 lds_dma16(is_a ? ra : rb, dst, v);
             } else {
                 lds_dma16s(is_a ? ra : rb, dst, voff, soff);
@@ -478,7 +513,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         };
         auto dma_ao = [&](auto checked, int j, int tl) { dma(checked, true, pa0 + 4 * j, vao[A_T ? 0 : j], 0u, tl); };
         auto dma_bh = [&](auto checked, int h, int i, int tl) {
-            if (NT == 4) dma(checked, false, pb0 + 8 * i + 16 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
+            if (B_KH) dma(checked, false, kh_q(i) + PH * h, vbk[B_KH ? i : 0], 64u * h, tl, h);
+            else if (NT == 4) dma(checked, false, pb0 + 8 * i + 16 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
             else if (i < 2) dma(checked, false, pb0 + 10 * i + 20 * h, vb0, (uint32_t)(16 * i + 32 * h) * b_row, tl);
             else dma(checked, false, pbx + 20 * h, vbx, (uint32_t)(32 * h) * b_row, tl);
         };
@@ -538,7 +574,14 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                         for (int q = 0; q < 8; ++q) racc[q] = mfma16(ones, af[q], racc[q]);
                     }
                     if (idx == 8 * NT - 1) {
-                        if (GRP == 0) wait_g0(fast_c);
+                        // (the counted wait is an asm the scheduler may hoist over the register-only MFMAs -- it did, to right
+                        // behind the segment's last piece, giving up a segment of landing time: pinned behind them)
+                        if (GRP == 0) {
+#if YAT_GEMM_PIN_WAIT
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                            wait_g0(fast_c);
+                        }
                         YAT_PHASE_BARRIER();
                     }
                 }
@@ -594,90 +637,6 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
       };
       if (grp == 0) deep_loop(std::integral_constant<int, 0>{});
       else deep_loop(std::integral_constant<int, 1>{});
-    } else if constexpr (DEEP_NN) {
-      // Both operands k-contiguous (the forward GEMMs): a 128-B row carries both 32-deep halves, so nothing can be refilled
-      // per half.  What the two-stage ring still allows: the pieces of tile t+1 go out at the top of LOAD(t, ks0) as before, but
-      //   * a group loads its OWN 128 rows of A (nobody else reads them), so their wait moves from the end of LOAD(t, ks1) to
-      //     the end of COMPUTE(t, ks1) -- the rendezvous right before the group's first read;
-      //   * group 0, whose COMPUTE(t, ks1) ends with the rendezvous that precedes every first read of tile t+1, waits for ALL
-      //     its pieces there and takes 7 of every 10 B pieces; group 1 keeps the earlier wait for its 3 (B first, counted).
-      // 60 of a tile's 72 pieces get 4 segments to land instead of 3; images, reads and MFMA order unchanged (bit-identical).
-      auto nn_loop = [&](auto grp_c) {
-        constexpr int GRP = decltype(grp_c)::value;
-        constexpr int NB0 = NT == 5 ? 7 : 6, NB1 = NT == 5 ? 3 : 2, NBW = GRP == 0 ? NB0 : NB1;
-        static_assert(4 * NB0 + 4 * NB1 == G::B_BYTES / 1024, "B pieces per tile");
-        const int pa0 = 16 * GRP + wc, pb0 = (GRP ? 4 * NB0 : 0) + wc;
-        uint32_t vao[4], vbw[NBW];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vao[j] = make_piece<false, BM>(pa0 + 4 * j, lane, p.lda, m0, p.M).voff;
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) vbw[j] = make_piece<false, G::BN>(pb0 + 4 * j, lane, p.ldb, n0, p.N).voff;
-        const uint32_t kch = swz128((uint32_t)wc * 8 + (lane >> 3), lane & 7);      // (the same for every piece above)
-        auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, int tl) {
-            constexpr bool CHECKED = decltype(checked)::value;
-            const int t = kt0 + tl;
-            YAT_LDS void* dst = (YAT_LDS void*)(smem + (tl & 1) * G::STAGE + (is_a ? 0 : G::A_BYTES) + pi * 1024);
-            if (CHECKED) {
-                uint32_t v = voff + (uint32_t)t * (uint32_t)(BK * 2);
-                if (kch >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
-                lds_dma16(is_a ? ra : rb, dst, v);
-            } else {
-                lds_dma16s(is_a ? ra : rb, dst, voff, (uint32_t)t * (uint32_t)(BK * 2));
-            }
-        };
-        auto issue_tile = [&](auto checked, int tl) {           // B first: group 1 waits for them one segment earlier
-#pragma unroll
-            for (int j = 0; j < NBW; ++j) dma(checked, false, pb0 + 4 * j, vbw[j], tl);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dma(checked, true, pa0 + 4 * j, vao[j], tl);
-        };
-        auto compute_nn = [&](bool wait_all) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
-                    if (i * NT + j == 8 * NT - 1) {
-                        if (wait_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        YAT_PHASE_BARRIER();
-                    }
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto iteration_nn = [&](auto fast_c, int t) {
-            constexpr bool FAST = decltype(fast_c)::value;
-            if (FAST) issue_tile(std::false_type{}, t + 1);
-            else if (t + 1 < nt) {
-                if (is_tail(t + 1)) issue_tile(std::true_type{}, t + 1);
-                else issue_tile(std::false_type{}, t + 1);
-            }
-            load_frags(grp_c, t, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            YAT_PHASE_BARRIER();
-            compute_nn(false);
-            load_frags(grp_c, t, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (GRP == 1) {                                      // its B pieces of tile t+1 (issued first) have landed
-                if (FAST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            YAT_PHASE_BARRIER();
-            compute_nn(true);                                    // everything of tile t+1 this wave issued has landed
-        };
-        if (is_tail(0)) issue_tile(std::true_type{}, 0);
-        else issue_tile(std::false_type{}, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        YAT_PHASE_BARRIER();                       // rendezvous 0: tile 0 visible to everyone
-        if (GRP == 1) YAT_PHASE_BARRIER();         // stagger: group 1 runs one segment behind group 0
-        const int nfast = max(0, nt - 1 - (ragged && kt0 + nt == nt_all ? 1 : 0));
-        int t = 0;
-        for (; t < nfast; ++t) iteration_nn(std::true_type{}, t);
-        for (; t < nt; ++t) iteration_nn(std::false_type{}, t);
-      };
-      if (grp == 0) nn_loop(std::integral_constant<int, 0>{});
-      else nn_loop(std::integral_constant<int, 1>{});
     } else {
 
     issue(0, smem);

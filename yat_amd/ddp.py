@@ -38,19 +38,17 @@ REFERENCE_NCCL_ENV_NOT_INHERITED = {
 
 
 def default_transport():
-    """Which transport a data-parallel job uses when nothing is said: ``YAT_COMM`` = torch | native wins; a job whose process
-    group was forced onto another backend (``YAT_DIST_BACKEND=gloo``: several ranks sharing one GPU in a rehearsal, where RCCL
-    cannot be used at all) sends its buckets through that group; otherwise on a GPU the library's own communicator
-    (``native``) -- since round 4 the faster configuration: with the rendezvous group on gloo the process holds ONE RCCL
-    communicator, and the forced one-rank rehearsal runs 79.3 ms per step against 85.5 ms through torch.distributed's group
-    (77.0 ms plain; profiles/r04_d_*).  Called in rank processes only (it may initialise the GPU)."""
+    """Which transport a data-parallel job uses when nothing is said.  ``YAT_COMM`` = torch | native wins.  Otherwise
+    ``torch``: the gradient buckets go through torch.distributed's process group (RCCL on a GPU) -- the path every multi-GPU
+    PyTorch job on this image takes.  The library's own communicator (``native``: one RCCL communicator per process, the
+    launcher-level group on gloo) was the faster configuration in every forced ONE-rank rehearsal (79.3 ms per step against
+    85.5 ms through torch's group, 77.0 ms plain; profiles/r04_d_*), but RCCL refuses two ranks on one device and no
+    multi-GPU box was available to the builder, so it has never run with N > 1 ranks: it stays opt-in
+    (``YAT_COMM=native``, ``bench.py --transport native``) until such a run is recorded under profiles/ (round-4 advisor)."""
     env = os.environ.get("YAT_COMM")
     if env:
         return env
-    forced = os.environ.get("YAT_DIST_BACKEND")
-    if forced and forced != "nccl":
-        return "torch"
-    return "native" if torch.cuda.is_available() else "torch"
+    return "torch"
 
 
 def group_backend(on_gpu=True):
@@ -63,6 +61,34 @@ def group_backend(on_gpu=True):
     if not on_gpu:
         return "gloo"
     return "gloo" if default_transport() == "native" else "nccl"
+
+
+def agree(ok, process_group=None, device=None):
+    """True iff ``ok`` holds on every rank of the group: one MIN all-reduce of a flag -- on the host for a gloo group, on
+    ``device`` (default: the current GPU) for an nccl one."""
+    if not (dist.is_initialized() and dist.get_world_size(process_group) > 1):
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(process_group) == "nccl":
+        flag = flag.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+    return bool(int(flag.item()))
+
+
+def negotiate_native(process_group=None, device=None, factory=None):
+    """Every rank builds the library's communicator, then all agree on the outcome: ``(NativeComm, None)`` when every rank has
+    one, else ``(None, first local error or None)`` on EVERY rank, a communicator that was built on this rank destroyed
+    again.  ``factory``: NativeComm.get (tests pass a stub)."""
+    err, native = None, None
+    try:
+        native = (factory or NativeComm.get)(process_group)
+    except Exception as e:              # noqa: BLE001 -- reported by the caller, after the ranks have agreed
+        err = e
+    if agree(err is None, process_group, device):
+        return native, None
+    if native is not None:
+        native.destroy()
+    return None, err
 
 
 class NativeComm:
@@ -86,18 +112,32 @@ class NativeComm:
                                f"{cls._instance.rank} of {cls._instance.world}); the C-ABI transport holds one communicator")
         return cls._instance
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, lib=None):
         from . import lib as _l
-        self._l, self.lib = _l, _l.load()
+        self._l, self.lib = _l, (lib if lib is not None else _l.load())
         multi = dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.rank = dist.get_rank(process_group) if multi else 0
         self.world = dist.get_world_size(process_group) if multi else 1
+        # Rendezvous that cannot strand a rank (round-4 advisor): yat_comm_init is collective, so nobody may enter it
+        # unless EVERY rank can.  (1) every rank binds RCCL, rank 0 also draws the id -- failures are kept, not raised;
+        # (2) rank 0 ALWAYS broadcasts, the id or None; (3) one MIN all-reduce over "I could and I hold an id"; only
+        # then (4) the collective init.  A failure on any rank before (4) raises on all of them, after the same two
+        # collectives on every rank.
+        err, ident = None, [None]
         buf = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            _l.check(self.lib.yat_comm_unique_id(buf), "yat_comm_unique_id")
-        ident = [bytes(buf.raw)]
+        try:
+            _l.check(self.lib.yat_comm_available(), "yat_comm_available")
+            if self.rank == 0:
+                _l.check(self.lib.yat_comm_unique_id(buf), "yat_comm_unique_id")
+                ident = [bytes(buf.raw)]
+        except Exception as e:          # noqa: BLE001 -- raised below, after the ranks have agreed
+            err = e
         if multi:
             dist.broadcast_object_list(ident, src=0, group=process_group)
+            if not agree(err is None and ident[0] is not None, process_group):
+                raise err if err is not None else RuntimeError("NativeComm: another rank cannot build the communicator")
+        elif err is not None:
+            raise err
         _l.check(self.lib.yat_comm_init(self.rank, self.world, ident[0]), "yat_comm_init")
 
     def broadcast(self, t, root=0):
@@ -109,6 +149,15 @@ class NativeComm:
                                                           producer_stream.cuda_stream, comm_stream.cuda_stream),
                       "yat_bucket_allreduce_async")
 
+    def allreduce(self, t, mean=True, stream=None):
+        """In-place all-reduce of a bf16 / fp32 device tensor on ``stream`` (default: the current one), stream-ordered."""
+        code = {torch.bfloat16: 0, torch.float32: 1}.get(t.dtype)
+        if code is None or not t.is_contiguous():
+            raise ValueError("NativeComm.allreduce: contiguous bf16 or fp32 tensors")
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self._l.check(self.lib.yat_comm_allreduce(t.data_ptr(), t.numel(), code, 0 if mean else 1, st.cuda_stream),
+                      "yat_comm_allreduce")
+
     def wait(self, stream, bucket_id=-1):
         self._l.check(self.lib.yat_comm_wait(bucket_id, stream.cuda_stream), "yat_comm_wait")
 
@@ -118,9 +167,11 @@ class NativeComm:
 
 
 class HipDDP:
-    """``transport``: "torch" = torch.distributed's RCCL process group (default for multi-rank jobs: the launcher has built it
-    anyway), "native" = the library's own communicator through the C ABI (``YAT_COMM=native``; also what a forced one-rank
-    rehearsal uses when no process group exists).  Same buckets, same streams, same arithmetic (RCCL mean) either way."""
+    """``transport``: "torch" = the gradient buckets go through torch.distributed's process group (RCCL on a GPU) -- the
+    default of a multi-rank job (``default_transport``); "native" = the library's own communicator through the C ABI
+    (``yat_comm_*``; opt-in with ``YAT_COMM=native``, the launcher-level group is then built over gloo:
+    ``group_backend``).  Same buckets, same streams, same arithmetic (RCCL mean) either way.  ``allreduce_bulk`` sends any
+    other device tensor (the EMA mean before validation) through whichever transport the buckets use."""
 
     def __init__(self, model, process_group=None, average=True, force=False, transport=None):
         self.model = model
@@ -131,7 +182,10 @@ class HipDDP:
         self.sync = True
         self.on_gpu = model.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=model.flat_grad.device) if self.on_gpu else None
-        transport = transport or default_transport()
+        if transport is None:
+            transport = default_transport()
+            if force and self.on_gpu and not dist.is_initialized() and "YAT_COMM" not in os.environ:
+                transport = "native"      # a forced one-rank rehearsal without any process group: only the library can run it
         if transport not in ("torch", "native"):
             raise ValueError(f"transport {transport!r}: torch | native")
         self.native = None
@@ -141,25 +195,11 @@ class HipDDP:
             # Every rank must end up on the same transport: build the communicator, agree on the outcome over the process
             # group, and if ANY rank failed (no librccl, a communicator error) all of them fall back to torch.distributed's
             # RCCL group -- created here, collectively, when the launcher-level group is gloo.
-            err = None
-            try:
-                self.native = NativeComm.get(process_group)
-            except Exception as e:      # noqa: BLE001 -- reported below, after the ranks have agreed
-                err = e
-            ok = 0 if err is not None else 1
-            if dist.is_initialized() and self.world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32)
-                if dist.get_backend(process_group) == "nccl":
-                    flag = flag.to(model.flat_grad.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
-                ok = int(flag.item())
-            if not ok:
+            self.native, err = negotiate_native(process_group, model.flat_grad.device)
+            if self.native is None:
                 import warnings
                 warnings.warn(f"HipDDP: the native transport is not available on every rank ({err!r}); falling back to "
                               f"torch.distributed's RCCL group")
-                if self.native is not None:
-                    self.native.destroy()
-                    self.native = None
                 if not dist.is_initialized():
                     raise err
                 if dist.get_backend(process_group) != "nccl":
@@ -204,6 +244,21 @@ class HipDDP:
                 self.native.broadcast(self.model.flat_param, src)
             else:
                 dist.broadcast(self.model.flat_param, src=src, group=self.pg)
+
+    def allreduce_bulk(self, t, mean=True):
+        """In-place all-reduce of a flat device / host tensor outside the bucket schedule -- the EMA shadow before validation
+        (common/trainer.py:374-377) -- through the transport the gradients use: the library's communicator when it is the
+        transport (a gloo rendezvous group would stage GBs through the host), else this object's process group."""
+        if self.world == 1 and not self.force:
+            return t
+        if self.native is not None and t.is_cuda:
+            self.native.allreduce(t, mean=mean)
+            return t
+        if dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            if mean:
+                t /= dist.get_world_size(self.pg)
+        return t
 
     def track_loss(self, running_sum=None):
         """Arm the piggyback for the coming micro-step; ``running_sum``: the window's earlier micro-step losses (device

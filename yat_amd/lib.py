@@ -107,12 +107,14 @@ SIGNATURES = {
     "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),
     "yat_plan_op_id": (I, [C.c_char_p]),
     "yat_plan_replay": (I, [C.POINTER(PlanEntry), I, C.POINTER(I)]),
+    "yat_comm_available": (I, []),
     "yat_comm_unique_id": (I, [P]),
     "yat_comm_init": (I, [I, I, P]),
     "yat_comm_world": (I, []),
     "yat_comm_rank": (I, []),
     "yat_comm_broadcast": (I, [P, U64, I, P]),
     "yat_bucket_allreduce_async": (I, [P, U64, I, P, P]),
+    "yat_comm_allreduce": (I, [P, U64, I, I, P]),
     "yat_comm_wait": (I, [I, P]),
     "yat_comm_destroy": (I, []),
     "yat_comm_last_error": (C.c_char_p, []),
