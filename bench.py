@@ -308,11 +308,16 @@ def main():
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the serialized GEMM-timing pass")
-    ap.add_argument("--rccl-channels", type=int, default=0, metavar="N",
+    ap.add_argument("--rccl-channels", type=int, default=-1, metavar="N",
                     help="cap RCCL at N channels (NCCL_MAX_NCHANNELS=N before the communicator is built): fewer channels = "
                          "fewer persistent collective workgroups competing with the GEMM tiles for CUs, at lower link "
-                         "bandwidth; 0 = RCCL's default.  The value in force is reported in the `comm` object")
+                         "bandwidth; 0 = RCCL's default; -1 = the policy of yat_amd/ddp.py (16 unless the site set the "
+                         "variable).  The value in force is reported in the `comm` object")
     ap.add_argument("--comm-steps", type=int, default=6, help="steps of each pass of the data-parallel diagnostics")
+    ap.add_argument("--transport", choices=["torch", "native"], default=None,
+                    help="gradient all-reduce transport of an N > 1 job (yat_amd/ddp.py): torch = torch.distributed's RCCL group "
+                         "(default), native = the library's own communicator (yat_comm_*) with the launcher group on gloo")
+    ap.add_argument("--coalesce", type=int, default=1, help="consecutive gradient buckets per collective (1 = one per block)")
     ap.add_argument("--phases", default=None, metavar="FILE",
                     help="after the timed region, time the phases of 6 steps with HIP events and write them to FILE")
     args = ap.parse_args()
@@ -340,6 +345,8 @@ def main():
     # cuda:0 -- RCCL refuses two ranks on one device -- so everything but the transport is exercised.)
     # YAT_COMM=native: gradients go through the library's own RCCL communicator (yat_comm_*, csrc/comm.hip); the process group is
     # then only rendezvous / barrier / max-over-ranks and is built over gloo, so the process holds ONE RCCL communicator
+    if args.transport:
+        os.environ["YAT_COMM"] = args.transport
     from yat_amd.ddp import group_backend
     backend = group_backend()
     ndev = torch.cuda.device_count()
@@ -350,10 +357,8 @@ def main():
     # YAT_DDP_FORCE=1: run the whole data-parallel machinery (RCCL group, bucket hooks on the side stream, comm stream,
     # optimizer wait) even with ONE rank -- the only way to exercise that code path on a single-GPU box.
     force_ddp = os.environ.get("YAT_DDP_FORCE", "0") != "0"
-    if args.rccl_channels > 0:
-        os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
-        if int(os.environ.get("NCCL_MIN_NCHANNELS", "0") or 0) > args.rccl_channels:
-            os.environ["NCCL_MIN_NCHANNELS"] = str(args.rccl_channels)
+    from yat_amd.ddp import apply_channel_policy
+    apply_channel_policy(max(world, 2 if force_ddp else 1), None if args.rccl_channels < 0 else args.rccl_channels)
     if world > 1 or force_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -390,8 +395,21 @@ def main():
                                        "proj"], r=args.lora, alpha=float(args.lora))
         log(f"LoRA rank {args.lora}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
     opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
-                    overlap_update=os.environ.get("YAT_OVERLAP_ADAMW", "1") != "0")
-    ddp = HipDDP(trained, force=force_ddp) if (world > 1 or force_ddp) else None
+                    overlap_update=os.environ.get("YAT_SERIAL", "0") == "0")
+    ddp = HipDDP(trained, force=force_ddp, coalesce=args.coalesce) if (world > 1 or force_ddp) else None
+    # small consensus / timing scalars of the launcher-level group: host tensors when it is gloo (no device round trip)
+    ctl_dev = dev if (world > 1 or force_ddp) and dist.is_initialized() and dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def communicator_view():
+        if ddp is None:
+            return None
+        if ddp.native is not None:
+            from yat_amd import lib as _ylib
+            L = _ylib.load()
+            return {"owner": "libyat_hip.so (yat_comm_*: RCCL bound at run time)", "rank": int(L.yat_comm_rank()),
+                    "world": int(L.yat_comm_world())}
+        return {"owner": f"torch.distributed process group ({dist.get_backend(ddp.pg)})", "rank": dist.get_rank(ddp.pg),
+                "world": dist.get_world_size(ddp.pg)}
     if ddp:
         ddp.broadcast_parameters()
     recipe = SanaRecipe(model, pad_to=512, device=dev)
@@ -466,7 +484,7 @@ def main():
     # default stream, which shares its hardware queue with whatever else the process creates -- with a process group around
     # that was the weight-gradient and optimizer streams, and the step lost 16 ms (profiles/LOG_r01_r03.md section 6, "hardware queues").
     from yat_amd.flat import compute_stream, isolate_streams
-    if os.environ.get("YAT_HP_MAIN", "1") != "0" and isolate_streams():      # (only with a process group around)
+    if isolate_streams():      # (only with a process group around)
         hp = compute_stream(dev)
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)
@@ -488,7 +506,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"host enqueue time {1e3 * issue / args.steps:.1f} ms/step")
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     loss_val = loss_dev.item()
@@ -525,7 +543,7 @@ def main():
         def agreed_ok():
             bad = 0 if state["err"] is None else 1
             if world > 1:
-                f = torch.tensor([bad], dtype=torch.int32, device=dev)
+                f = torch.tensor([bad], dtype=torch.int32, device=ctl_dev)
                 dist.all_reduce(f, op=dist.ReduceOp.MAX)
                 bad = int(f.item())
             return bad == 0
@@ -541,7 +559,7 @@ def main():
             barrier()
             dt = time.perf_counter() - tp
             if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = tt.item()
             return 1e3 * dt / K
@@ -580,6 +598,8 @@ def main():
             big = [(nb, e0.elapsed_time(e1)) for _, nb, e0, e1 in ddp.timed_buckets if nb >= (32 << 20)]
             comm = {
                 "world": world, "forced_one_rank": bool(force_ddp and world == 1),
+                # what the communicator itself says (not the launcher's environment): the driver can see that RCCL saw N ranks
+                "communicator": communicator_view(),
                 "transport": "native (yat_comm_* behind the C ABI)" if ddp.native is not None else f"torch.distributed ({backend})",
                 "buckets_per_step": (ddp.buckets_reduced - n0) / K, "bytes_per_step": (ddp.bytes_reduced - b0) / K,
                 "bucket_mb_min_max": [min(sizes) / 2 ** 20, max(sizes) / 2 ** 20] if sizes else None,
@@ -662,7 +682,7 @@ def main():
     # ---- roofline pass (after the timed region): per-launch GEMM durations by HIP events on the launch stream.
     # The step overlaps independent GEMMs on two streams, so in the timed region two kernels share the CUs and
     # their individual durations overlap; the per-kernel figure is therefore taken with the streams serialized
-    # (YAT_SIDE_WGRAD=0 YAT_OVERLAP_ADAMW=0 YAT_FWD_CHAINS=1 behaviour), same kernels, same shapes, same inputs.
+    # (YAT_SERIAL=1 behaviour), same kernels, same shapes, same inputs.
     timer = None
     if not args.no_gemm_timer:          # every rank runs it (the DDP collectives need all of them); rank 0 reports
         saved = (model.side_wgrad, opt.overlap_update, model.fwd_chains)

@@ -7,6 +7,7 @@ cap) and then times ~0.5 s of launches with one pair of HIP events:
   cold       R rotating (A, B, C) sets, > 1.3 GB in all -- every launch reads its operands from HBM and writes a cold output
   cold_in    rotating A, B; the same C                  -- only the reads are cold
   cold_out   the same A, B; rotating C                  -- only the writes are cold
+  cold_a / cold_b  (PROBE_AB=1) rotating A only / B only, the same C
 
 Diagnostic only."""
 import os
@@ -56,7 +57,11 @@ for lay, m, n, k in SHAPES:
     fl = 2.0 * m * n * k
     est = fl / 1.0e9          # us at 1000 TF/s
     res = {}
-    for mode, si, so in (("hot", ins[:1], outs[:1]), ("cold", ins, outs), ("cold_in", ins, outs[:1]), ("cold_out", ins[:1], outs)):
+    modes = [("hot", ins[:1], outs[:1]), ("cold", ins, outs), ("cold_in", ins, outs[:1]), ("cold_out", ins[:1], outs)]
+    if os.environ.get("PROBE_AB"):            # which operand's coldness costs: rotate only A / only B
+        modes = [("hot", ins[:1], outs[:1]), ("cold", ins, outs), ("cold_a", [(a, ins[0][1]) for a, _ in ins], outs[:1]),
+                 ("cold_b", [(ins[0][0], b) for _, b in ins], outs[:1])]
+    for mode, si, so in modes:
         res[mode] = run(si, so, m, n, k, a_t, b_t, est)
     print(f"{lay} {m:6d}x{n:6d}x{k:6d} R={R}: " + "   ".join(f"{md} {us:7.1f} us ({fl / us / 1e6:5.0f})" for md, us in res.items())
           + f"   cold/hot +{100 * (res['cold'] / res['hot'] - 1):.1f} %", flush=True)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 # streams serialized, one forward chain: the launch mix of bench.py's roofline pass (which the per-launch traffic is quoted for)
-export YAT_SIDE_WGRAD=0 YAT_OVERLAP_ADAMW=0 YAT_FWD_CHAINS=1
+export YAT_SERIAL=1
 PASSES="${1:-sq fetch write}"
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timer"
 run() { # name counters...

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 for n in product "$1"; do
   if [ "$n" = product ]; then export YAT_HIP_LIB=""; else export YAT_HIP_LIB="yat_amd/build/variants/libyat_$n.so"; fi
   for mode in ovl ser; do
-    if [ $mode = ser ]; then export YAT_SIDE_WGRAD=0 YAT_OVERLAP_ADAMW=0 YAT_FWD_CHAINS=1; else unset YAT_SIDE_WGRAD YAT_OVERLAP_ADAMW YAT_FWD_CHAINS; fi
+    if [ $mode = ser ]; then export YAT_SERIAL=1; else unset YAT_SERIAL; fi
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pab_${n}_$mode -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timer > gpurun_out/pab_${n}_$mode.json 2> gpurun_out/pab_${n}_$mode.err; rc=$?
     echo "$n $mode rc=$rc $(python3 -c "import json; d=json.loads(open('gpurun_out/pab_${n}_$mode.json').read().strip().splitlines()[-1]); print(d['ms_per_step'])" 2>&1 | tail -1)"
     [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit $rc

@@ -24,7 +24,7 @@ for s in $STEPS; do
       echo "prof rc=$rc"; find gpurun_out/prof -name "*kernel_stats*" | head -3 ;;
     profserial)   # same bench with every stream joined: the per-kernel durations the roofline figure is taken from
       export TMPDIR=/tmp
-      YAT_SIDE_WGRAD=0 YAT_OVERLAP_ADAMW=0 YAT_FWD_CHAINS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_serial -o prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timer > gpurun_out/prof_serial_bench.json 2> gpurun_out/prof_serial.err; rc=$?
+      YAT_SERIAL=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_serial -o prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timer > gpurun_out/prof_serial_bench.json 2> gpurun_out/prof_serial.err; rc=$?
       echo "profserial rc=$rc"; find gpurun_out/prof_serial -name "*kernel_stats*" | head -3 ;;
     smoke)
       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; rc=$?

@@ -21,7 +21,7 @@ write = 1024.0 * sum(wt.get(k, 0.0) for k in fam) / max(1, sum(wn.get(k, 0) for 
 out = {"kernel_family": "gemm256_kernel / gemm256_grouped_kernel / gemm_bf16_kernel (all variants)", "launches_sampled": launches,
        "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/gpu_pmc.sh, streams serialized: "
-                 "YAT_SIDE_WGRAD=0 YAT_OVERLAP_ADAMW=0 YAT_FWD_CHAINS=1), KiB units, FETCH_SIZE doubled per the gfx950 "
+                 "YAT_SERIAL=1), KiB units, FETCH_SIZE doubled per the gfx950 "
                  "correction of MI355X_MICROARCH.md",
        "source": sys.argv[1] if len(sys.argv) > 1 else "profiles/pmc_per_kernel.txt"}
 json.dump(out, open("profiles/gemm_traffic.json", "w"), indent=1)

@@ -83,6 +83,9 @@ def test_no_kernel_uses_scratch(built_lib):
     with open(path) as f:
         res = json.load(f)
     assert len(res) >= 60, "resource remarks missing"
+    from yat_amd.build import SOURCES
+    seen = {k.split(":")[0] for k in res}
+    assert seen >= set(SOURCES) - {"comm.hip", "plan.hip"}, f"no resource remarks for {set(SOURCES) - seen}"   # (no kernels in those two)
     for name, r in res.items():
         assert r.get("ScratchSize [bytes/lane]", 0) == 0, (name, r)
         assert r.get("VGPRs Spill", 0) == 0, (name, r)

@@ -347,3 +347,20 @@ def test_default_transport_and_group_backend(monkeypatch):
     monkeypatch.setenv("YAT_COMM", "native")
     monkeypatch.setenv("YAT_DIST_BACKEND", "nccl")
     assert ddp.default_transport() == "native" and ddp.group_backend() == "nccl"
+
+
+def test_rccl_channel_policy(monkeypatch):
+    """yat_amd/ddp.py apply_channel_policy: one-rank jobs export nothing; an N > 1 job caps RCCL at RCCL_CHANNEL_CAP unless
+    the site set NCCL_MAX_NCHANNELS itself; an explicit cap wins, lowers a larger NCCL_MIN_NCHANNELS, and 0 leaves RCCL alone."""
+    from yat_amd import ddp
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    assert ddp.apply_channel_policy(1) is None and "NCCL_MAX_NCHANNELS" not in os.environ
+    assert ddp.apply_channel_policy(8) == ddp.RCCL_CHANNEL_CAP and os.environ["NCCL_MAX_NCHANNELS"] == str(ddp.RCCL_CHANNEL_CAP)
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "40")
+    assert ddp.apply_channel_policy(8) == 40 and os.environ["NCCL_MAX_NCHANNELS"] == "40"          # the site's own choice
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "32")
+    assert ddp.apply_channel_policy(8, 8) == 8
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and os.environ["NCCL_MIN_NCHANNELS"] == "8"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    assert ddp.apply_channel_policy(8, 0) is None and "NCCL_MAX_NCHANNELS" not in os.environ

@@ -40,32 +40,122 @@ def _hipcc() -> str:
 
 PLAN_GEN_VERSION = "1"
 
-# Sources whose device assembly is kept (-save-temps) for a structural check after the compile.
-ASM_CHECKED = {"dwconv_glu.hip"}
+# Sources whose device assembly is kept (-save-temps) for a structural check after the compile: source -> checker name.
+ASM_CHECKED = {"dwconv_glu.hip": "check_dwconv_stream_asm", "gemm256.hip": "check_gemm256_deep_asm"}
+
+_VM_OTHER = re.compile(r"(buffer|global)_(load|store|atomic)|flat_|scratch_")
 
 
-def check_dwconv_stream_asm(asm_path: str, sseg: int = 4) -> None:
-    """csrc/dwconv_tile_fwd.inc, dwglu_stream_kernel: the LDS-DMA prefetch of the next rows is awaited with ``s_waitcnt
+def _asm_functions(text, pattern):
+    """[(mangled name, instruction-and-label lines)] of every function whose mangled name matches ``pattern``."""
+    lines = text.split("\n")
+    out = []
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\S*):", l)
+        if m and re.search(pattern, m.group(1)):
+            end = next((k for k in range(i, len(lines)) if ".amdhsa_kernel" in lines[k] or lines[k].startswith(".Lfunc_end")), len(lines))
+            out.append((m.group(1), lines[i + 1:end]))
+    return out
+
+
+def _asm_loops(body):
+    """The loops the compiler annotated in one function: [(header label, [instruction lines])].  A loop = its header block
+    plus every block marked ``in Loop: Header=<label>`` (the annotation sits on the block's label line or the line after)."""
+    blocks, cur = [], None                       # (label or None, comment text, [instructions])
+    for l in body:
+        t = l.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)", t)
+        if m or t.startswith("; %bb."):
+            cur = [m.group(1) if m else None, m.group(2) if m else t, []]
+            blocks.append(cur)
+            continue
+        if cur is None:
+            continue
+        if t.startswith(";"):
+            cur[1] += " " + t                    # (continuation of the block's comment: "in Loop: Header=...")
+        elif t and not t.startswith("."):
+            cur[2].append(t)
+    loops = []
+    for lab, com, _ in blocks:
+        if lab and "Loop Header" in com:
+            key = lab.lstrip(".L")
+            ins = []
+            for l2, c2, i2 in blocks:
+                if l2 == lab or re.search(rf"in Loop: Header={key}\b", c2):
+                    ins += i2
+            loops.append((lab, ins))
+    return loops
+
+
+def check_dwconv_stream_asm(asm_path: str) -> None:
+    """csrc/dwconv_tile_fwd.inc, dwglu_stream_kernel<SSEG>: the LDS-DMA prefetch of the next rows is awaited with ``s_waitcnt
     vmcnt(3*SSEG)`` -- correct only while every wave issues EXACTLY 3*SSEG vector-memory operations (the u / y stores) after
     the prefetch in every step.  A compiler that spills, splits or merges a store, or adds any other vector-memory
     operation to the loop would make the wait return early and the kernel read stale ring rows without any test on this
-    toolchain noticing (round-3 advisor finding).  Fail the BUILD instead: the kernel must contain exactly 3*SSEG buffer
-    stores, the counted wait, no scratch / flat operation, and no plain load after the first LDS-DMA."""
-    text = open(asm_path).read().split("\n")
-    start = next((i for i, l in enumerate(text) if re.match(r"^_Z\S*dwglu_stream_kernel\S*:", l)), None)
-    if start is None:
+    toolchain noticing (round-3 advisor finding).  Fail the BUILD instead: EVERY instantiation (SSEG read from its mangled
+    name) must contain exactly 3*SSEG buffer stores, the counted wait, no scratch / flat operation, and no plain load after
+    the first LDS-DMA."""
+    funcs = _asm_functions(open(asm_path).read(), r"dwglu_stream_kernelILi\d+E")
+    if not funcs:
         raise RuntimeError("dwglu_stream_kernel not found in " + asm_path)
-    end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])
-    ins = [l.strip() for l in text[start:end] if l.strip() and not l.strip().startswith((";", "."))]
-    stores = [l for l in ins if re.match(r"(buffer|global)_store", l)]
-    bad = [l for l in ins if l.startswith(("scratch_", "flat_")) or re.match(r"(buffer|global)_atomic", l)]
-    first_dma = next((i for i, l in enumerate(ins) if l.startswith("buffer_load") and " lds" in l), None)
-    late_loads = [l for l in ins[first_dma:] if re.match(r"(buffer|global)_load", l) and " lds" not in l] if first_dma is not None else ["<no LDS-DMA>"]
-    waits = [l for l in ins if re.match(rf"s_waitcnt vmcnt\({3 * sseg}\)", l)]
-    if len(stores) != 3 * sseg or bad or late_loads or len(waits) != 1:
-        raise RuntimeError(f"dwglu_stream_kernel no longer matches its `s_waitcnt vmcnt({3 * sseg})`: {len(stores)} stores "
-                           f"(want {3 * sseg}), {len(waits)} counted wait(s) (want 1), scratch/flat/atomic ops {bad[:3]}, loads after "
-                           f"the first LDS-DMA {late_loads[:3]} -- fix the kernel or fall back to vmcnt(0) there")
+    for name, body in funcs:
+        sseg = int(re.search(r"dwglu_stream_kernelILi(\d+)E", name).group(1))
+        ins = [l.strip() for l in body if l.strip() and not l.strip().startswith((";", "."))]
+        stores = [l for l in ins if re.match(r"(buffer|global)_store", l)]
+        bad = [l for l in ins if l.startswith(("scratch_", "flat_")) or re.match(r"(buffer|global)_atomic", l)]
+        first_dma = next((i for i, l in enumerate(ins) if l.startswith("buffer_load") and " lds" in l), None)
+        late_loads = [l for l in ins[first_dma:] if re.match(r"(buffer|global)_load", l) and " lds" not in l] if first_dma is not None else ["<no LDS-DMA>"]
+        waits = [l for l in ins if re.match(rf"s_waitcnt vmcnt\({3 * sseg}\)", l)]
+        if len(stores) != 3 * sseg or bad or late_loads or len(waits) != 1:
+            raise RuntimeError(f"{name} no longer matches its `s_waitcnt vmcnt({3 * sseg})`: {len(stores)} stores "
+                               f"(want {3 * sseg}), {len(waits)} counted wait(s) (want 1), scratch/flat/atomic ops {bad[:3]}, loads after "
+                               f"the first LDS-DMA {late_loads[:3]} -- fix the kernel or fall back to vmcnt(0) there")
+
+
+def check_gemm256_deep_asm(asm_path: str) -> None:
+    """csrc/gemm256.hip, DEEP schedule: the K loop's FAST form waits for an LDS-DMA batch with ``s_waitcnt vmcnt(n)``, n = the
+    pieces of the two younger batches -- correct only while a wave's loop iteration issues EXACTLY the pieces the source
+    counts (PER_TILE = NAO + 2 NAH + 2 NB per K-tile) and no other vector-memory operation: one spilled register, one
+    compiler-split load or a stray global access inside the loop and every gradient GEMM reads LDS bytes that have not
+    landed, with no test on this one toolchain bound to notice (round-4 review).  Per instantiation (layout and tile width
+    from the mangled name) the build therefore requires: exactly two loops with counted waits (wave group 0 and 1), each
+    with exactly its PER_TILE LDS-DMA loads, wait values exactly those of wait_g0 / wait_g1, no other buffer / global / flat
+    / scratch operation inside them; every other loop that issues LDS-DMA waits with vmcnt(0) only; no scratch anywhere."""
+    funcs = _asm_functions(open(asm_path).read(), r"gemm256_(grouped_)?kernelILb[01]ELb[01]ELi[45]E")
+    if not funcs:
+        raise RuntimeError("no gemm256 kernel found in " + asm_path)
+    for name, body in funcs:
+        a_t, b_t, nt = re.search(r"kernelILb([01])ELb([01])ELi([45])E", name).groups()
+        nao, nah = (0, 2) if a_t == "1" else (4, 0)
+        want = []                                                      # (pieces per iteration, wait values) of group 0, 1
+        for grp, nb in ((0, 2), (1, 3 if nt == "5" else 2)):
+            per_tile = nao + 2 * nah + 2 * nb
+            want.append((per_tile, {per_tile} if grp == 0 or not nao else {2 * nb + nao, 2 * nb}))
+        if any(l.strip().startswith("scratch_") for l in body):
+            raise RuntimeError(f"{name}: scratch access (a spill) in a gemm256 kernel")
+        fast = []
+        for label, ins in _asm_loops(body):
+            dma = [l for l in ins if l.startswith("buffer_load") and " lds" in l]
+            other = [l for l in ins if _VM_OTHER.match(l) and not (l.startswith("buffer_load") and " lds" in l)]
+            counted = [int(m.group(1)) for l in ins for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", l)] if m and int(m.group(1)) > 0]
+            if not dma:
+                if counted:
+                    raise RuntimeError(f"{name} {label}: counted vmcnt wait in a loop without LDS-DMA")
+                continue
+            if not counted:
+                continue                          # the general form of the loop: vmcnt(0) everywhere
+            if other:
+                raise RuntimeError(f"{name} {label}: vector-memory operations other than LDS-DMA inside a loop with counted "
+                                   f"waits: {other[:3]}")
+            sig = (len(dma), set(counted))
+            if sig not in want:
+                raise RuntimeError(f"{name} {label}: {len(dma)} LDS-DMA loads per iteration with waits {sorted(set(counted))}; the "
+                                   f"source counts on {[(k, sorted(v)) for k, v in want]} (pieces, waits) -- fix the kernel or "
+                                   f"fall back to vmcnt(0)")
+            fast.append(sig)
+        if len(fast) != 2 or any(w not in fast for w in want):
+            raise RuntimeError(f"{name}: expected one counted-wait loop per wave group {[(k, sorted(v)) for k, v in want]}, "
+                               f"found {[(k, sorted(v)) for k, v in fast]}")
 
 
 def generate_plan_dispatch(out_path: str) -> None:
@@ -116,10 +206,26 @@ def _digest() -> str:
             with open(path, "rb") as f:
                 h.update(f.read())
     h.update(PLAN_GEN_VERSION.encode())
-    h.update(repr(sorted(ASM_CHECKED)).encode())
+    h.update(repr(sorted(ASM_CHECKED.items())).encode())
     h.update(" ".join(FLAGS).encode())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
+
+
+def parse_resource_remarks(stderr: str, src: str) -> dict:
+    """-Rpass-analysis=kernel-resource-usage remarks of one compile -> {"<src>:<mangled kernel>": {field: value}}.  With
+    -save-temps (the assembly-checked sources) every remark carries a file:line:col prefix; without, none."""
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark:.*?\bFunction Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(f"{src}:{m.group(1)}", {})
+            continue
+        m = re.search(r"remark:.*?\s(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill|Occupancy \[waves/SIMD\]|"
+                      r"LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return out
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -156,20 +262,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
             asm = [f for f in os.listdir(temps) if f.endswith(".s") and "amdgcn" in f]
             if len(asm) != 1:
                 raise RuntimeError(f"{src}: expected one device assembly file in {temps}, found {asm}")
-            if src == "dwconv_glu.hip":
-                check_dwconv_stream_asm(os.path.join(temps, asm[0]))
+            globals()[ASM_CHECKED[src]](os.path.join(temps, asm[0]))
             shutil.copyfile(obj_out, obj)
             shutil.rmtree(temps, ignore_errors=True)
-        cur = None
-        for line in r.stderr.splitlines():
-            m = re.search(r"remark:\s+Function Name: (\S+)", line)
-            if m:
-                cur = resources.setdefault(f"{src}:{m.group(1)}", {})
-                continue
-            m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill|Occupancy \[waves/SIMD\]|"
-                          r"LDS Size \[bytes/block\]): (\d+)", line)
-            if m and cur is not None:
-                cur[m.group(1)] = int(m.group(2))
+        resources.update(parse_resource_remarks(r.stderr, src))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:

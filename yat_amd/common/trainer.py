@@ -69,7 +69,8 @@ class HipAccelerator:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if device is None:
             if torch.cuda.is_available():
-                if os.environ.get("YAT_DIST_BACKEND", "nccl") != "nccl":     # one-GPU rehearsal: ranks share the devices present
+                from ..ddp import forced_backend
+                if (forced_backend() or "nccl") != "nccl":                    # one-GPU rehearsal: ranks share the devices present
                     local %= max(torch.cuda.device_count(), 1)
                 device = torch.device("cuda", local)
             else:
@@ -82,8 +83,9 @@ class HipAccelerator:
             # backend of the launcher-level group (yat_amd/ddp.py group_backend): nccl (= RCCL) on a GPU; gloo when the
             # gradients were asked to travel through the library's own communicator (YAT_COMM=native) -- the group is then
             # only the rendezvous / barrier / consensus channel, no second RCCL communicator beside the library's
-            from ..ddp import group_backend
+            from ..ddp import apply_channel_policy, group_backend
             backend = backend or group_backend(on_gpu=self.device.type == "cuda")
+            apply_channel_policy(self.num_processes)     # (before any RCCL communicator exists)
             dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s))
         self.is_main_process = self.process_index == 0
         self.sync_gradients = True
@@ -164,9 +166,9 @@ def _step_stream(dev):
     engine's streams around, the default stream shared a queue with the weight-gradient and optimizer streams and the step
     lost 16 ms ("hardware queues").  In a data-parallel job the compute streams are therefore the only
     users of the high-priority level -- four streams, four queues; without a process group nothing changes
-    (``flat.isolate_streams``).  ``YAT_HP_MAIN=0`` keeps the default stream."""
+    (``flat.isolate_streams``)."""
     from ..flat import compute_stream, isolate_streams
-    if torch.device(dev).type != "cuda" or os.environ.get("YAT_HP_MAIN", "1") == "0" or not isolate_streams():
+    if torch.device(dev).type != "cuda" or not isolate_streams():
         yield
         return
     prev = torch.cuda.current_stream(dev)

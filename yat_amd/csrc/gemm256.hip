@@ -241,10 +241,33 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // loop-invariant registers of make_piece.  The scalar offset is not part of the buffer range check, so the two cases that
     // lean on per-lane checks -- the ragged last k-tile (row-mode chunks past K, k-strided rows past K) -- take the CHECKED
     // form (per-lane add + compare) instead; which form a segment uses is one uniform branch per segment, not per piece.
-    auto is_tail = [&](int tl) { return ragged && kt0 + tl == nt_all - 1; };
+    // K rotation (round 5).  Workgroups that share an operand panel run their K loops in lockstep, so every one of them sits
+    // behind the same HBM miss at the same time: with operands from HBM the forward GEMMs lose 11 .. 20 % and the prefetch
+    // window of the LDS ring (1.2 .. 1.5 us) cannot be made longer (scripts/gemm_sustained_probe.py PROBE_AB=1: cold A and
+    // cold B cost about the same, and add up).  The sharers of a B panel inside one XCD are the GROUP row tiles of a row
+    // group (tile order below); row tile tm therefore starts its loop (tm % KROT) / KROT of the way into K and wraps around:
+    // each sharer is the first to touch a B line -- and waits for HBM -- for 1 / KROT of its loop only; for the rest it runs
+    // over lines a neighbour fetched 1 / KROT of a loop earlier (L2 or Infinity Cache).  B is the operand that is cold in
+    // the step: weights in the forward and input-gradient GEMMs, saved activations in the weight-gradient ones.  A ragged
+    // last K-tile keeps its place at the end (the FAST loop form counts on it).  The fp32 accumulation order of a tile
+    // changes with its row tile, deterministically; -DYAT_GEMM_KROT=1 is the unrotated loop.
+#ifndef YAT_GEMM_KROT
+#define YAT_GEMM_KROT 4
+#endif
+#ifndef YAT_GEMM_KROT_DIM
+#define YAT_GEMM_KROT_DIM 0          // 0: by row tile (spreads the sharers of a B panel); 1: by column tile (A panel); 2: by tm + tn
+#endif
+    const int nrot = nt - ((ragged && kt0 + nt == nt_all) ? 1 : 0);               // full K-tiles of this slice
+    const int kcls = (YAT_GEMM_KROT_DIM == 0 ? tm : YAT_GEMM_KROT_DIM == 1 ? tn : tm + tn) % YAT_GEMM_KROT;
+    const int krot = (YAT_GEMM_KROT > 1 && nrot > 1) ? (int)(((int64_t)kcls * nrot) / YAT_GEMM_KROT) : 0;
+    auto ktile = [&](int tl) {                                                   // iteration tl of this slice -> global K-tile
+        const int r = tl + krot;
+        return kt0 + (tl < nrot ? (r >= nrot ? r - nrot : r) : tl);
+    };
+    auto is_tail = [&](int tl) { return ragged && ktile(tl) == nt_all - 1; };
     auto piece = [&](auto checked, int tl, char* stage, int j) {
         constexpr bool CHECKED = decltype(checked)::value;
-        const int t = kt0 + tl;
+        const int t = ktile(tl);
         const bool opa = j < G::PA;
         const int jj = opa ? j : j - G::PA;
         if (opa) {
@@ -495,7 +518,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         // one piece: operand / image piece / source offset (per-lane + uniform) / target tile (local index tl)
         auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, uint32_t delta, int tl, int kh_half = 0) {
             constexpr bool CHECKED = decltype(checked)::value;
-            const int t = kt0 + tl;
+            const int t = ktile(tl);
             YAT_LDS void* dst = (YAT_LDS void*)(smem + (tl & 1) * G::STAGE + (is_a ? 0 : G::A_BYTES) + pi * 1024);
             const uint32_t soff = (uint32_t)t * (is_a ? a_kstep : b_kstep) + delta;
             if (CHECKED) {

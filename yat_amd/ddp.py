@@ -45,22 +45,58 @@ def default_transport():
     85.5 ms through torch's group, 77.0 ms plain; profiles/r04_d_*), but RCCL refuses two ranks on one device and no
     multi-GPU box was available to the builder, so it has never run with N > 1 ranks: it stays opt-in
     (``YAT_COMM=native``, ``bench.py --transport native``) until such a run is recorded under profiles/ (round-4 advisor)."""
-    env = os.environ.get("YAT_COMM")
-    if env:
-        return env
-    return "torch"
+    return forced_transport() or "torch"
+
+
+def forced_transport():
+    """``YAT_COMM`` = torch | native, or None."""
+    return os.environ.get("YAT_COMM") or None
+
+
+def forced_backend():
+    """``YAT_DIST_BACKEND`` (gloo: several ranks sharing one GPU in a rehearsal, where RCCL cannot be used at all), or None."""
+    return os.environ.get("YAT_DIST_BACKEND") or None
 
 
 def group_backend(on_gpu=True):
     """Backend of the launcher-level process group: ``YAT_DIST_BACKEND`` if given; gloo when the gradients travel through the
     native transport (the group is then rendezvous / barrier / consensus only -- no second RCCL communicator and its streams
     beside the library's: that pairing cost the step 23 ms in round 3); nccl (= RCCL) otherwise on a GPU."""
-    env = os.environ.get("YAT_DIST_BACKEND")
+    env = forced_backend()
     if env:
         return env
     if not on_gpu:
         return "gloo"
     return "gloo" if default_transport() == "native" else "nccl"
+
+
+# RCCL channel cap of a data-parallel job.  A channel is a persistent workgroup of the collective kernel, and a gemm256
+# workgroup owns its CU outright (144 KiB of LDS, 2 x 250 VGPRs per SIMD: DESIGN.md section 5), so the two never share a CU:
+# while a bucket's all-reduce runs, every channel takes one CU away from the backward.  3.21 GB of gradients per step need
+# ~17 ms of ring time at the xGMI plateau (~190 GB/s algorithm bandwidth at 8 ranks) and have ~50 ms of backward to hide
+# under, so bandwidth is not what the step is short of -- CUs are: 16 channels cost the backward 16 / 256 of its rate while a
+# collective is in flight (~1 - 2 ms per step even if the ring then runs at half the plateau), RCCL's own choice of 32 - 64
+# twice to four times that for a transfer that is hidden either way; the last bucket (the embedders, 88 - 149 MB, nothing left
+# to hide under) costs ~1 ms more at 16.  Never measured on N > 1 GPUs: a site's own NCCL_MAX_NCHANNELS wins, and
+# ``bench.py --rccl-channels N`` (0 = RCCL's default) is there to sweep it.
+RCCL_CHANNEL_CAP = 16
+
+
+def apply_channel_policy(world, cap=None):
+    """Export NCCL_MAX_NCHANNELS for an N > 1 job before any communicator exists; returns the cap in force (None = RCCL's
+    default).  ``cap``: None = the policy above, 0 = leave RCCL alone, N = that many."""
+    if world <= 1:
+        return None
+    if cap is None:
+        if os.environ.get("NCCL_MAX_NCHANNELS"):
+            return int(os.environ["NCCL_MAX_NCHANNELS"])
+        cap = RCCL_CHANNEL_CAP
+    if cap <= 0:
+        return None
+    os.environ["NCCL_MAX_NCHANNELS"] = str(cap)
+    if int(os.environ.get("NCCL_MIN_NCHANNELS", "0") or 0) > cap:
+        os.environ["NCCL_MIN_NCHANNELS"] = str(cap)
+    return cap
 
 
 def agree(ok, process_group=None, device=None):
@@ -173,7 +209,7 @@ class HipDDP:
     ``group_backend``).  Same buckets, same streams, same arithmetic (RCCL mean) either way.  ``allreduce_bulk`` sends any
     other device tensor (the EMA mean before validation) through whichever transport the buckets use."""
 
-    def __init__(self, model, process_group=None, average=True, force=False, transport=None):
+    def __init__(self, model, process_group=None, average=True, force=False, transport=None, coalesce=1):
         self.model = model
         self.force = force            # run the collectives even in a one-rank group (single-GPU rehearsal of the N>1 path)
         self.pg = process_group
@@ -184,7 +220,7 @@ class HipDDP:
         self.comm_stream = torch.cuda.Stream(device=model.flat_grad.device) if self.on_gpu else None
         if transport is None:
             transport = default_transport()
-            if force and self.on_gpu and not dist.is_initialized() and "YAT_COMM" not in os.environ:
+            if force and self.on_gpu and not dist.is_initialized() and forced_transport() is None:
                 transport = "native"      # a forced one-rank rehearsal without any process group: only the library can run it
         if transport not in ("torch", "native"):
             raise ValueError(f"transport {transport!r}: torch | native")
@@ -215,9 +251,9 @@ class HipDDP:
         self.timed_buckets = []          # (bucket index, bytes, start event, end event) per collective
         self.timed_waits = []            # (before, after) events of the compute stream's wait in ``wait()``
         self.buckets_reduced = 0
-        # YAT_DDP_COALESCE=k: k consecutive buckets (they complete in reverse order and are adjacent in the flat gradient
-        # buffer) go out as one collective -- fewer, larger messages; 1 = one per transformer block
-        self.coalesce = max(1, int(os.environ.get("YAT_DDP_COALESCE", "1")))
+        # coalesce = k: k consecutive buckets (they complete in reverse order and are adjacent in the flat gradient buffer)
+        # go out as one collective -- fewer, larger messages; 1 = one per transformer block (bench.py --coalesce)
+        self.coalesce = max(1, int(coalesce))
         self._pending = None
         model.grad_ready = self.bucket_ready
         # The logged loss (``accelerator.gather(avg_loss).mean()``, common/trainer.py:359) without a collective of its own:

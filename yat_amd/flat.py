@@ -23,15 +23,20 @@ class _Node(nn.Module):
     """Anonymous container so parameter names can carry the diffusers dotted paths."""
 
 
+def schedule(chains):
+    """(weight gradients on a side stream?, forward chains) of a model's step.  ``YAT_SERIAL=1`` is the one diagnostic switch
+    left of the per-model stream switches of rounds 1-4: every launch of the step on ONE stream, in program order -- the
+    form whose per-kernel durations the roofline figures are taken from (bench.py's serialized pass, scripts/gpu_round.sh
+    profserial)."""
+    serial = os.environ.get("YAT_SERIAL", "0") != "0"
+    return (not serial), (1 if serial else int(chains))
+
+
 def isolate_streams():
     """Should the step's compute streams live on the high-priority level?  Only when a process group exists (data-parallel
     job, or the forced one-rank rehearsal): that is when the streams of the process group and of the copy engine crowd the
     normal level's hardware queues.  Alone, the step's four streams get a hardware queue each at the normal level anyway,
-    and the trainer fed from shards was measured SLOWER with high-priority streams (84 -> 107 ms).
-    ``YAT_STREAM_PRIORITY`` = 0 | -1 overrides."""
-    env = os.environ.get("YAT_STREAM_PRIORITY")
-    if env is not None:
-        return int(env) != 0
+    and the trainer fed from shards was measured SLOWER with high-priority streams (84 -> 107 ms)."""
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
 

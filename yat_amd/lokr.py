@@ -66,7 +66,7 @@ class LoKrAdapters:
     def __init__(self, model, targets, r: int, alpha: float, module_dropout: float = 0.0, mode: str | None = None):
         self.model, self.r, self.alpha, self.scale = model, int(r), float(alpha), float(alpha) / int(r)
         self.targets, self.module_dropout = list(targets), float(module_dropout)
-        self.mode = mode or os.environ.get("YAT_LOKR_MODE", "factored")
+        self.mode = mode or "factored"
         if self.mode not in ("factored", "dense"):
             raise ValueError(f"LoKr mode {self.mode!r}")
         self.R = (self.r + 7) // 8 * 8                      # rank padded to 16-byte rows (zero columns / rows)

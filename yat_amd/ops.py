@@ -202,19 +202,16 @@ def linear_dgrad_act(dy2d, w, z, act, out=None):
     return gemm(dy2d, w, out, b_t=True, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, activation=act, dact_z=z)
 
 
-FUSE_BIAS_GRAD = os.environ.get("YAT_FUSE_BIAS_GRAD", "1") != "0"
-
-
 def wgrad_fuses_bias(N, K):
     """Does ``linear_wgrad`` take the bias gradient out of the weight-gradient GEMM itself ([N, K] weight)?  Only where the
     shape policy would not split K anyway (>= 96 tiles of 256 x 256); otherwise it is a separate column-sum pass."""
-    return FUSE_BIAS_GRAD and ((N + 255) // 256) * ((K + 255) // 256) >= 96
+    return ((N + 255) // 256) * ((K + 255) // 256) >= 96
 
 
 def linear_wgrad(dy2d, x2d, out, accumulate=False, bias_grad=None, colsum_ws=None):
     """dW = dy^T x : dy [M,N], x [M,K] -> out [N,K] (optionally += for gradient accumulation).  ``bias_grad`` [N]: the bias
-    gradient (column sums of dy) from the same launch (yat_gemm_epilogue.a_rowsum_out) -- or, with YAT_FUSE_BIAS_GRAD=0 and a
-    ``colsum_ws``, from the separate yat_colsum_bf16 pass it replaces."""
+    gradient (column sums of dy) from the same launch (yat_gemm_epilogue.a_rowsum_out) -- or, for the shapes whose K is split
+    (``wgrad_fuses_bias``), from the separate yat_colsum_bf16 pass (``colsum_ws``: its workspace)."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     # fused only where the shape policy would not split K anyway (>= 96 tiles of 256 x 256: csrc/gemm.hip est_time_256) -- the
@@ -241,7 +238,7 @@ def wgrad_grouped(items, accumulate=False):
     flops = 0.0
     for i, item in enumerate(items):
         dy, x, out = item[:3]
-        bias_grad = item[3] if len(item) > 3 and FUSE_BIAS_GRAD else None      # optional 4th member: the bias gradient [N]
+        bias_grad = item[3] if len(item) > 3 else None      # optional 4th member: the bias gradient [N]
         _chk_bf16(dy, x, out, bias_grad)
         M, N = dy.shape
         K = x.shape[1]

@@ -38,8 +38,9 @@ class FlatAdamW:
         # event per bucket; the next forward waits per bucket, so this HBM-bound pass hides under the forward GEMMs.
         # Anything else that reads parameters first calls model.join_pending_update().
         self.overlap_update = overlap_update and dev.type == "cuda"
-        # overlapped update: workgroups of the 48-VGPR background kernel (0 = the full-width kernel); see yat_adamw_step
-        self.background_blocks = int(os.environ.get("YAT_ADAMW_BG", "0"))
+        # (yat_adamw_step's 48-VGPR background form -- a few persistent workgroups under the forward instead of the
+        # full-width kernel -- was measured and rejected in round 3; the update always uses the full-width kernel)
+        self.background_blocks = 0
         self._stream = None
 
     def _ema_decay_now(self):

@@ -28,7 +28,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
-from .flat import FlatParamModule
+from .flat import FlatParamModule, schedule
 
 BF16 = torch.bfloat16
 
@@ -141,21 +141,19 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         specs = _param_specs(cfg)
         offs, total = self._alloc_flat(specs, device)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers)
-        self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"     # weight gradients / text branch on a 2nd stream
-        # GELU' in the ff.net.2 dgrad epilogue (yat_gemm_epilogue.dact_z): 92 us less kernel time per block when run alone
-        # (540 vs 448 + 184 us), but measured SLOWER in the step (same box, both orders: 267.3 vs 261.2, 292.6 vs 262.8 ms):
-        # the separate HBM-bound pass overlaps the second stream's MFMA-bound weight gradients for free, a longer epilogue
-        # in a one-workgroup-per-CU GEMM does not.  Off by default.
-        self.fuse_act_bwd = os.environ.get("YAT_FUSE_ACT_BWD", "0") != "0"
-        self.split_parts = os.environ.get("YAT_PIXART_SPLIT", "1") != "0"    # LN statistics / cross dK,dV off the chain
+        # weight gradients / text branch on a 2nd stream; independent forward chains over image ranges: 241.9 -> 237.9 ms per
+        # step with two (same box).  (GELU' in the ff.net.2 dgrad epilogue -- yat_gemm_epilogue.dact_z, 92 us less kernel
+        # time per block alone -- was measured SLOWER in the step, 267.3 vs 261.2 ms: the separate HBM-bound pass overlaps
+        # the second stream's weight gradients for free, a longer epilogue in a one-workgroup-per-CU GEMM does not.  The
+        # branch is gone; the epilogue stays a library feature with its own kernel tests.)
+        self.side_wgrad, self.fwd_chains = schedule(2)
+        self.split_parts = True           # LN statistics / cross dK,dV off the dependent chain
         # Bias gradients that are their own column-sum pass (weight gradients of < 96 tiles are split along K, and the fused
         # row-sum form needs the whole K in one workgroup) leave the weight-gradient stream: a 14 us column sum queued there
         # waits for CUs that the GEMM workgroups of both streams hold for their whole life -- the kernel trace shows it
         # "running" for a median 216 - 270 us, and the next weight gradient queued behind it.  On the forward's second chain
         # stream (idle during the backward) it trickles in beside them instead.
-        self.aux_colsum = os.environ.get("YAT_AUX_COLSUM", "1") != "0"
-        self.fwd_chains = int(os.environ.get("YAT_PIXART_CHAINS", "2"))      # independent forward chains (image ranges):
-        #                                                                      241.9 -> 237.9 ms per step with two (same box)
+        self.aux_colsum = True
         self.pos_bf16_base = True         # the base-grid table is a module buffer: ``.to(bfloat16)`` rounds it (:52)
         self._pos = {}
 
@@ -195,7 +193,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
 
     # ------------------------------------------------------------------ device path (launch plans, yat_amd/flat.py)
     def _schedule_flags(self):
-        return (self.side_wgrad, self.fuse_act_bwd, self.split_parts, self.fwd_chains, self.aux_colsum, self.training)
+        return (self.side_wgrad, self.split_parts, self.fwd_chains, self.aux_colsum, self.training)
 
     def forward_device(self, latents, enc, timestep, key_bias, kv_len, kv_work=None):
         """``forward_impl`` on device-resident inputs in persistent buffers, replayed from a launch plan when this (shapes,
@@ -488,11 +486,8 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate,
                          dbias=G[pre + "ff.net.2.bias"], accumulate_bias=acc)
             wgrad(dlin3, A.f1, G[pre + "ff.net.2.weight"])
-            if self.fuse_act_bwd and ad is None:   # see __init__: measured slower in the step, kept as a switch
-                dz = ops.linear_dgrad_act(dlin3, P[pre + "ff.net.2.weight"], A.z, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
-            else:
-                df1 = dgrad(dlin3, P[pre + "ff.net.2.weight"], out=buf("df1", (M, 4 * D)))
-                dz = ops.act_bwd(A.z, df1, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
+            df1 = dgrad(dlin3, P[pre + "ff.net.2.weight"], out=buf("df1", (M, 4 * D)))
+            dz = ops.act_bwd(A.z, df1, "gelu_tanh", buf(f"dz.{par}", (M, 4 * D)))
             wgrad(dz, A.h2, G[pre + "ff.net.0.proj.weight"], G[pre + "ff.net.0.proj.bias"])
             # this step is bound by the dependent chain (serialized kernel time 264 ms vs 247 ms per step), so what only
             # parameters or the text side need leaves it: LayerNorm column statistics and the cross-attention dK/dV go to the

@@ -37,7 +37,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .flat import FlatParamModule
+from .flat import FlatParamModule, schedule
 
 BF16 = torch.bfloat16
 
@@ -144,13 +144,12 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         offs, total = self._alloc_flat(specs, device)
         # bucket boundaries for data parallel reduction: head | one per block (+tail on the last)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers)
-        self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"   # weight gradients on a second stream
-        self.keep_glu_u = os.environ.get("YAT_KEEP_GLU_U", "1") != "0"         # keep the depthwise-conv output (183 MB/block)
-        self.fwd_chains = int(os.environ.get("YAT_FWD_CHAINS", "2"))           # independent forward chains (image ranges)
-        self.group_big_wgrad = os.environ.get("YAT_GROUP_BIG_WGRAD", "0") != "0"
-        self.group_small_wgrad = os.environ.get("YAT_GROUP_SMALL_WGRAD", "1") != "0"   # D x D weight gradients grouped
-        self.defer_wgrad = os.environ.get("YAT_DEFER_WGRAD", "0") != "0"       # weight gradients at the block's end ...
-        self.grouped_wgrad = os.environ.get("YAT_GROUPED_WGRAD", "0") != "0"   # ... as one grouped GEMM launch
+        # weight gradients on a second stream; independent forward chains over image ranges (flat.schedule: YAT_SERIAL=1
+        # puts the whole step on one stream).  Variants measured and rejected in rounds 2-4 -- weight gradients deferred to
+        # the block's end / as one grouped launch per block, the three big ones grouped -- are gone (profiles/LOG_r01_r03.md)
+        self.side_wgrad, self.fwd_chains = schedule(2)
+        self.keep_glu_u = True                # keep the depthwise-conv output (183 MB/block) for the backward
+        self.group_small_wgrad = True         # the three D x D weight gradients of a block as one grouped launch
 
     def init_synthetic(self, seed: int = 0):
         """Deterministic random weights of the right scale (no checkpoints offline): weights ~ N(0, 1/fan_in),
@@ -180,8 +179,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
     # ------------------------------------------------------------------ device path (launch plans, yat_amd/flat.py)
     def _schedule_flags(self):
-        return (self.side_wgrad, self.keep_glu_u, self.fwd_chains, self.group_big_wgrad, self.group_small_wgrad,
-                self.defer_wgrad, self.grouped_wgrad, self.training)
+        return (self.side_wgrad, self.keep_glu_u, self.fwd_chains, self.group_small_wgrad, self.training)
 
     packed_text = True         # forward_device / forward_impl accept the text rows without padding (``kv_off``)
 
@@ -576,25 +574,17 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
             small = []                                        # the three D x D weight gradients: one grouped launch
 
-            big = []                                          # experiment: conv_inverted + conv_point + kv in one launch
-
             def emit(dy_, x_, gw_, bias=None, group=False, text=False):
                 """``text``: the reduction runs over the (packed) text rows -- never grouped, its K is the plan's dynamic
                 row count"""
                 if ad is not None:        # frozen base: adapter gradients only, launched by the dgrad() of the same dy
                     pending_ad.append((dy_, x_, gw_))
                     return
-                if self.defer_wgrad:
-                    deferred.append((dy_, x_, gw_, bias, text))
-                    return
-                if group is True and self.group_small_wgrad:      # (also without a side stream: one launch instead of three
+                if group and self.group_small_wgrad:      # (also without a side stream: one launch instead of three
                     small.append((dy_, x_, gw_, bias))            #  split-K ones -- the serialized pass runs the step's kernels)
                     return
                 if side is None:
                     deferred.append((dy_, x_, gw_, bias, text))
-                    return
-                if group == "big" and self.group_big_wgrad and not text:
-                    big.append((dy_, x_, gw_, bias))
                     return
 
                 def run():
@@ -605,7 +595,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             # x3 = x2 + gate_mlp * lin3
             dlin3 = buf(f"dlin3.{par}", (M, D))
             ops.gate_bwd(dx, A.lin3, mod2d[:, 5 * D:6 * D], 6 * D, N, dlin3, dmod2d[:, 5 * D:6 * D], 6 * D, ws_gate)
-            emit(dlin3, A.y, G[pre + "ff.conv_point.weight"].view(D, Hc), group="big")
+            emit(dlin3, A.y, G[pre + "ff.conv_point.weight"].view(D, Hc))
             dz = buf(f"dz.{par}", (M, 2 * Hc))
             if A.u is not None:
                 # the GLU backward runs in the epilogue of the GEMM that produces dy (dy itself never reaches memory);
@@ -618,7 +608,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                                P[pre + "ff.conv_depth.bias"], dy, dz, G[pre + "ff.conv_depth.weight"].view(2 * Hc, 9),
                                G[pre + "ff.conv_depth.bias"], ws_dw, accumulate=acc,
                                dz_colsum=G[pre + "ff.conv_inverted.bias"], du=du_)        # bias gradient in the same pass
-            emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), group="big")
+            emit(dz, A.h2, G[pre + "ff.conv_inverted.weight"].view(2 * Hc, D))
             dh2_ = dgrad(dz, P[pre + "ff.conv_inverted.weight"].view(2 * Hc, D), out=buf(f"dh2.{par}", (M, D)))
             other = dxb if dx is dxa else dxa
             # LayerNorm backward: dx on the chain; the shift/scale gradients (column statistics) feed only the
@@ -656,15 +646,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
             dx1 = dgrad(dq2, P[pre + "attn2.to_q.weight"], out=other, residual=dx2)    # dx1 = dx2 + dq2 Wq
             wkv, gkv = self._fused(pre + "attn2.to_k.weight", 2 * D, D)
             _, gbkv = self._fused(pre + "attn2.to_k.bias", 2 * D)
-            emit(dkv2, S.encn, gkv, gbkv, group="big", text=packed)
-            if big:
-                def big_grads(big=big):
-                    ops.wgrad_grouped(sorted([(a, b_, c) for a, b_, c, _ in big], key=lambda it: -it[0].shape[0]),
-                                      accumulate=acc)
-                    for a, _, _, bias_ in big:
-                        if bias_ is not None:
-                            ops.colsum(a, bias_, ws_col, accumulate=acc)
-                off_chain(big_grads)
+            emit(dkv2, S.encn, gkv, gbkv, text=packed)
             # x1 = x + gate_msa * lin1
             dlin1 = buf(f"dlin1.{par}", (M, D))
             ops.gate_bwd(dx1, A.lin1, mod2d[:, 2 * D:3 * D], 6 * D, N, dlin1, dmod2d[:, 2 * D:3 * D], 6 * D, ws_gate,
@@ -674,13 +656,8 @@ class SanaTransformer2DModelHIP(FlatParamModule):
                 # 2240 x 2240 x 8192 each: 81 tiles of 256 x 256 -- alone they need split-K (fp32 slabs + a reduce launch);
                 # together 243 full-K tiles fill the 256 CUs in one round
                 def small_grads(small=small):
-                    fuse = ops.FUSE_BIAS_GRAD
-                    ops.wgrad_grouped([(a, b, c, bias_) if (fuse and bias_ is not None) else (a, b, c)
+                    ops.wgrad_grouped([(a, b, c, bias_) if bias_ is not None else (a, b, c)
                                        for a, b, c, bias_ in small], accumulate=acc)          # bias gradients: same launch
-                    if not fuse:
-                        for a, _, _, bias_ in small:
-                            if bias_ is not None:
-                                ops.colsum(a, bias_, ws_col, accumulate=acc)
                 off_chain(small_grads)
             dattn = dgrad(dlin1, P[pre + "attn1.to_out.0.weight"], out=buf("dh", (M, D)))
             dqkv = buf(f"dqkv.{par}", (M, 3 * D))
@@ -705,15 +682,10 @@ class SanaTransformer2DModelHIP(FlatParamModule):
 
             def block_grads(deferred=deferred, dx2=dx2, dq2=dq2, dkv2=dkv2, wkv=wkv, gbkv=gbkv, pre=pre,
                             first=(i == cfg.num_layers - 1)):
-                if deferred:
-                    grouped = [it for it in deferred if not it[4]] if self.grouped_wgrad else []
-                    if grouped:
-                        # largest K first: the short tiles (text side, K = B*T) fill the tail
-                        ops.wgrad_grouped(sorted([it[:3] for it in grouped], key=lambda it: -it[0].shape[0]), accumulate=acc)
+                if deferred:                                      # (one-stream schedule: the weight gradients at the block's end)
                     for dy_, x_, gw_, _, text_ in deferred:
-                        if not self.grouped_wgrad or text_:
-                            with (text_scope() if text_ else contextlib.nullcontext()):
-                                ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
+                        with (text_scope() if text_ else contextlib.nullcontext()):
+                            ops.linear_wgrad(dy_, x_, gw_, accumulate=acc)
                     for dy_, _, _, bias_, text_ in deferred:      # attn2.to_out / to_q (unless grouped above) / to_k|to_v
                         if bias_ is not None:
                             with (text_scope() if text_ else contextlib.nullcontext()):

@@ -31,7 +31,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
-from .flat import FlatParamModule
+from .flat import FlatParamModule, schedule
 
 BF16 = torch.bfloat16
 
@@ -155,12 +155,12 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         specs = _param_specs(cfg)
         offs, total = self._alloc_flat(specs, device)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers, first_key="norm1.linear.weight")
-        self.side_wgrad = os.environ.get("YAT_SIDE_WGRAD", "1") != "0"     # weight gradients / modulation linears on a 2nd stream
+        # weight gradients / modulation linears on a 2nd stream (flat.schedule)
         # (a third stream for the text tokens' own chain was measured in round 2 -- 405.0 vs 399.7 ms per step, no gain -- and
         # is gone).  Forward as independent chains over image ranges, as in yat_amd/sana.py: two chains won in round 3 (350.5 ->
         # 343.9 ms); on the round-4 GEMM schedule ONE chain does -- 347.8 / 348.5 ms against 351.7 / 352.7 (two) and 349.1 /
         # 351.7 (three), same box, two rounds (profiles/r04_i_*): M = 35 k rows per launch already fill the chip
-        self.fwd_chains = int(os.environ.get("YAT_SD3_CHAINS", "1"))
+        self.side_wgrad, self.fwd_chains = schedule(1)
         self._pos = {}
 
     def init_synthetic(self, seed: int = 0):
