@@ -192,8 +192,32 @@ def test_forced_ddp_native_transport_is_bit_identical():
     assert lib.yat_comm_wait(7, s) == 0
     torch.cuda.synchronize()
     assert torch.equal(x, torch.ones_like(x))
+    # every other bulk collective rides the same communicator (round-4 review: the EMA mean before validation,
+    # common/trainer.py:374-377, went through the gloo rendezvous group): yat_comm_allreduce, fp32 and bf16, mean and sum --
+    # over one rank both are the identity -- and HipDDP.allreduce_bulk picks it whenever the native transport is in use
+    from yat_amd.ddp import HipDDP
+    ema = torch.randn(1 << 20, device=DEV)
+    ema_ref = ema.clone()
+    assert lib.yat_comm_allreduce(ema.data_ptr(), ema.numel(), 1, 0, s) == 0
+    h = torch.randn(4096, device=DEV).to(BF)
+    h_ref = h.clone()
+    NativeComm.get().allreduce(h, mean=False)
+    _, trained, _ = _case("sana")
+    ddp = HipDDP(trained, force=True, transport="native")
+    assert ddp.native is NativeComm.get()
+    shadow = trained.flat_param.float()
+    shadow_ref = shadow.clone()
+    assert ddp.allreduce_bulk(shadow, mean=True) is shadow
+    torch.cuda.synchronize()
+    assert torch.equal(ema, ema_ref) and torch.equal(h, h_ref) and torch.equal(shadow, shadow_ref)
+    assert lib.yat_comm_allreduce(ema.data_ptr(), 0, 1, 0, s) == -1                # empty
+    assert lib.yat_comm_allreduce(ema.data_ptr(), 8, 2, 0, s) == -1                # unknown dtype
+    assert lib.yat_comm_allreduce(ema.data_ptr(), 8, 1, 2, s) == -1                # unknown reduction
+    with pytest.raises(ValueError):
+        NativeComm.get().allreduce(torch.ones(8, dtype=torch.float16, device=DEV))
     NativeComm.get().destroy()
     assert lib.yat_comm_world() == 0
+    assert lib.yat_comm_allreduce(ema.data_ptr(), 8, 1, 0, s) == -2                # YAT_ENOCOMM after destroy
 
 
 def test_native_transport_failure_falls_back_to_the_process_group(one_rank_group, monkeypatch):

@@ -51,6 +51,13 @@ def rescale_adapter_scale(adapters, multiplier):
         gate = getattr(adapters, "_gate", None)
         if gate is not None:
             gate.fill_(v)
+        # a recorded launch plan holds the scalar arguments of its launches (ops.Recorder stores [fn, args]): none may
+        # outlive a change of the scale.  (Today no plan is recorded while adapters are attached -- FlatParamModule.planned
+        # -- so this is a guard for the day one is, round-4 advisor.)
+        for owner in (adapters, getattr(adapters, "model", None)):
+            plans = getattr(owner, "_plans", None)
+            if plans:
+                plans.clear()
     put(original * multiplier)
     try:
         yield

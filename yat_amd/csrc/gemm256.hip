@@ -241,29 +241,11 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // loop-invariant registers of make_piece.  The scalar offset is not part of the buffer range check, so the two cases that
     // lean on per-lane checks -- the ragged last k-tile (row-mode chunks past K, k-strided rows past K) -- take the CHECKED
     // form (per-lane add + compare) instead; which form a segment uses is one uniform branch per segment, not per piece.
-    // K rotation (round 5).  Workgroups that share an operand panel run their K loops in lockstep, so every one of them sits
-    // behind the same HBM miss at the same time: with operands from HBM the forward GEMMs lose 11 .. 20 % and the prefetch
-    // window of the LDS ring (1.2 .. 1.5 us) cannot be made longer (scripts/gemm_sustained_probe.py PROBE_AB=1: cold A and
-    // cold B cost about the same, and add up).  The sharers of a B panel inside one XCD are the GROUP row tiles of a row
-    // group (tile order below); row tile tm therefore starts its loop (tm % KROT) / KROT of the way into K and wraps around:
-    // each sharer is the first to touch a B line -- and waits for HBM -- for 1 / KROT of its loop only; for the rest it runs
-    // over lines a neighbour fetched 1 / KROT of a loop earlier (L2 or Infinity Cache).  B is the operand that is cold in
-    // the step: weights in the forward and input-gradient GEMMs, saved activations in the weight-gradient ones.  A ragged
-    // last K-tile keeps its place at the end (the FAST loop form counts on it).  The fp32 accumulation order of a tile
-    // changes with its row tile, deterministically; -DYAT_GEMM_KROT=1 is the unrotated loop.
-#ifndef YAT_GEMM_KROT
-#define YAT_GEMM_KROT 4
-#endif
-#ifndef YAT_GEMM_KROT_DIM
-#define YAT_GEMM_KROT_DIM 0          // 0: by row tile (spreads the sharers of a B panel); 1: by column tile (A panel); 2: by tm + tn
-#endif
-    const int nrot = nt - ((ragged && kt0 + nt == nt_all) ? 1 : 0);               // full K-tiles of this slice
-    const int kcls = (YAT_GEMM_KROT_DIM == 0 ? tm : YAT_GEMM_KROT_DIM == 1 ? tn : tm + tn) % YAT_GEMM_KROT;
-    const int krot = (YAT_GEMM_KROT > 1 && nrot > 1) ? (int)(((int64_t)kcls * nrot) / YAT_GEMM_KROT) : 0;
-    auto ktile = [&](int tl) {                                                   // iteration tl of this slice -> global K-tile
-        const int r = tl + krot;
-        return kt0 + (tl < nrot ? (r >= nrot ? r - nrot : r) : tl);
-    };
+    // (K rotation -- workgroups that share a B panel starting their loops at different depths, so that only one of them at
+    // a time waits for a line's HBM miss -- was built and measured in round 5: the cold / hot gap of the forward GEMMs fell
+    // from 9 .. 19 % to 3 .. 13 %, but giving up the lockstep L2 sharing cost more than that: hot + 10 %, step 76.5 -> 80.4 ms.
+    // profiles/r05_b_gemm_k_rotation_rejected_*.)
+    auto ktile = [&](int tl) { return kt0 + tl; };                              // iteration tl of this slice -> global K-tile
     auto is_tail = [&](int tl) { return ragged && ktile(tl) == nt_all - 1; };
     auto piece = [&](auto checked, int tl, char* stage, int j) {
         constexpr bool CHECKED = decltype(checked)::value;
@@ -914,6 +896,12 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     }
 }
 
+// One tile per workgroup.  Measured in round 5 and not kept (profiles/r05_d_*): a PERSISTENT form (256 workgroups walking the
+// tile list, same tile -> XCD assignment, bit-identical) is 1.7 .. 2.3 % faster alone on launches of five and more rounds,
+// 4.6 % slower on two-round ones and 0.5 % slower in the step, where its grid holds every CU against the other stream; the
+// K sweep it came with puts the fixed cost of a tile round at 6.6 us against 1.75 us per K-tile -- the time is in the loop,
+// not between tiles.  Delaying the first round's workgroups so that the epilogues leave lockstep changes nothing (the
+// epilogue is not HBM-bound: cold outputs cost nothing).
 template <bool A_T, bool B_T, int NT, int EPI = 0>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmP p) {
     gemm256_body<A_T, B_T, NT, EPI>(p, xcd_contiguous(p.nbm * p.nbn * p.ksplit));

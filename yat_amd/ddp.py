@@ -442,11 +442,6 @@ class HipDDP:
             self._loss_offset = torch.where(torch.isfinite(v), v, prev).detach().clone()
         self._tail.zero_()
 
-    def reset_loss_offset(self):
-        """Forget the previous step's mean (checkpoint resume, a diagnostic pass that did not reduce): the next carried loss
-        travels as the plain value again.  Must be called on every rank at the same step."""
-        self._loss_offset = None
-
     def all_reduce_scalar_mean(self, t):
         """accelerator.gather(avg_loss).mean() (trainer.py:359) as one tiny all-reduce."""
         if self.world > 1:
