@@ -51,8 +51,9 @@ for lay, m, n, k in SHAPES:
     a_t, b_t = lay[0] == "t", lay[1] == "t"
     per_set = 2 * (m * k + k * n + m * n)
     R = max(3, -(-1400_000_000 // per_set))
-    ins = [((torch.randn((k, m) if a_t else (m, k), device=dev) * 0.5).to(BF),
-            (torch.randn((k, n) if b_t else (n, k), device=dev) * 0.05).to(BF)) for _ in range(R)]
+    zero = float(os.environ.get("PROBE_ZERO", "0"))          # 1: all-zero operands (same instructions, no toggling: the power test)
+    ins = [((torch.randn((k, m) if a_t else (m, k), device=dev) * (0.0 if zero else 0.5)).to(BF),
+            (torch.randn((k, n) if b_t else (n, k), device=dev) * (0.0 if zero else 0.05)).to(BF)) for _ in range(R)]
     outs = [torch.empty(m, n, dtype=BF, device=dev) for _ in range(R)]
     fl = 2.0 * m * n * k
     est = fl / 1.0e9          # us at 1000 TF/s

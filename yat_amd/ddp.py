@@ -342,6 +342,8 @@ class HipDDP:
         self.bytes_reduced += chunk.numel() * chunk.element_size()
         self.buckets_reduced += 1
         rccl = self.on_gpu and (self.native is not None or dist.get_backend(self.pg) == "nccl")
+        if self.dryrun and rccl and not self.timing and self.native is None:
+            return                  # torch transport, collective off: its live form below touches no stream of ours either
         if self.on_gpu and (self.timing or (self.dryrun and rccl)):
             # diagnostic form, both transports: the producer's event and the communication stream's wait for it are issued
             # here, so that the start event sits between that wait and the collective (inside the library / process group
@@ -374,17 +376,22 @@ class HipDDP:
             self.native.allreduce_async(chunk, i, torch.cuda.current_stream(), self.comm_stream)
             return
         op = dist.ReduceOp.AVG if (self.average and rccl) else dist.ReduceOp.SUM
-        if self.on_gpu:
+        if rccl:
+            # torch's RCCL group runs every collective on a stream of its own and makes THAT stream wait for the stream the
+            # call is issued from -- here the one that has just finished the bucket -- so no stream of ours sits in between.
+            # (Through round 4 the call went out under ``comm_stream`` behind an event: one more stream for the runtime to
+            # fold onto its few hardware queues, and the forced one-rank step ran 86.3 ms against 79.7 ms through the
+            # library's communicator, which has exactly this shape; profiles/r05_c_ddp_forced_one_rank_*.)
+            self._works.append(dist.all_reduce(chunk, op=op, group=self.pg, async_op=True))
+        elif self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if rccl:
-                    self._works.append(dist.all_reduce(chunk, op=op, group=self.pg, async_op=True))
-                else:       # one-GPU rehearsal over gloo (device tensors staged through the host): sum, then the mean
-                    dist.all_reduce(chunk, op=op, group=self.pg)
-                    if self.average:
-                        chunk.div_(self.world)
+                # one-GPU rehearsal over gloo (device tensors staged through the host): sum, then the mean
+                dist.all_reduce(chunk, op=op, group=self.pg)
+                if self.average:
+                    chunk.div_(self.world)
         else:  # gloo path used by the CPU multi-process tests
             w = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
             self._works.append((w, chunk))
@@ -410,7 +417,8 @@ class HipDDP:
         elif self.on_gpu:
             for w in self._works:
                 w.wait()                         # makes the current stream wait; does not block the host
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if dist.get_backend(self.pg) != "nccl":
+                torch.cuda.current_stream().wait_stream(self.comm_stream)     # (the gloo rehearsal's staging copies)
         else:
             for w, chunk in self._works:
                 w.wait()
