@@ -281,7 +281,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
         if (forced >= 1 && forced <= 8) streams = forced;
     }
     if (variant >= 100) { ksplit = variant / 100; variant %= 100; }
-    if (variant != 0 && variant != 1 && variant != 4 && variant != 5 && variant != 6) return YAT_EINVAL;
+    if (variant != 0 && variant != 1 && variant != 4 && variant != 5) return YAT_EINVAL;
     if (ksplit < 1 || ksplit > 32) return YAT_EINVAL;
     GemmP p;
     {
@@ -331,8 +331,7 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
                 }
         }
     }
-    if (variant == 6 && !wide_ok) return YAT_EINVAL;      // the one-wave kernel has no 8-B epilogue fallback
-    if (variant == 4 || variant == 5 || variant == 6) {
+    if (variant == 4 || variant == 5) {
         if (ksplit > 1 && (!workspace || !wide_ok || (uint64_t)ksplit * M * N * 4 > workspace_bytes)) return YAT_EINVAL;
         p.ksplit = ksplit;
         p.partial = (float*)workspace;

@@ -22,7 +22,8 @@
 // before its 4th barrier of iteration t; group 1 issues tile t+2 in COMPUTE(t,ks1) and waits for tile
 // t+1 before its 3rd barrier of iteration t -- both waits precede rendezvous 4t+4.
 //
-// DEEP schedule (round 4; layouts with a k-strided B operand: the input- and weight-gradient GEMMs).  The two-stage ring above
+// DEEP schedule (round 4: layouts with a k-strided B operand, the input- and weight-gradient GEMMs; round 5: every layout -- a
+// k-contiguous B operand gets a half-major LDS image of the same piece shape, see B_KH below).  The two-stage ring above
 // gives a piece 2..4 of the 4 segments of a K-tile to land: enough for the Infinity Cache, short for HBM under load (operands
 // from HBM cost the same launches +10..+25 % at the sustained clock, scripts/gemm_sustained_probe.py).  The LDS images are
 // unchanged, but a k-strided image is refilled per 32-deep HALF (k-rows 0..31 / 32..63 are contiguous: a four-slot ring of
@@ -792,6 +793,10 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
                       !(p.gate && (p.gate_ld & 7)) && !(p.glu_u && (p.ld_glu & 7)) && !(p.pre_add && (p.ld_pre & 7)) &&
                       !(p.dact_z && (p.ld_z & 7));
     const bool split = p.ksplit > 1;           // host guarantees `wide` alignment when splitting
+    // (Round 5 built the 8-column units by a LANE EXCHANGE instead -- v_permlane16_swap of two neighbouring result tiles leaves
+    // every lane with 8 consecutive columns of one row, no LDS slab, no lgkmcnt waits; bit-identical -- and it was 3 .. 10 %
+    // SLOWER per launch (step 76.5 -> 79.7 ms): a store instruction then covers 16 rows x 64 B instead of 6.4 rows x 160 B.
+    // The epilogue is bound by the row segments its stores touch, not by the LDS round trip.  profiles/r05_g_*.)
     if (wide || split) {
         constexpr int WCOLS = 16 * NT;             // columns per wave
         constexpr int LDW = WCOLS + 4;             // padded fp32 row (conflict-free ds_write_b128)
@@ -954,242 +959,8 @@ int launch256_grouped(int ngroups, const GemmP* probs, hipStream_t stream) {
     return e == hipSuccess ? YAT_OK : (int)e;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// gemm1w: the same 256 x 256 x 64 tile with ONE wave per SIMD (4 waves, 2 x 2, each 128 x 128 = 256 accumulator registers
-// out of the 512 a lone wave may hold) and the K loop software-pipelined inside each wave instead of across two wave groups:
-//   * the fragments of the next 32-deep sub-step are read (second register buffer) between the MFMAs of the current one;
-//   * ONE rendezvous per K-tile (after the reads of its second sub-step retired): it hands tile t's stage to the DMA of tile
-//     t + 2, whose 16 pieces per wave go out between the MFMAs of the second sub-step, a full K-tile ahead of their use;
-//   * per K-tile and CU: 64 KB of fragment reads per sub-step instead of 96 KB (128 x 128 wave tiles), 1 barrier instead of 4.
-// LDS images, swizzles, pieces, epilogue: gemm256's.  Selected as tile variant 6.
-struct Geo1w {
-    static constexpr int BN = 256;
-    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
-    static constexpr int PA = A_BYTES / 1024 / 4, PB = B_BYTES / 1024 / 4;      // pieces per wave per tile: 8 + 8
-};
-
-template <bool A_T, bool B_T, int EPI = 0>
-__device__ __forceinline__ void gemm1w_body(const GemmP p, int id) {
-    using G = Geo1w;
-    constexpr int NT = 8;                                   // 16-column fragments per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wave >> 1, wc = wave & 1;               // rows [128 grp, +128), columns [128 wc, +128)
-
-    const int ksl = id % p.ksplit;
-    id /= p.ksplit;
-    const int GROUP = p.group > 0 ? p.group : YAT_GEMM_GROUP;
-    const int per_group = GROUP * p.nbn;
-    const int gid = id / per_group, first_m = gid * GROUP;
-    const int gsz = min(p.nbm - first_m, GROUP);
-    const int tm = first_m + (id % per_group) % gsz;
-    const int tn = (id % per_group) / gsz;
-    const int m0 = tm * BM, n0 = tn * G::BN;
-
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
-    Piece pa[G::PA], pb[G::PB];
-#pragma unroll
-    for (int j = 0; j < G::PA; ++j) pa[j] = make_piece<A_T, BM>(wave + 4 * j, lane, p.lda, m0, p.M);
-#pragma unroll
-    for (int j = 0; j < G::PB; ++j) pb[j] = make_piece<B_T, G::BN>(wave + 4 * j, lane, p.ldb, n0, p.N);
-    const uint32_t kchunk = piece_kchunk(wave, lane);
-    const uint32_t a_kstep = A_T ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
-    const uint32_t b_kstep = B_T ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
-    const int nt_all = (p.K + BK - 1) / BK;
-    const int kt0 = (int)(((int64_t)nt_all * ksl) / p.ksplit);
-    const int nt = (int)(((int64_t)nt_all * (ksl + 1)) / p.ksplit) - kt0;
-    const bool ragged = (p.K & (BK - 1)) != 0;
-    constexpr int NPIECE = G::PA + G::PB;
-
-    auto is_tail = [&](int tl) { return ragged && kt0 + tl == nt_all - 1; };
-    auto piece = [&](auto checked, int tl, char* stage, int j) {
-        constexpr bool CHECKED = decltype(checked)::value;
-        const int t = kt0 + tl;
-        const bool opa = j < G::PA;
-        const int jj = opa ? j : j - G::PA;
-        YAT_LDS void* dst = (YAT_LDS void*)(stage + (opa ? 0 : G::A_BYTES) + (wave + 4 * jj) * 1024);
-        const Piece& pc = opa ? pa[jj] : pb[jj];
-        const uint32_t kstep = opa ? a_kstep : b_kstep;
-        const bool kstr = opa ? A_T : B_T;
-        if (CHECKED) {
-            const uint32_t kvalid = (uint32_t)(p.K - t * BK) >> 3;
-            uint32_t v = pc.voff + (uint32_t)t * kstep;
-            if (!kstr && kchunk >= kvalid) v = YAT_OOB;
-            lds_dma16(opa ? ra : rb, dst, v);
-        } else {
-            lds_dma16s(opa ? ra : rb, dst, pc.voff, (uint32_t)t * kstep);
-        }
-    };
-    auto issue_all = [&](int tl, char* stage) {
-        if (is_tail(tl)) {
-#pragma unroll
-            for (int j = 0; j < NPIECE; ++j) piece(std::true_type{}, tl, stage, j);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NPIECE; ++j) piece(std::false_type{}, tl, stage, j);
-        }
-    };
-
-    f32x4 acc[8][NT];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[2][8], bfr[2][NT];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(YAT_LDS char*)smem;
-    const uint32_t a_tr = A_T ? tr_lane_addr<BM>(0, lane) + grp * 256 : 0;
-    const uint32_t b_tr = B_T ? tr_lane_addr<G::BN>(0, lane) + wc * 256 + G::A_BYTES : 0;
-
-    // fragment f of sub-step kk of the tile in `stage`: f < 8 operand A (rows), else operand B (columns)
-    auto read_frag = [&](auto buf_c, int f, int stage, int kk) {
-        constexpr int BUF = decltype(buf_c)::value;
-        const uint32_t st = stage * G::STAGE;
-        if (f < 8) {
-            if (A_T) af[BUF][f] = frag_tr<BM>((lds0 + a_tr + st) ^ (uint32_t)(f << 5), kk);
-            else af[BUF][f] = frag256<false, BM>(smem + st, grp * 128 + f * 16, kk, lane);
-        } else {
-            const int j = f - 8;
-            if (B_T) bfr[BUF][j] = frag_tr<G::BN>((lds0 + b_tr + st) ^ (uint32_t)(j << 5), kk);
-            else bfr[BUF][j] = frag256<false, G::BN>(smem + st + G::A_BYTES, wc * 128 + j * 16, kk, lane);
-        }
-    };
-    // 64 MFMAs on buffer BUF; between them (one slot per MFMA): the 16 fragment reads of the next sub-step into the other
-    // buffer (slots 0, 2, 4, ...: `rd_stage` < 0 = none) and the DMA pieces of tile `dma_tile` (every fourth slot from 1;
-    // MODE 0 none, 1 unconditional scalar-offset pieces, 2 decided per piece)
-    auto block = [&](auto buf_c, auto mode_c, int rd_stage, int rd_kk, int dma_tile) {
-        constexpr int BUF = decltype(buf_c)::value;
-        constexpr int MODE = decltype(mode_c)::value;
-        char* dst = smem + (dma_tile & 1) * G::STAGE;
-        const bool checked = MODE == 2 && dma_tile >= 0 && is_tail(dma_tile);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                // accumulators pinned in AGPRs, destination tied to the addend: with 512 registers the compiler's own MFMA
-                // forms either shuffle the 64 accumulators through ~1000 v_accvgpr moves per iteration (AGPR form, untied
-                // destination) or park the fragments in AGPRs (VGPR form)
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[BUF][j]), "v"(af[BUF][i]));
-                const int idx = i * NT + j;
-                __builtin_amdgcn_sched_barrier(0);
-                if ((idx & 1) == 0 && idx / 2 < 16 && rd_stage >= 0)
-                    read_frag(std::integral_constant<int, 1 - BUF>{}, idx / 2, rd_stage, rd_kk);
-                if (MODE != 0 && (idx & 3) == 1 && idx / 4 < NPIECE) {
-                    if (MODE == 1) piece(std::false_type{}, dma_tile, dst, idx / 4);
-                    else if (dma_tile >= 0) {
-                        if (checked) piece(std::true_type{}, dma_tile, dst, idx / 4);
-                        else piece(std::false_type{}, dma_tile, dst, idx / 4);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    // prologue: tiles 0 and 1 in flight, tile 0 visible, its first sub-step's fragments in buffer 0
-    issue_all(0, smem);
-    if (nt > 1) {
-        issue_all(1, smem + G::STAGE);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // all but the 16 youngest: tile 0 landed
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    YAT_PHASE_BARRIER();
-#pragma unroll
-    for (int f = 0; f < 16; ++f) read_frag(std::integral_constant<int, 0>{}, f, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                       // (builtin, not asm: the compiler's wait-count scoreboard sees it)
-
-    auto iteration = [&](auto fast_c, int t) {
-        constexpr bool FAST = decltype(fast_c)::value;
-        const int st = t & 1;
-        // sub-step 0 on buffer 0; the second sub-step's fragments arrive in buffer 1 meanwhile
-        block(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, st, 1, -1);
-        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): every read of tile t retired ...
-        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): ... and this wave's pieces of tile t + 1 landed
-        YAT_PHASE_BARRIER();                                    // rendezvous t: stage st is free, tile t + 1 is visible
-        // sub-step 1 on buffer 1; tile t + 1's first fragments into buffer 0, tile t + 2's pieces into stage st
-        if (FAST) block(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, 1 - st, 0, t + 2);
-        else block(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, t + 1 < nt ? 1 - st : -1, 0,
-                   t + 2 < nt ? t + 2 : -1);
-        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
-    };
-    {
-        const int nfast = max(0, nt - 2 - (ragged && kt0 + nt == nt_all ? 1 : 0));
-        int t = 0;
-        for (; t < nfast; ++t) iteration(std::true_type{}, t);
-        for (; t < nt; ++t) iteration(std::false_type{}, t);
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results before anything reads the AGPRs
-    YAT_PHASE_BARRIER();                                        // the stages become the epilogue's slabs
-
-    // epilogue through the per-wave LDS slabs (16-B global accesses).  The host only selects this kernel when every epilogue
-    // operand is 16-B aligned (`wide`), so the 8-B fallback of gemm256 -- and the registers it costs -- is not compiled in.
-    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
-    const bool split = p.ksplit > 1;
-    {
-        constexpr int WCOLS = 16 * NT, LDW = WCOLS + 4, CPR = WCOLS / 8;
-        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * LDW);
-        const int g4 = lane >> 4, li = lane & 15;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    *reinterpret_cast<f32x4*>(slab + (ii * 16 + li) * LDW + j * 16 + 4 * g4) = acc[pass * 2 + ii][j];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < (32 * CPR + 63) / 64; ++k) {
-                const int u = lane + 64 * k;
-                if (u < 32 * CPR) {
-                    const int row = u / CPR, ch = u % CPR;
-                    const int m = m0 + grp * 128 + pass * 32 + row;
-                    const int n = n0 + wc * WCOLS + ch * 8;
-                    if (m < p.M && n < p.N) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * LDW + ch * 8 + 4);
-                        if (split) {
-                            float* dst = p.partial + ((int64_t)ksl * p.M + m) * p.N + n;
-                            *reinterpret_cast<f32x4*>(dst) = lo;
-                            *reinterpret_cast<f32x4*>(dst + 4) = hi;
-                        } else {
-                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            if (EPI == 1) glu_bwd_store<8>(p, v, m, n);
-                            else if (EPI == 3) act_bwd_store<8>(p, v, m, n);
-                            else gemm_epilogue_store8<EPI == 2>(p, v, m, n, m / rpb);
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    }
-}
-
-template <bool A_T, bool B_T, int EPI = 0>
-__global__ __launch_bounds__(256, 1) void gemm1w_kernel(GemmP p) {
-    gemm1w_body<A_T, B_T, EPI>(p, xcd_contiguous(p.nbm * p.nbn * p.ksplit));
-}
-
-template <bool A_T, bool B_T, int EPI = 0>
-int launch1w(const GemmP& p0, hipStream_t stream) {
-    using G = Geo1w;
-    GemmP p = p0;
-    p.nbm = (p.M + BM - 1) / BM;
-    p.nbn = (p.N + G::BN - 1) / G::BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm1w_kernel<A_T, B_T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G::LDS) != hipSuccess)
-            return YAT_EINVAL;
-        attr_set = true;
-    }
-    if (p.ksplit < 1) p.ksplit = 1;
-    hipLaunchKernelGGL((gemm1w_kernel<A_T, B_T, EPI>), dim3(p.nbm * p.nbn * p.ksplit), dim3(256), G::LDS, stream, p);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? YAT_OK : (int)e;
-}
+// (gemm1w -- the same 256 x 256 x 64 tile with ONE wave per SIMD and the K loop software-pipelined inside each wave, tile
+// variant 6 -- was measured in round 2, never won a shape and is gone; profiles/LOG_r01_r03.md section 9.)
 
 template <bool A_T, bool B_T, int NT, int EPI = 0>
 int launch256(const GemmP& p0, hipStream_t stream) {
@@ -1271,8 +1042,7 @@ int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStre
     }
 #define YAT_CASE(AT, BT)                                                     \
     if (a_t == AT && b_t == BT)                                              \
-        return nt_variant == 6 ? launch1w<AT, BT>(p, stream)                 \
-                               : nt_variant == 5 ? launch256<AT, BT, 5>(p, stream) : launch256<AT, BT, 4>(p, stream);
+        return nt_variant == 5 ? launch256<AT, BT, 5>(p, stream) : launch256<AT, BT, 4>(p, stream);
     YAT_CASE(false, false)
     YAT_CASE(false, true)
     YAT_CASE(true, true)
