@@ -417,7 +417,7 @@ class HipDDP:
         elif self.on_gpu:
             for w in self._works:
                 w.wait()                         # makes the current stream wait; does not block the host
-            if dist.get_backend(self.pg) != "nccl":
+            if not (dist.is_initialized() and dist.get_backend(self.pg) == "nccl"):
                 torch.cuda.current_stream().wait_stream(self.comm_stream)     # (the gloo rehearsal's staging copies)
         else:
             for w, chunk in self._works:
