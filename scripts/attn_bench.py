@@ -33,7 +33,9 @@ for name, lens in (("all64", [64] * B), ("all160", [160] * B), ("all512", [512] 
     work = ops.kv_work_list(lens, T, dev)
     b_ = timeit(lambda: ops.sdpa_bwd(q, kv[:, :D], kv[:, D:], B, N, T, H, dh, sc, bias, kvl, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:], work=work))
     tiles = sum((L + 63) // 64 for L in lens)
-    print(f"sdpa {name:8s} key-tiles={tiles:3d}  fwd={f:7.1f}us  bwd(dq+dkv)={b_:7.1f}us", flush=True)
+    bq = timeit(lambda: ops.sdpa_bwd(q, kv[:, :D], kv[:, D:], B, N, T, H, dh, sc, bias, kvl, out, dout, lse, delta, dq, dkv[:, :D], dkv[:, D:], work=work, parts=1))
+    print(f"sdpa {name:8s} key-tiles={tiles:3d}  fwd={f:7.1f}us  bwd(dq+dkv)={b_:7.1f}us  dq alone={bq:7.1f}us  dkv={b_ - bq:7.1f}us  "
+          f"checksum {dkv.float().abs().sum().item():.4e}", flush=True)
 H1, D1 = 70, 2240
 qkv = torch.randn(B * N, 3 * D1, device=dev).to(BF)
 o1 = torch.empty(B * N, D1, dtype=BF, device=dev); do1 = torch.randn(B * N, D1, device=dev).to(BF); dqkv = torch.empty_like(qkv)
