@@ -62,8 +62,11 @@ for lay, m, n, k in SHAPES:
     if os.environ.get("PROBE_AB"):            # which operand's coldness costs: rotate only A / only B
         modes = [("hot", ins[:1], outs[:1]), ("cold", ins, outs), ("cold_a", [(a, ins[0][1]) for a, _ in ins], outs[:1]),
                  ("cold_b", [(ins[0][0], b) for _, b in ins], outs[:1])]
+    if os.environ.get("PROBE_MODES"):         # e.g. "hot" or "cold": one mode per process (PMC passes: one counter set per mode)
+        modes = [md for md in modes if md[0] in os.environ["PROBE_MODES"].split(",")]
     for mode, si, so in modes:
         res[mode] = run(si, so, m, n, k, a_t, b_t, est)
+    res.setdefault("hot", float("nan")); res.setdefault("cold", float("nan"))
     print(f"{lay} {m:6d}x{n:6d}x{k:6d} R={R}: " + "   ".join(f"{md} {us:7.1f} us ({fl / us / 1e6:5.0f})" for md, us in res.items())
           + f"   cold/hot +{100 * (res['cold'] / res['hot'] - 1):.1f} %", flush=True)
     del ins, outs
