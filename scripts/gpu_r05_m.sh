@@ -2,5 +2,7 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout -k 10 300 python scripts/prefetch_probe.py > gpurun_out/prefetch_probe.txt 2> gpurun_out/prefetch_probe.err; rc=$?
-cat gpurun_out/prefetch_probe.txt; tail -n 3 gpurun_out/prefetch_probe.err; exit $rc
+for st in 1 8; do
+  echo "== prefetch reads every ${st}th 4-byte word"
+  PREFETCH_STRIDE=$st timeout -k 10 300 python scripts/prefetch_probe.py 2>&1 | grep pair || exit 1
+done | tee gpurun_out/prefetch_probe2.txt

@@ -15,6 +15,7 @@ BF, dev = torch.bfloat16, "cuda"
 M, D = 8192, 2240
 SHAPES = [(6720, 11200), (2240, 11200), (11200, 2240)]
 R = 24
+STRIDE = int(os.environ.get("PREFETCH_STRIDE", "32"))
 x = (torch.randn(M, D, device=dev) * 0.5).to(BF)
 side = torch.cuda.Stream()
 
@@ -34,7 +35,7 @@ def run(n1, n2, prefetch, reps=60):
             ev.record()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                sink.add_(b.view(torch.int32).view(-1)[::32].sum(dtype=torch.int32))       # one word per 128-B line
+                sink.add_(b.view(torch.int32).view(-1)[::STRIDE].sum(dtype=torch.int32))       # STRIDE 32: one word per 128-B line; 1: every byte
         ops.gemm(x, a, o1, M=M, N=n1, K=D)
         ops.gemm(x, b, o2, M=M, N=n2, K=D)
     for i in range(12):
