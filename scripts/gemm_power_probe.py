@@ -39,8 +39,7 @@ M, D, Hc = 8192, 2240, 5600
 SHAPES = [("inv_fwd   nt 8192x11200x2240", "nt", M, 2 * Hc, D, 0), ("inv_dgrad nn 8192x2240x11200", "nn", M, D, 2 * Hc, 0),
           ("inv_wgrad tn 11200x2240x8192", "tn", 2 * Hc, D, M, 0), ("out_fwd   nt 8192x2240x2240 ", "nt", M, D, D, 0),
           ("inv_fwd   nt  .. 128x128 tile", "nt", M, 2 * Hc, D, 1), ("inv_fwd   nt  .. 256x256 tile", "nt", M, 2 * Hc, D, 4),
-          ("inv_fwd   nt  .. 256x256, 1 wave/SIMD", "nt", M, 2 * Hc, D, 6), ("inv_wgrad tn  .. 256x256 tile", "tn", 2 * Hc, D, M, 4),
-          ("inv_wgrad tn  .. 256x256, 1 wave/SIMD", "tn", 2 * Hc, D, M, 6)]
+          ("inv_wgrad tn  .. 256x256 tile", "tn", 2 * Hc, D, M, 4)]
 time.sleep(1.5)
 t0 = time.time(); time.sleep(2.0); print("idle                          :", window(t0 - 0.8, time.time() + 0.2), flush=True)
 for name, lay, m, n, k, var in SHAPES:
