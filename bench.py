@@ -311,7 +311,7 @@ def main():
     ap.add_argument("--rccl-channels", type=int, default=-1, metavar="N",
                     help="cap RCCL at N channels (NCCL_MAX_NCHANNELS=N before the communicator is built): fewer channels = "
                          "fewer persistent collective workgroups competing with the GEMM tiles for CUs, at lower link "
-                         "bandwidth; 0 = RCCL's default; -1 = the policy of yat_amd/ddp.py (16 unless the site set the "
+                         "bandwidth; 0 = RCCL's default; -1 = the policy of yat_amd/ddp.py (24 unless the site set the "
                          "variable).  The value in force is reported in the `comm` object")
     ap.add_argument("--comm-steps", type=int, default=6, help="steps of each pass of the data-parallel diagnostics")
     ap.add_argument("--transport", choices=["torch", "native"], default=None,

@@ -72,14 +72,17 @@ def group_backend(on_gpu=True):
 
 # RCCL channel cap of a data-parallel job.  A channel is a persistent workgroup of the collective kernel, and a gemm256
 # workgroup owns its CU outright (144 KiB of LDS, 2 x 250 VGPRs per SIMD: DESIGN.md section 5), so the two never share a CU:
-# while a bucket's all-reduce runs, every channel takes one CU away from the backward.  3.21 GB of gradients per step need
-# ~17 ms of ring time at the xGMI plateau (~190 GB/s algorithm bandwidth at 8 ranks) and have ~50 ms of backward to hide
-# under, so bandwidth is not what the step is short of -- CUs are: 16 channels cost the backward 16 / 256 of its rate while a
-# collective is in flight (~1 - 2 ms per step even if the ring then runs at half the plateau), RCCL's own choice of 32 - 64
-# twice to four times that for a transfer that is hidden either way; the last bucket (the embedders, 88 - 149 MB, nothing left
-# to hide under) costs ~1 ms more at 16.  Never measured on N > 1 GPUs: a site's own NCCL_MAX_NCHANNELS wins, and
-# ``bench.py --rccl-channels N`` (0 = RCCL's default) is there to sweep it.
-RCCL_CHANNEL_CAP = 16
+# while a bucket's all-reduce runs, every channel takes one CU away from the backward.  3.21 GB of gradients per step have
+# ~50 ms of backward to hide under, and a channel moves roughly 9 GB/s of bus bandwidth over xGMI (RCCL reaches its ~300 GB/s
+# plateau at 8 ranks with 32+ of them), so bandwidth is not what the step is short of -- CUs are:
+#   channels   bus GB/s   ring time of 3.21 GB   CU share while it runs   cost to the backward   last bucket (149 MB) exposed
+#      16        ~145          ~39 ms                  6 %                    ~2.4 ms                  ~1.8 ms
+#      24        ~215          ~26 ms                  9 %                    ~2.4 ms                  ~1.2 ms
+#      64        ~300          ~19 ms                 25 %                    ~4.7 ms                  ~0.9 ms
+# 24 keeps the ring time at half the backward (16 leaves too little margin should a channel move less than assumed: a ring
+# that outlasts the backward is exposed in full) at a third of the CUs RCCL would take by itself.  Never measured on N > 1
+# GPUs: a site's own NCCL_MAX_NCHANNELS wins, and ``bench.py --rccl-channels N`` (0 = RCCL's default) is there to sweep it.
+RCCL_CHANNEL_CAP = 24
 
 
 def apply_channel_policy(world, cap=None):
