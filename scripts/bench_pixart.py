@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--gemm-detail", default=None)
+    ap.add_argument("--chains", type=int, default=0, help="independent forward chains over image ranges (0 = the model's default)")
     ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile of four steps enqueued onto an idle GPU")
     ap.add_argument("--roofline-steps", type=int, default=2)
     ap.add_argument("--lora", type=int, default=0, metavar="RANK", help="plain LoRA adapters of this rank on a frozen base")
@@ -66,6 +67,8 @@ def main():
         trained = LoRAAdapters(model, ["to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"], r=args.lora,
                                alpha=float(args.lora))
         log(f"LoRA rank {args.lora}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
+    if args.chains > 0:
+        model.fwd_chains = args.chains
     opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0, overlap_update=True)
     recipe = PixArtRecipe(model, device=dev)
     B, T, Cc = args.batch, 300, cfg.caption_channels

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--gemm-detail", default=None)
+    ap.add_argument("--chains", type=int, default=0, help="independent forward chains over image ranges (0 = the model's default)")
     ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile of four steps enqueued onto an idle GPU")
     ap.add_argument("--roofline-steps", type=int, default=2)
     args = ap.parse_args()
@@ -67,6 +68,8 @@ def main():
     cfg = SD3Config(num_layers=args.layers, dual_attention_layers=tuple(i for i in range(13) if i < args.layers))
     model = SD3Transformer2DModelHIP(cfg, device=dev).init_synthetic(seed=0)
     log(f"SD3.5-Medium MMDiT: {args.layers} blocks ({len(cfg.dual_attention_layers)} dual), {model.numel_flat / 1e6:.1f} M parameters")
+    if args.chains > 0:
+        model.fwd_chains = args.chains
     opt = FlatAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0, overlap_update=True)
     recipe = SD3Recipe(model, device=dev)
     B, T = args.batch, 333
