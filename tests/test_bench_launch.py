@@ -53,3 +53,7 @@ def test_self_launch_world2_over_gloo_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and d["scaling"] == "weak"
     assert d["comm"]["world"] == 2 and "error" not in d["comm"]
+    # what the communicator itself saw (round-4 review 5b), not the launcher's environment; and the channel cap in force
+    assert d["comm"]["communicator"]["world"] == 2 and d["comm"]["communicator"]["rank"] == 0
+    assert "gloo" in d["comm"]["communicator"]["owner"]
+    assert d["comm"]["rccl_channels"]["NCCL_MAX_NCHANNELS"] == "24"
