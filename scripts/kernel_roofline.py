@@ -20,7 +20,7 @@ BYTES = [            # (regex on the kernel name, algorithmic bytes per call, wh
     (r"adamw_kernel", 14 * NP, "p, g, m, v read; p, m, v written (bf16): 14 B / parameter, one launch"),
     (r"gradnorm_partial", 2 * NP, "g read"),
     (r"dwglu_(tile|stream)_kernel", 10 * M * Hc, "s read; u (kept for the backward) and y written"),
-    (r"dwglu_bwd2", 16 * M * Hc, "du, s, z read; dz written"),
+    (r"dwglu_bwd2", 12 * M * Hc, "du, z read; dz written (s = SiLU(z) is recomputed since round 5)"),
     (r"ln_mod_fwd", 4 * M * D, "x read, h written"),
     (r"ln_mod_bwd_rows", 8 * M * D, "dy, x, incoming dx read; dx written"),
     (r"ln_mod_bwd_cols", 4 * M * D, "dy, x read (column statistics)"),

@@ -90,10 +90,8 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s * (1 + x * (1 - s))
-__device__ __forceinline__ float dsilu_f(float x) {
-    float s = sigmoid_f(x);
-    return s * (1.0f + x * (1.0f - s));
-}
+__device__ __forceinline__ float dsilu_from_sigmoid(float x, float s) { return s * (1.0f + x * (1.0f - s)); }
+__device__ __forceinline__ float dsilu_f(float x) { return dsilu_from_sigmoid(x, sigmoid_f(x)); }
 // GELU(approximate='tanh') through the identity 0.5 (1 + tanh u) = sigmoid(2u), u = k0 (x + k1 x^3): one v_exp_f32 and one
 // v_rcp_f32 instead of libm's tanhf (~40 instructions with branches -- in the epilogue of the K = 1152 FFN GEMM of PixArt
 // that was half of the main loop's time).  Same function, fp32 rounding differences ~1e-7, far below the bf16 output.

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
     const int PHd = ((R + 2) * WP + 1 + TILE_PAD + 15) & ~15, PHc = (R * WP + 1 + TILE_PAD + 15) & ~15;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, nslots = blockDim.x / NCG;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    clear_tile(tile, (PHd + 2 * PHc) * TCH * 2);
+    clear_tile(tile, (PHd + PHc) * TCH * 2);
     const int cg = lane & (NCG - 1);
     const int c0 = ch0 + cg * 4;
     const bool chan_ok = c0 < C2;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
     }
     const int nseg = (w + SEG - 1) / SEG, nruns = R * nseg;
     const int slot = threadIdx.x / NCG;
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(du, bytes), rs = make_rsrc(sact, bytes), rz = make_rsrc(z, bytes);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(du, bytes), rz = make_rsrc(z, bytes);
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(dz, bytes);
     const bool lane_ch_ok = ch0 + (lane % PPP) * 8 < C2;
 
@@ -262,8 +262,7 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
     const int i0 = rb * R;
     __syncthreads();
     stage_rows(rd, tile, 0, R + 2, i0 - 1, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
-    stage_rows(rs, tile, PHd, R, i0, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
-    stage_rows(rz, tile, PHd + PHc, R, i0, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
+    stage_rows(rz, tile, PHd, R, i0, b, h, w, WP, C2, ch0, lane_ch_ok, wave_s, nwaves, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -273,10 +272,9 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
         if (i >= h || !chan_ok) continue;
         const int j0 = seg * SEG;
         const unsigned char* pd = tile + ((row * WP + j0) * TCH + cg * 4) * 2;                 // du rows row .. row+2
-        const unsigned char* ps = tile + ((PHd + row * WP + j0 + 1) * TCH + cg * 4) * 2;       // s at output column j0
-        const unsigned char* pz = ps + PHc * TCH * 2;
+        const unsigned char* pz = tile + ((PHd + row * WP + j0 + 1) * TCH + cg * 4) * 2;       // z at output column j0
         const int64_t pix0 = ((int64_t)b * h + i) * w + j0;
-        f32x2 acc[3][2], S[3][2];
+        f32x2 acc[3][2], S[3][2], SG[3][2], ZC[3][2];
 #pragma unroll
         for (int m = 0; m < 3; ++m) acc[m][0] = acc[m][1] = f32x2{0.f, 0.f};
         u32x2 nxt[3];
@@ -292,9 +290,20 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
                 for (int r = 0; r < 3; ++r) nxt[r] = *reinterpret_cast<const u32x2*>(pd + (r * WP + t + 1) * TCH * 2);
             }
             if (t < SEG) {                                  // s of output column t (zero past the image: it must not count)
-                u32x2 sv = *reinterpret_cast<const u32x2*>(ps + t * TCH * 2);
-                if (j0 + t >= w) sv = u32x2{0u, 0u};
-                unpack22(sv, S[t % 3]);
+                // s = bf16(z sigmoid(z)) is what the conv_inverted GEMM stored (gemm_common.hpp: silu_f on the rounded z, rounded
+                // again by the store).  Round 5: recomputed here, bit for bit, from the z this pass reads anyway -- the sigmoid is
+                // kept for the SiLU' of the same column two iterations on -- so s is not read at all: a quarter of the pass's
+                // bytes (181 -> 163 us at 32 x 32, 239 -> 175 at 16 x 64; profiles/r05_o_*).
+                unpack22(*reinterpret_cast<const u32x2*>(pz + t * TCH * 2), ZC[t % 3]);
+                const bool in_img = j0 + t < w;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float zz = ZC[t % 3][pr][e], sg = sigmoid_f(zz);
+                        SG[t % 3][pr][e] = sg;
+                        S[t % 3][pr][e] = in_img ? rbf(zz * sg) : 0.f;
+                    }
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -319,11 +328,11 @@ __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, i
             }
             const int o = t - 2;
             if (o >= 0) {
-                float zz[4];
-                unpack4(*reinterpret_cast<const u32x2*>(pz + o * TCH * 2), zz);
+                float ds[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ds[e] = dsilu_from_sigmoid(ZC[o % 3][e >> 1][e & 1], SG[o % 3][e >> 1][e & 1]);
                 const f32x2 a0 = acc[o % 3][0], a1 = acc[o % 3][1];
-                const u32x2 v = pack4(rbf(a0[0]) * dsilu_f(zz[0]), rbf(a0[1]) * dsilu_f(zz[1]), rbf(a1[0]) * dsilu_f(zz[2]),
-                                      rbf(a1[1]) * dsilu_f(zz[3]));
+                const u32x2 v = pack4(rbf(a0[0]) * ds[0], rbf(a0[1]) * ds[1], rbf(a1[0]) * ds[2], rbf(a1[1]) * ds[3]);
                 acc[o % 3][0] = acc[o % 3][1] = f32x2{0.f, 0.f};
                 const bool live = j0 + o < w;
                 f32x2 vz[2];
@@ -368,7 +377,7 @@ inline int pick_band_rows_bwd2(int h, int w, size_t* lds_bytes, int* threads) {
     const int ns = *threads / NCG;
     for (int R = 4; R <= 16 && R <= ((h + 1) & ~1); ++R) {     // >= ROWS: the partial rows fit the workspace
         const int PHd = ((R + 2) * WP + 1 + TILE_PAD + 15) & ~15, PHc = (R * WP + 1 + TILE_PAD + 15) & ~15;
-        size_t bytes = (size_t)(PHd + 2 * PHc) * TCH * 2;
+        size_t bytes = (size_t)(PHd + PHc) * TCH * 2;
         if (bytes < ns * NCG * 4 * PK * sizeof(float)) bytes = ns * NCG * 4 * PK * sizeof(float);
         if (bytes > 65536) break;
         const int nruns = R * nseg, passes = (nruns + ns - 1) / ns;
