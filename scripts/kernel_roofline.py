@@ -30,8 +30,8 @@ BYTES = [            # (regex on the kernel name, algorithmic bytes per call, wh
     (r"sdpa_bwd_dkv", 4 * M * D, "q, do read (dk, dv: text rows)"),
     (r"la_state", 4 * M * D, "k, v read"),
     (r"la_fwd", 4 * M * D, "q read, out written"),
-    (r"la_bwd_q", 10 * M * D, "q, k, v, dout read; dq written (+ state-gradient slabs)"),
-    (r"la_bwd_kv", 10 * M * D, "k, v, dout read; dk, dv written"),
+    (r"la_bwd_q", 6 * M * D, "q, dout read; dq written (the state and its gradient slabs are small)"),
+    (r"la_bwd_kv", 8 * M * D, "k, v read; dk, dv written"),
 ]
 rows = list(csv.DictReader(open(path)))
 print(f"# {path}: {steps:g} steps; serialized stream; achieved = algorithmic bytes / average duration")

@@ -222,6 +222,8 @@ int launch_tile_best(int B, int h, int w, int Hc, const bf16_t* s, const bf16_t*
 //   dz[i,j] = SiLU'(z[i,j]) * bf16( sum_taps W[tap] du[i-di, j-dj] );  dW[tap] += s[i,j] * du[i-di, j-dj];  db += du[i,j]
 // The thread's dW/db registers are summed over the 32 run slots through the (then free) tile memory: one partial row
 // per workgroup, ws[(b*nbands + band)][2Hc*10].
+// (two workgroups per CU; sized for three -- 53 KB tiles, which the kernel's 166 registers would allow -- it is 5 .. 8 % slower:
+// shorter bands re-read more halo; profiles/r05_q_*)
 __global__ __launch_bounds__(256, 2) void dwglu_bwd2_tile_kernel(int h, int w, int Hc, int B, int R, int rmagic, int nbands,
                                                                  int bpb, int nchunk, const bf16_t* sact, const bf16_t* z,
                                                                  const bf16_t* du, uint64_t bytes, const bf16_t* wdw,
@@ -571,9 +573,11 @@ int yat_dwconv_glu_bwd(int B, int h, int w, int Hc, const void* s, const void* z
     // pass 2 variants: 64 channels per tile with s, z straight from global (128-byte pixel slices everywhere; 1), or the
     // 32-channel kernel with all three operands tiled in LDS (2); YAT_DW_BWD2=2 forces the latter
     static const int bwd2_force = YAT_TUNE_INT("YAT_DW_BWD2", 0);
-    // measured (B = 8, Hc = 5600, us, 32-channel all-LDS kernel -> 64-channel global-s/z kernel): 32x32 237 -> 172,
-    // 44x22 228 -> 211, but 24x42 199 -> 216 and 16x64 228 -> 246: narrow rows only
-    int nparts = (bwd2_force == 2 || (bwd2_force == 0 && w > 32)) ? 0 : v64w3::launch_bwd2_gs(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)z, du,
+    // measured again after the s read went away (round 5, B = 8, Hc = 5600, us, band kernel vs global-z kernel,
+    // profiles/r05_q_*): 32x32 171 vs 162, 44x22 211 vs 225, 24x42 196 vs 223, 16x64 180 vs 227, 7x9 40 vs 30: the global-z
+    // kernel where a row is exactly four 8-column segments or the image is tiny, the band kernel otherwise
+    const bool gs_shape = (w > 24 && w <= 32) || w < 16;
+    int nparts = (bwd2_force == 2 || (bwd2_force == 0 && !gs_shape)) ? 0 : v64w3::launch_bwd2_gs(B, h, w, Hc, (const bf16_t*)s, (const bf16_t*)z, du,
                                                               (const bf16_t*)wdw, (bf16_t*)dz, ws, (hipStream_t)stream);
     const bool gs = nparts > 0;
     const int R2 = !gs && w <= 64 && !(C2 & 7) && du_bytes <= 0x7fffffffull ? pick_band_rows_bwd2(h, w, &lds2, &threads2) : 0;
