@@ -70,6 +70,10 @@ __device__ unsigned int yat_sdpa_wg_times[4096 * 6];
 // the phases).  Measured at N = T = 4096 (scripts/gpu_attn_libs.sh, profiles/r04_l_*): dK/dV kernel 1.43 -> 1.36 ms (dh 72) and
 // 1.88 -> 1.80 ms (dh 64); forward 1.02 -> 0.98 ms at dh 64, level at dh 72; the dQ kernel 1 % slower with it -> not there.
 // The opposite assignment (softmax high) costs the forward 3..7 %.
+// A tie-break between the two waves of a SIMD (matrix phases at level 2 or 3 by the parity of the wave slot, HW_ID bit 0, so that
+// waves reaching their MFMA phases together do not take turns) was measured in round 5 and is slower: forward 795 -> 827 us (dh 72),
+// 974 -> 1043 (dh 64), dK/dV 1360 -> 1397; the waves are not in step to begin with (profiles/r04_l_attention_phase_stamps.txt:
+// the partner wave adds 14 % to a wave's tile time).  profiles/r05_w_attention_priority_tiebreak.txt.
 #ifndef YAT_SDPA_PRIO_DKV
 #define YAT_SDPA_PRIO_DKV 1
 #endif
