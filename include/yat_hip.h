@@ -68,6 +68,14 @@ typedef struct yat_gemm_epilogue {
                            /* dy), from one extra MFMA per A fragment against a fragment of ones in the workgroups of the first */
                            /* column tile instead of a second pass over dy; accumulate: out[m] = bf16(bf16(sum) + out[m])      */
                            /* (gradient accumulation, the `residual` = C convention)                                           */
+    const void* a2;        /* SECOND OPERAND PAIR, or NULL (forward layout (0,0) only, no split-K): C = epilogue(A B^T + A2 B2^T), */
+    const void* b2;        /* both products in one fp32 accumulator, rounded once -- a PEFT adapter's factored term folded into    */
+    int k2;                /* the base Linear: base_layer(x) + T P^T (LoKr: T = x' w2_b^T, P = kron(w1, w2_a) alpha/r; peft's       */
+    int a2_group_n;        /* wrap at common/trainer.py:212-238) without the [M, N] addend of `pre_add`.  A2 is bf16 [M, >= k2]   */
+                           /* with A's row stride lda, B2 bf16 [N, k2] with B's row stride ldb -- they are read as k2 further     */
+                           /* columns of A and B that live at other addresses; k2 a multiple of 64.  a2_group_n = g > 0 (a        */
+                           /* multiple of 320, or of 256): columns [j g, (j+1) g) of C take columns [j k2, (j+1) k2) of A2 (a     */
+                           /* fused q|k|v Linear with one adapter per block); excludes glu_u / pre_add / dact_z / a_rowsum_out    */
 } yat_gemm_epilogue;
 
 uint64_t yat_gemm_epilogue_size(void);   /* sizeof(yat_gemm_epilogue) in this build of the library */

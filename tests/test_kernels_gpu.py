@@ -254,6 +254,75 @@ def test_gemm256_epilogue_and_identity(ops, variant):
     close(s_out, F.silu(linr).to(BF), f"gemm256v{variant}_epi_silu")
 
 
+@pytest.mark.parametrize("variant", [0, 4, 5])
+@pytest.mark.parametrize("K,K2", [(64, 64), (128, 192), (320, 64), (2240, 320), (5600, 576), (72, 128), (200, 64)])
+def test_gemm256_second_operand_pair(ops, variant, K, K2):
+    """yat_gemm_epilogue.a2 / b2 / k2: C = epilogue(A B^T + A2 B2^T) with both products in one accumulator -- the K2 / 64 k-tiles
+    of the second pair ride behind the last (possibly ragged) tile of K in the same LDS-DMA loop.  A2 / B2 are views with the
+    row strides of A / B; the rest of their buffers holds NaNs that must never be read.  Every start-up / counted / tail form of
+    the loop (1 .. 97 tiles), ragged M and N, then the fused epilogue on top."""
+    M, N = 520, 648
+    x, w = rnd(M, K, seed=400), rnd(N, K, scale=(K + K2) ** -0.5, seed=401)
+    t, pm = rnd(M, K2, seed=402), rnd(N, K2, scale=(K + K2) ** -0.5, seed=403)
+    lda, ldb = max(K, K2), max(K, K2)                     # (a 64-wide K with a 192-wide second pair: strides cover both)
+    xs = torch.full((M, lda), float("nan"), dtype=BF, device=DEV); xs[:, :K] = x
+    ws = torch.full((N, ldb), float("nan"), dtype=BF, device=DEV); ws[:, :K] = w
+    a2 = torch.full((M, lda), float("nan"), dtype=BF, device=DEV); a2[:, :K2] = t
+    b2 = torch.full((N, ldb), float("nan"), dtype=BF, device=DEV); b2[:, :K2] = pm
+    ref = x.float() @ w.float().T + t.float() @ pm.float().T
+    out = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    ops.gemm(xs[:, :K], ws[:, :K], out, M=M, N=N, K=K, lda=lda, ldb=ldb, a2=a2[:, :K2], b2=b2[:, :K2], k2=K2, variant=variant)
+    close(out, ref.to(BF), f"gemm256v{variant}_pair K={K}+{K2}")
+    # the same sum as ONE product over the concatenated operands: bit-identical (same tiles in the same order) when K is whole tiles
+    if K % 64 == 0:
+        xc, wc = torch.cat([x, t], 1).contiguous(), torch.cat([w, pm], 1).contiguous()
+        one = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm(xc, wc, one, M=M, N=N, K=K + K2, variant=variant if variant else 0)
+        if variant:
+            assert torch.equal(out, one), "second operand pair differs from the concatenated product"
+    bias, res = rnd(N, seed=404), rnd(M, N, seed=405)
+    lin = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm(xs[:, :K], ws[:, :K], out, M=M, N=N, K=K, lda=lda, ldb=ldb, a2=a2[:, :K2], b2=b2[:, :K2], k2=K2, variant=variant,
+             bias=bias, aux_out=lin, activation="silu", residual=res)
+    linr = rb(ref + bias.float())
+    close(lin, linr, f"gemm256v{variant}_pair_lin K={K}+{K2}")
+    # (only a gate rounds in between; from the kernel's own pre-activation copy, so that a rounding tie there does not count twice)
+    close(out, (res.float() + F.silu(lin.float())).to(BF), f"gemm256v{variant}_pair_epi K={K}+{K2}")
+
+
+def test_gemm256_second_operand_pair_blocks_and_rejections(ops):
+    """a2_group_n: the column blocks of a fused q|k|v Linear each take their own K2 columns of A2 (one adapter per block); and what
+    the entry point refuses: other layouts, a K2 that is not whole tiles, strides that differ, blocks the column tile straddles."""
+    M, D, K, K2 = 520, 640, 256, 128
+    x, w = rnd(M, K, seed=410), rnd(3 * D, K, scale=K ** -0.5, seed=411)
+    t, pm = rnd(M, 3 * K2, seed=412), rnd(3 * D, K2, scale=K ** -0.5, seed=413)
+    lda = 3 * K2
+    xs = torch.full((M, lda), float("nan"), dtype=BF, device=DEV); xs[:, :K] = x
+    a2 = t.contiguous()                                   # [M, 3 K2]: row stride 3 K2 = lda
+    b2 = torch.full((3 * D, K), float("nan"), dtype=BF, device=DEV); b2[:, :K2] = pm
+    ref = x.float() @ w.float().T
+    for j in range(3):
+        ref[:, j * D:(j + 1) * D] += t[:, j * K2:(j + 1) * K2].float() @ pm[j * D:(j + 1) * D].float().T
+    out = torch.full((M, 3 * D), float("nan"), dtype=BF, device=DEV)
+    for variant in (0, 5):                                # 640 = 2 x 320: the 320-wide tile only
+        out.fill_(float("nan"))
+        ops.gemm(xs[:, :K], w, out, M=M, N=3 * D, K=K, lda=lda, a2=a2, b2=b2[:, :K2], k2=K2, a2_group_n=D, variant=variant)
+        close(out, ref.to(BF), f"gemm256_pair_blocks v{variant}")
+    from yat_amd import lib as L
+    bad = [dict(variant=4, a2_group_n=D),                 # 640 is not a multiple of 256
+           dict(k2=96), dict(variant=1), dict(variant=205), dict(a2_group_n=100)]
+    for kw in bad:
+        args = dict(M=M, N=3 * D, K=K, lda=lda, a2=a2, b2=b2[:, :K2], k2=K2, a2_group_n=D, variant=0)
+        args.update(kw)
+        with pytest.raises(L.YatLibraryError):
+            ops.gemm(xs[:, :K], w, out, **args)
+    with pytest.raises(L.YatLibraryError):                # dgrad layout
+        ops.gemm(xs[:, :K], w.T.contiguous(), out, b_t=True, M=M, N=3 * D, K=K, lda=lda, ldb=3 * D, a2=a2,
+                 b2=w.T.contiguous()[:K2], k2=K2)
+    with pytest.raises(ValueError):                       # A2 with another row stride
+        ops.gemm(xs[:, :K], w, out, M=M, N=3 * D, K=K, lda=lda, a2=t[:, :K2].contiguous(), b2=b2[:, :K2], k2=K2)
+
+
 @pytest.mark.parametrize("code", [204, 405, 205, 804, 304, 1005, 305])
 def test_gemm256_split_k(ops, code):
     """Split-K (fp32 slabs + reduce kernel with the fused epilogue), forced via variant = 100*ksplit + tile."""

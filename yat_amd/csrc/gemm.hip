@@ -240,6 +240,17 @@ static int fill_gemm_p(int a_t, int b_t, int M, int N, int K, const void* A, int
         p.rowsum = (bf16_t*)ep->a_rowsum_out; p.rowsum_acc = ep->a_rowsum_accumulate;
         if (p.rowsum && (!a_t || !b_t || p.bias || p.gate || p.aux || p.act || p.glu_u || p.pre_add || p.dact_z))
             return YAT_EINVAL;                                   // weight-gradient layout, plain (or accumulating) epilogue
+        p.A2 = (const bf16_t*)ep->a2; p.B2 = (const bf16_t*)ep->b2; p.K2 = ep->k2; p.a2_group = ep->a2_group_n;
+        if (p.A2 || p.B2) {                                      // second operand pair: forward layout, whole tiles of K2
+            if (!p.A2 || !p.B2 || a_t || b_t || p.K2 <= 0 || (p.K2 & 63) || p.glu_u || p.pre_add || p.dact_z || p.rowsum)
+                return YAT_EINVAL;
+            if (p.a2_group < 0 || (p.a2_group > 0 && (p.a2_group % 320) && (p.a2_group % 256))) return YAT_EINVAL;
+            const int blocks = p.a2_group > 0 ? (N + p.a2_group - 1) / p.a2_group : 1;
+            if ((int64_t)blocks * p.K2 > lda || p.K2 > ldb) return YAT_EINVAL;     // the rows of A2 / B2 have A's / B's stride
+            p.a2_bytes = ((uint64_t)(M - 1) * lda + (uint64_t)blocks * p.K2) * 2;
+            p.b2_bytes = ((uint64_t)(N - 1) * ldb + (uint64_t)p.K2) * 2;
+            if (p.a2_bytes > 0x7fffffffull || p.b2_bytes > 0x7fffffffull) return YAT_EINVAL;
+        }
     }
     p.a_bytes = (uint64_t)(a_t ? K : M) * lda * 2;
     p.b_bytes = (uint64_t)(b_t ? K : N) * ldb * 2;
@@ -298,6 +309,14 @@ extern "C" int yat_gemm_bf16_ex(int a_t, int b_t, int M, int N, int K, const voi
     if (p.glu_u) {                              // GLU-backward epilogue lives in the 256-row kernel only
         if (ksplit != 1 || variant == 1 || a_t || !b_t || !wide_ok) return YAT_EINVAL;
         if (variant == 0) variant = est_time_256(M, N, K, 320, 1, streams) < est_time_256(M, N, K, 256, 1, streams) ? 5 : 4;
+    }
+    if (p.A2) {                                 // second operand pair: 256-row kernel only, the K loop runs over K + K2
+        if (ksplit != 1 || variant == 1 || !wide_ok) return YAT_EINVAL;
+        const bool ok5 = p.a2_group == 0 || p.a2_group % 320 == 0, ok4 = p.a2_group == 0 || p.a2_group % 256 == 0;
+        if ((variant == 5 && !ok5) || (variant == 4 && !ok4)) return YAT_EINVAL;
+        if (variant == 0)
+            variant = !ok4 ? 5 : !ok5 ? 4
+                    : est_time_256(M, N, K + p.K2, 320, 1, streams) < est_time_256(M, N, K + p.K2, 256, 1, streams) ? 5 : 4;
     }
     if (p.rowsum) {                             // bias gradient fused into the weight gradient: 256 x 256 tile (the 320-wide
         if (ksplit != 1 || (variant != 0 && variant != 4)) return YAT_EINVAL;   // one has no registers for the extra

@@ -196,7 +196,8 @@ __device__ __forceinline__ int xcd_contiguous(int nwg) {
 
 // One workgroup's whole job: `id` = work item inside problem p (tile x K slice, before the row-group swizzle).
 template <bool A_T, bool B_T, int NT, int EPI = 0>      // EPI: 0 standard, 1 GLU backward, 2 standard + pre_add, 3 act backward,
-                                                         //      4 standard + row sums of A (wgrad + bias gradient)
+                                                         //      4 standard + row sums of A (wgrad + bias gradient),
+                                                         //      5 standard, second operand pair behind K (forward layout)
 __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     using G = Geo<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -222,6 +223,12 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+    // EPI 5, the second operand pair (C = epilogue(A B^T + A2 B2^T): a PEFT adapter's factored term T P^T folded into the base
+    // Linear): A2 / B2 have the row strides of A / B, so the K2 / 64 k-tiles behind the last tile of K are the same per-lane
+    // offsets against two other buffer resources -- nothing else in the loop knows.  Column tiles of one A2 block: a2_group.
+    const int a2_col = (EPI == 5 && p.a2_group > 0) ? (n0 / p.a2_group) * p.K2 : 0;
+    const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(EPI == 5 ? p.A2 + a2_col : p.A, EPI == 5 ? p.a2_bytes - (uint64_t)a2_col * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(EPI == 5 ? p.B2 : p.B, EPI == 5 ? p.b2_bytes : 0);
 
     // this wave's DMA pieces (loop invariant): A pieces wave + 8j, B pieces wave + 8j
     Piece pa[G::PA], pb[G::PB];
@@ -232,7 +239,8 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     const uint32_t kchunk = piece_kchunk(wave, lane);
     const uint32_t a_kstep = A_T ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
     const uint32_t b_kstep = B_T ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
-    const int nt_all = (p.K + BK - 1) / BK;
+    const int nt_main = (p.K + BK - 1) / BK;
+    const int nt_all = nt_main + (EPI == 5 ? p.K2 / BK : 0);
     const int kt0 = (int)(((int64_t)nt_all * ksl) / p.ksplit);                 // this slice: k-tiles [kt0, kt0 + nt)
     const int nt = (int)(((int64_t)nt_all * (ksl + 1)) / p.ksplit) - kt0;
     const bool ragged = (p.K & (BK - 1)) != 0;
@@ -247,7 +255,11 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     // from 9 .. 19 % to 3 .. 13 %, but giving up the lockstep L2 sharing cost more than that: hot + 10 %, step 76.5 -> 80.4 ms.
     // profiles/r05_b_gemm_k_rotation_rejected_*.)
     auto ktile = [&](int tl) { return kt0 + tl; };                              // iteration tl of this slice -> global K-tile
-    auto is_tail = [&](int tl) { return ragged && ktile(tl) == nt_all - 1; };
+    auto is_tail = [&](int tl) { return ragged && ktile(tl) == nt_main - 1; };
+    // leading k-tiles of this slice that are all full ones: up to the ragged tile of K if the slice holds it (it is the slice's
+    // last tile unless a second operand pair follows it)
+    const int tail_at = ragged ? nt_main - 1 - kt0 : nt;
+    const int nfull = (tail_at >= 0 && tail_at < nt) ? tail_at : nt;
     auto piece = [&](auto checked, int tl, char* stage, int j) {
         constexpr bool CHECKED = decltype(checked)::value;
         const int t = ktile(tl);
@@ -406,6 +418,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #else
     constexpr bool DEEP = YAT_GEMM_DEEP && (B_T || YAT_GEMM_DEEP_KH);
 #endif
+    static_assert(EPI != 5 || DEEP, "the second operand pair is wired into the DEEP loop's DMA only");
     // B image of a DEEP kernel with a k-contiguous B operand (the forward GEMMs: B = W[N, K]).  The row image of the two-stage
     // schedule keeps both 32-deep halves of a column in one 128-B row, so no half can be refilled before the other has been
     // read.  Here the image is HALF-MAJOR: [half h][column n][4 chunks of 16 B] -- 64-B rows, half h at h * 64 * BN bytes --
@@ -501,14 +514,18 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         // one piece: operand / image piece / source offset (per-lane + uniform) / target tile (local index tl)
         auto dma = [&](auto checked, bool is_a, int pi, uint32_t voff, uint32_t delta, int tl, int kh_half = 0) {
             constexpr bool CHECKED = decltype(checked)::value;
-            const int t = ktile(tl);
+            const int tg = ktile(tl);
+            const bool second = EPI == 5 && tg >= nt_main;                  // uniform: a tile of the second operand pair
+            const int t = second ? tg - nt_main : tg;
             YAT_LDS void* dst = (YAT_LDS void*)(smem + (tl & 1) * G::STAGE + (is_a ? 0 : G::A_BYTES) + pi * 1024);
             const uint32_t soff = (uint32_t)t * (is_a ? a_kstep : b_kstep) + delta;
-            if (CHECKED) {
+            if (CHECKED) {                                                  // (only the ragged tile of K: never `second`)
                 uint32_t v = voff + soff;
                 if (is_a && !A_T && kchunk_a >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
                 if (!is_a && B_KH && kchunk_b + 4 * kh_half >= ((uint32_t)(p.K - t * BK) >> 3)) v = YAT_OOB;
                 lds_dma16(is_a ? ra : rb, dst, v);
+            } else if (second) {
+                lds_dma16s(is_a ? ra2 : rb2, dst, voff, soff);
             } else {
                 lds_dma16s(is_a ? ra : rb, dst, voff, soff);
             }
@@ -636,7 +653,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
         for (int j = 0; j < batch_count(1); ++j) batch_piece(std::integral_constant<int, 1>{}, std::false_type{}, -1, j);
         if (GRP == 1) YAT_PHASE_BARRIER();         // stagger: group 1 runs one segment behind group 0
 
-        const int nfast = max(0, nt - 2 - (ragged && kt0 + nt == nt_all ? 1 : 0));
+        const int nfast = max(0, nfull - 2);
         int t = 0;
         for (; t < nfast; ++t) iteration_deep(std::true_type{}, t);
         for (; t < nt; ++t) iteration_deep(std::false_type{}, t);
@@ -750,7 +767,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
     auto k_loop = [&](auto grp_c) {
         // iterations whose fetched tile (t+1; t+2 for group 1 of a DIC kernel) exists and is not the ragged last one
         const int ahead = (grp_c.value == 0 ? DIC : DIC_G1) ? 1 + grp_c.value : 1;
-        const int nfast = max(0, nt - ahead - (ragged && kt0 + nt == nt_all ? 1 : 0));
+        const int nfast = max(0, nfull - ahead);
         int t = 0;
         for (; t < nfast; ++t) iteration(grp_c, std::true_type{}, t);
         for (; t < nt; ++t) iteration(grp_c, std::false_type{}, t);
@@ -811,7 +828,7 @@ __device__ __forceinline__ void gemm256_body(const GemmP p, int id) {
 #define YAT_GEMM_EPI_PREFETCH 1
 #endif
         constexpr int UPL = (32 * CPR + 63) / 64;          // 8-column units per lane and pass
-        constexpr bool HAS_IN = YAT_GEMM_EPI_PREFETCH && (EPI == 1 || EPI == 2 || EPI == 3 || EPI == 0 || EPI == 4);
+        constexpr bool HAS_IN = YAT_GEMM_EPI_PREFETCH && (EPI == 1 || EPI == 2 || EPI == 3 || EPI == 0 || EPI == 4 || EPI == 5);
         const bool pre_on = HAS_IN && !split && (EPI == 1 || EPI == 3 || EPI == 2 || p.res != nullptr);
         // one input stream (residual | z): a whole pass ahead, double-buffered; two streams (GLU u_a + u_g, residual + pre_add):
         // the registers do not hold two passes of both -- loaded at the top of their own pass, before its slab round trip
@@ -1035,6 +1052,10 @@ int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStre
     if (p.rowsum) {                // weight gradient + bias gradient: (1,1) layout, 256 x 256 tile, whole K per workgroup
         if (!a_t || !b_t || p.ksplit > 1 || nt_variant != 4) return YAT_EINVAL;
         return launch256<true, true, 4, 4>(p, stream);
+    }
+    if (p.A2) {                    // second operand pair: forward layout, no split-K
+        if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;
+        return nt_variant == 5 ? launch256<false, false, 5, 5>(p, stream) : launch256<false, false, 4, 5>(p, stream);
     }
     if (p.pre_add) {               // adapter addend: only the forward layout (x W^T) is instantiated, no split-K
         if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;

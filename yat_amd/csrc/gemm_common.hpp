@@ -24,6 +24,11 @@ struct GemmP {
     bf16_t* rowsum;        // wgrad layout: [M] row sums of the A operand over K (the Linear's bias gradient) or null
     int rowsum_acc;
     int group;             // gemm256: 256-row tiles per row group of the XCD-contiguous tile order (0 = the default, 4)
+    const bf16_t* A2;      // gemm256, forward layout: second operand pair, C = epilogue(A B^T + A2 B2^T); A2 [M, .] with row
+    const bf16_t* B2;      // stride lda, B2 [N, K2] with row stride ldb (yat_gemm_epilogue.a2 / b2 / k2)
+    int K2;                // multiple of 64
+    int a2_group;          // 0, or columns of C per block of K2 columns of A2 (fused q|k|v views: one T per target)
+    uint64_t a2_bytes, b2_bytes;
 };
 
 // GLU backward fused into the producer of dy (= this GEMM's result d, rounded to bf16 like the Linear's output):

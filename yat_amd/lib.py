@@ -21,7 +21,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("bias", P), ("aux_out", P), ("activation", I), ("gate", P), ("residual", P),
                 ("ld_aux", I), ("ld_gate", I), ("ld_residual", I), ("rows_per_batch", I),
                 ("glu_u", P), ("ld_glu_u", I), ("pre_add", P), ("ld_pre_add", I), ("dact_z", P), ("ld_dact_z", I),
-                ("a_rowsum_out", P), ("a_rowsum_accumulate", I)]
+                ("a_rowsum_out", P), ("a_rowsum_accumulate", I), ("a2", P), ("b2", P), ("k2", I), ("a2_group_n", I)]
 
 
     def __init__(self, *args, **kw):

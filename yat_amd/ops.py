@@ -132,21 +132,25 @@ def gemm_concurrency(streams: int):
 
 def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, aux_out=None,
          activation="none", gate=None, ld_gate=0, residual=None, rows_per_batch=0, ld_aux=0, ld_residual=0, variant=0,
-         glu_u=None, pre_add=None, dact_z=None, a_rowsum=None, a_rowsum_accumulate=False, dyn=None):
+         glu_u=None, pre_add=None, dact_z=None, a_rowsum=None, a_rowsum_accumulate=False, dyn=None, a2=None, b2=None,
+         k2=0, a2_group_n=0):
     """yat_gemm_bf16.  out[M,N] = epilogue(A_op @ B_op); see the header for layouts.  ``dyn`` ("M" | "K"): inside a
-    ``text_rows`` scope, the dimension that is the text row count."""
-    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add, dact_z, a_rowsum)
+    ``text_rows`` scope, the dimension that is the text row count.  ``a2`` / ``b2`` / ``k2``: the second operand pair of the
+    forward layout (yat_gemm_epilogue.a2): views whose row strides are lda / ldb."""
+    _chk_bf16(a, b, out, bias, aux_out, gate, residual, glu_u, pre_add, dact_z, a_rowsum, a2, b2)
     lda = lda if lda is not None else (M if a_t else K)
     ldb = ldb if ldb is not None else (N if b_t else K)
     ldc = ldc if ldc is not None else N
     ep = None
     if bias is not None or aux_out is not None or activation != "none" or gate is not None or residual is not None \
-            or glu_u is not None or pre_add is not None or dact_z is not None or a_rowsum is not None:
+            or glu_u is not None or pre_add is not None or dact_z is not None or a_rowsum is not None or a2 is not None:
+        if a2 is not None and (a2.stride(0) != lda or b2.stride(0) != ldb):
+            raise ValueError("gemm: the second operand pair must have the row strides of A and B")
         ep = _l.GemmEpilogue(_p(bias), _p(aux_out), ACT[activation], _p(gate), _p(residual), ld_aux, ld_gate,
                              ld_residual, rows_per_batch, _p(glu_u), 0 if glu_u is None else glu_u.stride(0),
                              _p(pre_add), 0 if pre_add is None else pre_add.stride(0),
                              _p(dact_z), 0 if dact_z is None else dact_z.stride(0),
-                             _p(a_rowsum), int(bool(a_rowsum_accumulate)))
+                             _p(a_rowsum), int(bool(a_rowsum_accumulate)), _p(a2), _p(b2), int(k2), int(a2_group_n))
     timer = GEMM_TIMER
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -161,7 +165,7 @@ def gemm(a, b, out, *, a_t=False, b_t=False, M, N, K, lda=None, ldb=None, ldc=No
         e1.record()
         nbytes = 2.0 * (M * K + K * N + M * N * (1 + (residual is not None) + (aux_out is not None) +
                                                  3 * (glu_u is not None) + (dact_z is not None)))
-        timer.append((2.0 * M * N * K, e0, e1, ("nt"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
+        timer.append((2.0 * M * N * (K + k2), e0, e1, ("nt"[int(a_t)] + "nt"[int(b_t)], M, N, K, activation,
                       gate is not None, residual is not None, aux_out is not None), nbytes))
     _l.check(rc, "yat_gemm_bf16")
     return out
