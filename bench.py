@@ -306,6 +306,8 @@ def main():
                          "(train_sana.SanaModel.run) fed from synthetic shards on local disk -- a side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--lokr-pre-add", action="store_true",
+                    help="LoKr: adapter term as a GEMM of its own + the pre_add epilogue instead of the base GEMM's second operand pair")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the serialized GEMM-timing pass")
     ap.add_argument("--rccl-channels", type=int, default=-1, metavar="N",
@@ -387,7 +389,8 @@ def main():
     if args.lokr:
         from yat_amd.lokr import LoKrAdapters
         trained = LoKrAdapters(model, ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2",
-                                       "proj"], r=args.lokr, alpha=float(args.lokr), module_dropout=0.05)
+                                       "proj"], r=args.lokr, alpha=float(args.lokr), module_dropout=0.05,
+                               pair=not args.lokr_pre_add)
         log(f"LoKr rank {args.lokr}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
     elif args.lora:
         from yat_amd.lora import LoRAAdapters

@@ -271,6 +271,10 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
 /* the two row-streaming products of that path: backward=0: io[rows, R] = a[rows, N] w2_b^T;
  * backward=1: io[rows, N] = bf16(bf16(a[rows, R] w2_b) + io)   (w2_b: bf16 [R, N], R = 8 or 16, N <= 128, N % 8 == 0) */
 int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, yat_stream_t stream);
+/* the forward one with T1 laid out as the second operand of the base Linear's GEMM (yat_gemm_epilogue.a2): t1_flat[m, j R + q] =
+ * t1[m in_m + j, q], row stride ldt (= the row stride of x as the GEMM's A: [M, in]), rows = M in_m */
+int yat_lokr_rows_fwd_flat(int64_t rows, int N, int R, int in_m, const void* w2_b, const void* x, void* t1_flat, int ldt,
+                           yat_stream_t stream);
 /* nn.Dropout(p) on a LoRA adapter's input (peft lora/layer.py [RECALL]; LoraConfig(lora_dropout=...) at common/trainer.py:215):
  * keep(i) = hash(seed, i) >= p (counter-based, so the backward regenerates the mask); backward_add=0: io = bf16(x * keep / (1-p));
  * backward_add=1: io = bf16(io + bf16(x * keep / (1-p)))  (gradient through the same mask, accumulated into an input gradient) */

@@ -222,8 +222,11 @@ __global__ __launch_bounds__(256) void lokr_small_wgrad_final_kernel(int G, int 
 // 64/LPR-row runs.  FWD: 8 x R partial products per lane, butterfly over the row's lanes, lane c keeps q = c.  BWD: a lane
 // updates its own chunk, no exchange.  (v1 gave a lane a whole row: every 16-byte load of a wave touched 64 different rows;
 // 109 / 245 us per call against ~40 / ~65 us of traffic.)
+// FWD with im > 0: t1 is written as T1_flat [rows / im, im * R] with row stride ldt -- row (m, j) at io[m * ldt + j * R] -- so that
+// it can be handed to the base Linear's GEMM as its second operand (yat_gemm_epilogue.a2: K2 further columns with A's row stride).
 template <int R, int LPR, bool BWD>
-__global__ __launch_bounds__(256) void lokr_rows_kernel(int64_t rows, int N, const bf16_t* wb, const bf16_t* a, bf16_t* io) {
+__global__ __launch_bounds__(256) void lokr_rows_kernel(int64_t rows, int N, const bf16_t* wb, const bf16_t* a, bf16_t* io,
+                                                        int im = 0, int ldt = 0) {
     __shared__ float w[R][128];
     for (int e = threadIdx.x; e < R * 128; e += 256) w[e >> 7][e & 127] = (e & 127) < N ? bf2f(wb[(e >> 7) * N + (e & 127)]) : 0.f;
     __syncthreads();
@@ -244,7 +247,11 @@ __global__ __launch_bounds__(256) void lokr_rows_kernel(int64_t rows, int N, con
                 acc[q] = s;
             }
             // every lane of the row now holds all R sums; lane c < R/8 stores 8 of them as one 16-byte vector
-            if (c < R / 8) *reinterpret_cast<u32x4*>(io + row * R + c * 8) = pack8(acc + c * 8);
+            if (c < R / 8) {
+                bf16_t* dst = io + row * R;
+                if (im > 0) { const int64_t m = row / im; dst = io + m * ldt + (row - m * im) * R; }
+                *reinterpret_cast<u32x4*>(dst + c * 8) = pack8(acc + c * 8);
+            }
         } else if (live) {
             float h[R], o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8];
 #pragma unroll
@@ -441,7 +448,18 @@ int yat_lokr_project(int out_l, int out_k, int in_m, int in_n, int r, const void
     return YAT_OK;
 }
 
+static int lokr_rows_launch(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, int im, int ldt,
+                            yat_stream_t stream);
 int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, yat_stream_t stream) {
+    return lokr_rows_launch(rows, N, R, backward, w2_b, a, io, 0, 0, stream);
+}
+int yat_lokr_rows_fwd_flat(int64_t rows, int N, int R, int in_m, const void* w2_b, const void* x, void* t1_flat, int ldt,
+                           yat_stream_t stream) {
+    if (in_m <= 0 || rows % in_m || (ldt & 7) || ldt < in_m * R) return YAT_EINVAL;
+    return lokr_rows_launch(rows, N, R, 0, w2_b, x, t1_flat, in_m, ldt, stream);
+}
+static int lokr_rows_launch(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, int im, int ldt,
+                            yat_stream_t stream) {
     if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 7) || !w2_b || !a || !io) return YAT_EINVAL;
     const int lpr = N <= 64 ? 8 : 16;
     int64_t g64 = (rows + 256 / lpr - 1) / (256 / lpr);
@@ -450,7 +468,7 @@ int yat_lokr_rows(int64_t rows, int N, int R, int backward, const void* w2_b, co
     const bf16_t* ap = (const bf16_t*)a;
     bf16_t* iop = (bf16_t*)io;
     hipStream_t st = (hipStream_t)stream;
-#define YAT_ROWS(RR, LL, BB) hipLaunchKernelGGL((lokr_rows_kernel<RR, LL, BB>), grid, block, 0, st, rows, N, wb, ap, iop)
+#define YAT_ROWS(RR, LL, BB) hipLaunchKernelGGL((lokr_rows_kernel<RR, LL, BB>), grid, block, 0, st, rows, N, wb, ap, iop, im, ldt)
     if (R == 8 && lpr == 8) { if (backward) YAT_ROWS(8, 8, true); else YAT_ROWS(8, 8, false); }
     else if (R == 8) { if (backward) YAT_ROWS(8, 16, true); else YAT_ROWS(8, 16, false); }
     else if (lpr == 8) { if (backward) YAT_ROWS(16, 8, true); else YAT_ROWS(16, 8, false); }

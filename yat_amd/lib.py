@@ -86,6 +86,7 @@ SIGNATURES = {
     "yat_flow_mix": (I, [I, I64, P, P, P, P, P, P]),
     "yat_mse_fwd_bwd": (I, [I64, P, P, F, P, P, P, P]),
     "yat_lokr_rows": (I, [I64, I, I, I, P, P, P, P]),
+    "yat_lokr_rows_fwd_flat": (I, [I64, I, I, I, P, P, P, I, P]),
     "yat_dropout": (I, [I64, F, U64, I, P, P, P]),
     "yat_rank_expand": (I, [I64, I, I, P, P, P, I, F, I, P]),
     "yat_lokr_small_wgrad_workspace_bytes": (U64, [I64, I, I]),

@@ -62,14 +62,36 @@ def is_target(module_name: str, targets) -> bool:
     return any(module_name == t or module_name.endswith("." + t) for t in targets)
 
 
+def adapted_linear(ad, x, w, bias=None, out=None, **ep):
+    """Linear of a (possibly adapted) target, the ``lin`` hook of the models: base_layer(x) + adapter(x) (peft's wrap).  An
+    adapter set that can hand its term over as the GEMM's second operand pair (``forward_pair``: the factored LoKr targets)
+    costs one launch; otherwise the term is computed first and folded in through the ``pre_add`` epilogue."""
+    if ad is None:
+        return ops.linear_fwd(x, w, bias, out=out, **ep)
+    pair = ad.forward_pair(x, w) if hasattr(ad, "forward_pair") else None
+    if pair == "plain":
+        return ops.linear_fwd(x, w, bias, out=out, **ep)
+    if pair is not None:
+        a2, b2, k2, group = pair
+        return ops.linear_fwd(x, w, bias, out=out, a2=a2, b2=b2, k2=k2, a2_group_n=group, **ep)
+    tmp = ad.forward_term(x, w)                                   # None: no adapter on this weight
+    if tmp is None:
+        return ops.linear_fwd(x, w, bias, out=out, **ep)
+    return ops.linear_fwd(x, w, bias, out=out, pre_add=tmp, **ep)
+
+
 class LoKrAdapters:
-    def __init__(self, model, targets, r: int, alpha: float, module_dropout: float = 0.0, mode: str | None = None):
+    def __init__(self, model, targets, r: int, alpha: float, module_dropout: float = 0.0, mode: str | None = None,
+                 pair: bool = True):
         self.model, self.r, self.alpha, self.scale = model, int(r), float(alpha), float(alpha) / int(r)
         self.targets, self.module_dropout = list(targets), float(module_dropout)
         self.mode = mode or "factored"
         if self.mode not in ("factored", "dense"):
             raise ValueError(f"LoKr mode {self.mode!r}")
         self.R = (self.r + 7) // 8 * 8                      # rank padded to 16-byte rows (zero columns / rows)
+        # factored targets in the forward: T1_flat P^T as the SECOND OPERAND PAIR of the base Linear's GEMM (one launch, no
+        # [M, out] addend) instead of a GEMM of its own + the pre_add epilogue; see forward_pair()
+        self.pair = bool(pair) and self.mode == "factored"
         dev = model.flat_param.device
         self.entries, off, segs = [], 0, [0]
 
@@ -118,11 +140,21 @@ class LoKrAdapters:
         if fact:
             # P = kron(w1, w2_a) * scale and its gradient, [out, in_m*R] per factored target, each in one flat buffer
             sizes = [e["out"] * e["in_m"] * R for e in fact]
-            flatP = torch.zeros(sum(sizes), dtype=BF16, device=dev)
+            # P lives in a zero-filled shadow of the model's flat weights: target t's P = the first in_m*R columns of the rows of
+            # W_t, with W_t's row stride -- what the GEMM's second operand pair wants (B2 with B's row stride; the fused q|k|v
+            # view of the weights has its stacked P at the same place), the columns up to the next multiple of 64 stay zero
+            self.pair = self.pair and all(e["in_m"] * R <= e["inn"] for e in fact)
+            flatP = torch.zeros_like(model.flat_param) if self.pair else torch.zeros(sum(sizes), dtype=BF16, device=dev)
+            self._flatP = flatP
             flatdP = torch.zeros(sum(sizes), dtype=BF16, device=dev)
             o = 0
             for e, n in zip(fact, sizes):
-                e["P"], e["dP"] = flatP[o:o + n].view(e["out"], e["in_m"] * R), flatdP[o:o + n].view(e["out"], e["in_m"] * R)
+                k2 = e["in_m"] * R
+                if self.pair:
+                    e["P"] = flatP[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])[:, :k2]
+                else:
+                    e["P"] = flatP[o:o + n].view(e["out"], k2)
+                e["dP"] = flatdP[o:o + n].view(e["out"], k2)
                 o += n
                 if R != self.r:                             # zero-padded copies of w2_a / w2_b and their gradients
                     e["wa_pad"] = torch.zeros(e["out_k"], R, dtype=BF16, device=dev)
@@ -134,6 +166,7 @@ class LoKrAdapters:
                  for e in self.entries)
         self._ws = torch.empty(int(ws), dtype=torch.uint8, device=dev)
         self._lookup = {}
+        self._slabs, self._slab_next = {}, {}          # T1 slabs of forward_pair(): in -> [buffers [rows, in]], next free column
         self.reset_parameters()
         model.adapters = self
 
@@ -186,11 +219,58 @@ class LoKrAdapters:
             else:
                 im, n_ = e["in_m"], e["in_n"]
                 t1 = ops.lokr_rows_fwd(x.view(M * im, n_), self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
-                ops.gemm(t1.view(M, im * R), e["P"], blk, M=M, N=e["out"], K=im * R, ldc=rows)
+                ops.gemm(t1.view(M, im * R), e["P"], blk, M=M, N=e["out"], K=im * R, ldb=e["P"].stride(0), ldc=rows)
                 # kept for the weight gradient (same x): the reference lives until the next forward replaces it, i.e.
                 # past every stream that reads it in the backward (which the main stream joins before the optimizer)
-                e["t1"] = (x.data_ptr(), t1)
+                e["t1"] = (x.data_ptr(), t1.view(M, im * R))
         return tmp
+
+    def _t1_slot(self, M, K, width):
+        """``width`` columns of a [rows >= M, K] slab for this step's T1 products (row stride K = the row stride of the x they
+        are computed from); slabs are kept from step to step and handed out in call order."""
+        slabs = self._slabs.setdefault(K, [])
+        i, col = self._slab_next.get(K, (0, 0))
+        if col + width > K:
+            i, col = i + 1, 0
+        if i == len(slabs) or slabs[i].shape[0] < M:
+            buf = torch.zeros(M, K, dtype=BF16, device=self.flat_param.device)
+            if i == len(slabs):
+                slabs.append(buf)
+            else:
+                slabs[i] = buf                                  # (a larger batch than any before: this step's earlier slots
+        self._slab_next[K] = (i, col + width)                   #  live in the old buffer, which their views keep alive)
+        return slabs[i][:M, col:col + width]
+
+    def forward_pair(self, x, w):
+        """The adapter term of target view ``w`` as the second operand pair of the base GEMM: (a2 [M, n k2] with x's row
+        stride, b2 [rows(w), k2] with w's, k2, columns of the output per block of a2) -- or None when the view has no adapter,
+        when every one of its adapters is dropped this step ("plain"), or when this form does not apply (then
+        forward_term()).  T1 = x' w2_b^T of each entry is written straight into its columns of a slab; a dropped entry of a
+        fused view gets zeros there.  The sum base + adapter is rounded ONCE (peft rounds the two terms and their sum)."""
+        ents = self.lookup(w, self.model.flat_param)
+        if not ents:
+            return None
+        if not any(e["active"] for e, _ in ents):
+            return "plain"
+        M, K, R = x.shape[0], x.shape[1], self.R
+        e0 = ents[0][0]
+        kr = e0["in_m"] * R
+        k2 = (kr + 63) // 64 * 64
+        if not self.pair or not x.is_contiguous() or w.stride(0) != K or w.shape[0] != sum(e["out"] for e, _ in ents) \
+                or any(not e["factored"] or e["in_m"] * R != kr or e["inn"] != K or e["out"] != e0["out"] for e, _ in ents) \
+                or len(ents) * k2 > K or (len(ents) > 1 and e0["out"] % 320 and e0["out"] % 256):
+            return None
+        a2 = self._t1_slot(M, K, len(ents) * k2)
+        for j, (e, row0) in enumerate(ents):
+            assert row0 == j * e0["out"]
+            t1 = a2[:, j * k2:j * k2 + kr]
+            if e["active"]:
+                ops.lokr_rows_fwd_flat(x.view(M * e["in_m"], e["in_n"]), self._w2(e)[1], t1, e["in_m"])
+                e["t1"] = (x.data_ptr(), t1)                    # kept for the weight gradient, as in forward_term()
+            else:
+                t1.zero_()
+        b2 = self._flatP[(w.data_ptr() - self.model.flat_param.data_ptr()) // 2:][:w.shape[0] * K].view(w.shape[0], K)[:, :k2]
+        return a2, b2, k2, (e0["out"] if len(ents) > 1 else 0)
 
     def dgrad_term(self, dy, w, dx):
         """dx += dy delta_w for the target view ``w`` (dy [M, rows(w)], dx [M, in] contiguous).  Returns {id(entry): H}
@@ -213,7 +293,7 @@ class LoKrAdapters:
                 continue
             im, n_ = e["in_m"], e["in_n"]
             h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
-            ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
+            ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=e["P"].stride(0), ldc=im * R)
             ops.lokr_rows_bwd(h.view(M * im, R), self._w2(e)[1], dx.view(M * im, n_))
             hs[id(e)] = h
         return hs
@@ -241,16 +321,16 @@ class LoKrAdapters:
             im, n_ = e["in_m"], e["in_n"]
             x2 = x.view(M * im, n_)
             kept = e.get("t1")
-            if kept is not None and kept[0] == x.data_ptr() and kept[1].shape[0] == M * im:
-                t1 = kept[1]                                 # T1 of this very x, computed by the forward
-            else:
-                t1 = ops.lokr_rows_fwd(x2, self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device))
-            ops.gemm(dyb, t1.view(M, im * R), e["dP"], a_t=True, b_t=True, M=e["out"], N=im * R, K=M, lda=ld, ldb=im * R,
+            if kept is not None and kept[0] == x.data_ptr() and kept[1].shape[0] == M:
+                t1 = kept[1]                                 # T1_flat [M, in_m R] of this very x, computed by the forward
+            else:                                            # (a view with a row stride when it sits in a forward_pair() slab)
+                t1 = ops.lokr_rows_fwd(x2, self._w2(e)[1], torch.empty(M * im, R, dtype=BF16, device=x.device)).view(M, im * R)
+            ops.gemm(dyb, t1, e["dP"], a_t=True, b_t=True, M=e["out"], N=im * R, K=M, lda=ld, ldb=t1.stride(0),
                      ldc=im * R, residual=e["dP"] if accumulate else None)
             h = hs.get(id(e)) if hs else None
             if h is None:
                 h = torch.empty(M, im * R, dtype=BF16, device=dy.device)
-                ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=im * R, ldc=im * R)
+                ops.gemm(dyb, e["P"], h, b_t=True, M=M, N=im * R, K=e["out"], lda=ld, ldb=e["P"].stride(0), ldc=im * R)
             else:
                 h.record_stream(torch.cuda.current_stream())     # produced on the chain's stream, read on this one
             _, _, gb = self._views(e, self.flat_grad)
@@ -277,6 +357,7 @@ class LoKrAdapters:
     def materialize(self, training=True):
         """Rebuild every delta_w from the current adapter parameters (zeros where module dropout drops the adapter)."""
         self.join_pending_update()
+        self._slab_next = {}                # this step's T1 products take the slab columns from the start again
         first_micro = not getattr(self.model, "accumulate_grads", False)
         for e in self.entries:
             if first_micro:

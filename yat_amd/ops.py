@@ -329,6 +329,20 @@ def lokr_rows_fwd(x2d, wb, t1):
     return t1
 
 
+def lokr_rows_fwd_flat(x2d, wb, t1_flat, in_m):
+    """t1_flat[m, j R + q] = (x2d wb^T)[m in_m + j, q]: T1 of the factored LoKr path written as [M, in_m R] columns of a
+    row-strided view -- the layout the base GEMM takes as its second operand (``gemm(..., a2=t1_flat)``)."""
+    _chk_bf16(x2d, wb, t1_flat)
+    rows, N = x2d.shape
+    R = wb.shape[0]
+    if wb.shape[1] != N or rows % in_m or t1_flat.shape != (rows // in_m, in_m * R) or t1_flat.stride(1) != 1 \
+            or not (x2d.is_contiguous() and wb.is_contiguous()):
+        raise ValueError("lokr_rows_fwd_flat: shape mismatch")
+    _l.check(_lib().yat_lokr_rows_fwd_flat(rows, N, R, in_m, _p(wb), _p(x2d), _p(t1_flat), t1_flat.stride(0), _stream()),
+             "yat_lokr_rows_fwd_flat")
+    return t1_flat
+
+
 def lokr_rows_bwd(h2d, wb, dx2d):
     """dx2d[rows, N] += h2d[rows, R] wb (product rounded to bf16 first, like a GEMM's residual epilogue)."""
     _chk_bf16(h2d, wb, dx2d)

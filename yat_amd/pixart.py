@@ -29,6 +29,7 @@ import torch
 
 from . import ops
 from .flat import FlatParamModule, schedule
+from .lokr import adapted_linear
 
 BF16 = torch.bfloat16
 
@@ -257,10 +258,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
 
         def lin(x_, w_, bias_=None, out=None, **ep):
             """Linear of a (possibly adapted) target: the adapter term is folded in through the GEMM's pre_add epilogue."""
-            tmp = ad.forward_term(x_, w_) if ad is not None else None
-            if tmp is None:
-                return ops.linear_fwd(x_, w_, bias_, out=out, **ep)
-            return ops.linear_fwd(x_, w_, bias_, out=out, pre_add=tmp, **ep)
+            return adapted_linear(ad, x_, w_, bias_, out=out, **ep)
 
         def params_ready(bucket, stream=main):
             if pev is not None:

@@ -38,6 +38,7 @@ import torch.nn as nn
 
 from . import ops
 from .flat import FlatParamModule, schedule
+from .lokr import adapted_linear
 
 BF16 = torch.bfloat16
 
@@ -290,10 +291,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         def lin(x_, w_, bias_=None, out=None, **ep):
             """Linear of a (possibly adapted) target: with adapters, x delta_w^T is computed first and folded into the
             base GEMM right after its bias rounding (peft: base_layer(x) + F.linear(x, delta_w))."""
-            tmp = ad.forward_term(x_, w_) if ad is not None else None       # None: no adapter on this weight
-            if tmp is None:
-                return ops.linear_fwd(x_, w_, bias_, out=out, **ep)
-            return ops.linear_fwd(x_, w_, bias_, out=out, pre_add=tmp, **ep)
+            return adapted_linear(ad, x_, w_, bias_, out=out, **ep)
 
         def params_ready(bucket, stream=main):
             if pev is not None:
