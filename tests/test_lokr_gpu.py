@@ -99,6 +99,87 @@ def test_lokr_rows_products(rows, R, N):
     assert ((dx.double() - want).abs() <= 2.0 ** -7 * want.abs() + 2.0 ** -8 * (h.double().abs() @ wb.double().abs()) + 1e-6).all()
 
 
+def test_lokr_rows_fwd_flat_layout():
+    """yat_lokr_rows_fwd_flat: T1 written as [M, in_m R] columns of a row-strided view = the reshaped contiguous product, bit for
+    bit; nothing outside those columns is touched."""
+    from yat_amd import ops
+    M, im, n_, R, ld = 300, 20, 32, 8, 640
+    g = torch.Generator().manual_seed(3)
+    x, wb = torch.randn(M * im, n_, generator=g).to(BF).to(DEV), (torch.randn(R, n_, generator=g) * 0.3).to(BF).to(DEV)
+    t1 = ops.lokr_rows_fwd(x, wb, torch.empty(M * im, R, dtype=BF, device=DEV))
+    slab = torch.full((M, ld), 7.0, dtype=BF, device=DEV)
+    ops.lokr_rows_fwd_flat(x, wb, slab[:, 192:192 + im * R], im)
+    assert torch.equal(slab[:, 192:192 + im * R], t1.view(M, im * R))
+    assert (slab[:, :192] == 7).all() and (slab[:, 192 + im * R:] == 7).all()
+
+
+def test_lokr_forward_pair_matches_the_pre_add_path():
+    """The factored adapter term as the base GEMM's second operand pair (LoKrAdapters.forward_pair, the default) against the
+    same term through a GEMM of its own + the pre_add epilogue (pair=False) and against fp32: a fused q|k|v view with one
+    adapter per block, a single target, a dropped block inside the fused view, a fully dropped target; then the weight
+    gradients from the T1 kept in the slab."""
+    from types import SimpleNamespace
+    from yat_amd import ops
+    from yat_amd.lokr import LoKrAdapters, adapted_linear
+    D, M = 640, 520
+    g = torch.Generator().manual_seed(11)
+    names = ["blk.to_q", "blk.to_k", "blk.to_v", "blk.to_out.0"]
+
+    def make(pair):
+        flat = (torch.randn(4 * D * D, generator=torch.Generator().manual_seed(5)) * D ** -0.5).to(BF).to(DEV)
+        model = SimpleNamespace(P={n + ".weight": flat[i * D * D:(i + 1) * D * D].view(D, D) for i, n in enumerate(names)},
+                                flat_param=flat, flat_grad=torch.zeros_like(flat))
+        ad = LoKrAdapters(model, ["to_q", "to_k", "to_v", "to_out.0"], r=8, alpha=8.0, pair=pair)
+        assert all(e["factored"] for e in ad.entries) and ad.pair == pair
+        return model, ad
+    (m1, a1), (m2, a2) = make(True), make(False)
+    a2.flat_param.copy_(a1.flat_param)
+    for e in a1.entries:
+        w1 = a1._views(e, a1.flat_param)[0]
+        w1.copy_((torch.randn(w1.shape, generator=g) * 0.2).to(BF))
+    a2.flat_param.copy_(a1.flat_param)
+    x, bias = torch.randn(M, D, generator=g).to(BF).to(DEV), torch.randn(3 * D, generator=g).to(BF).to(DEV)
+    e0 = a1.entries[0]
+    assert e0["in_m"] * a1.R <= D and (e0["in_m"] * a1.R) % 64 != 0          # exercises the zero columns up to the next tile
+
+    def truth(model, ad, lo, hi, drop=()):
+        W = model.flat_param[lo * D * D:hi * D * D].view((hi - lo) * D, D).float()
+        dW = torch.zeros_like(W)
+        for j, e in enumerate(ad.entries[lo:hi]):
+            if e["module"] in drop:
+                continue
+            w1, wa, wb = (t.float() for t in ad._views(e, ad.flat_param))
+            dW[j * D:(j + 1) * D] = torch.kron(w1, wa @ wb) * ad.scale
+        return x.float() @ (W + dW).T
+
+    def rel(a, b):
+        return ((a.float() - b.float()).norm() / b.float().norm()).item()
+    for drop in ((), ("blk.to_k",), ("blk.to_out.0",)):
+        for ad in (a1, a2):
+            ad.active_override = (lambda name, drop=drop: name not in drop)
+            ad.materialize(True)
+        qkv1, qkv2 = (m.flat_param[:3 * D * D].view(3 * D, D) for m in (m1, m2))
+        y1 = adapted_linear(a1, x, qkv1, bias)
+        y2 = adapted_linear(a2, x, qkv2, bias)
+        t = truth(m1, a1, 0, 3, drop) + bias.float()
+        assert rel(y1, t) <= rel(y2, t) * 1.05 + 1e-4 and rel(y1, t) < 4e-3, (drop, rel(y1, t), rel(y2, t))
+        o1 = adapted_linear(a1, x, m1.P["blk.to_out.0.weight"])
+        o2 = adapted_linear(a2, x, m2.P["blk.to_out.0.weight"])
+        t = truth(m1, a1, 3, 4, drop)
+        assert rel(o1, t) <= rel(o2, t) * 1.05 + 1e-4 and rel(o1, t) < 4e-3
+        if "blk.to_out.0" in drop:                           # every adapter of the view dropped: the plain base Linear, bit for bit
+            assert torch.equal(o1, ops.linear_fwd(x, m1.P["blk.to_out.0.weight"]))
+        # weight gradients: d_P from the T1 the forward left in its slab columns == from a freshly computed one
+        dy = torch.randn(M, 3 * D, generator=g).to(BF).to(DEV)
+        for m, ad in ((m1, a1), (m2, a2)):
+            ad.wgrad(dy, x, m.flat_grad[:3 * D * D].view(3 * D, D))
+        torch.cuda.synchronize()
+        for ea, eb in zip(a1.entries[:3], a2.entries[:3]):
+            if ea["module"] not in drop:
+                assert torch.equal(ea["dP"], eb["dP"]), ea["module"]
+        assert torch.equal(a1.flat_grad, a2.flat_grad)
+
+
 @pytest.mark.parametrize("mode", ["factored", "dense"])
 def test_lokr_training_step_matches_oracle(mode):
     """One adapted training step (tiny SANA, non-zero w1 so the adapters matter): loss / prediction / adapter gradients
