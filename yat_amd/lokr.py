@@ -162,9 +162,14 @@ class LoKrAdapters:
                     e["ga_pad"] = torch.zeros(e["out_k"], R, dtype=BF16, device=dev)
             self._eye = torch.eye(R, dtype=BF16, device=dev)
             self._gb_dummy = torch.empty(R, R, dtype=BF16, device=dev)
-        ws = max(ops._lib().yat_lokr_project_workspace_bytes(e["out_l"], e["out_k"], R if e["factored"] else e["in_n"])
-                 for e in self.entries)
-        self._ws = torch.empty(int(ws), dtype=torch.uint8, device=dev)
+        # projection workspaces, one per entry: an entry is projected right behind its weight gradient, on whatever stream
+        # that runs (wgrad()), so two entries may be in flight at once
+        sizes = [(int(ops._lib().yat_lokr_project_workspace_bytes(e["out_l"], e["out_k"], R if e["factored"] else e["in_n"]))
+                  + 255) & ~255 for e in self.entries]
+        ws_all = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+        o = 0
+        for e, n in zip(self.entries, sizes):
+            e["ws"], o = ws_all[o:o + n], o + n
         self._lookup = {}
         self._slabs, self._slab_next = {}, {}          # T1 slabs of forward_pair(): in -> [buffers [rows, in]], next free column
         self.reset_parameters()
@@ -317,6 +322,7 @@ class LoKrAdapters:
                 g = self.model.flat_grad[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
                 ops.gemm(dyb, x, g, a_t=True, b_t=True, M=e["out"], N=e["inn"], K=M, lda=ld, ldb=e["inn"], ldc=e["inn"],
                          residual=g if accumulate else None)
+                self._project_entry(e)
                 continue
             im, n_ = e["in_m"], e["in_n"]
             x2 = x.view(M * im, n_)
@@ -335,6 +341,9 @@ class LoKrAdapters:
                 h.record_stream(torch.cuda.current_stream())     # produced on the chain's stream, read on this one
             _, _, gb = self._views(e, self.flat_grad)
             ops.lokr_small_wgrad(h.view(M * im, R), x2, gb, accumulate=accumulate)
+            # d_P is complete: project it here, on the weight-gradient stream beside the chain's GEMMs -- at the end of the
+            # backward the ~200 x 3 small launches of project() were a serial tail (~10 ms at B = 32) with the chip idle
+            self._project_entry(e)
 
     def reset_parameters(self):
         """peft init_weights=True: w1 zeros, w2_a / w2_b kaiming_uniform(a=sqrt(5)) drawn on the CPU, then cast."""
@@ -360,6 +369,7 @@ class LoKrAdapters:
         self._slab_next = {}                # this step's T1 products take the slab columns from the start again
         first_micro = not getattr(self.model, "accumulate_grads", False)
         for e in self.entries:
+            e["projected"] = False
             if first_micro:
                 e["has_grad"] = False       # a new accumulation window: nothing has contributed yet
             e["active"] = (not training) or self.module_dropout <= 0.0 or bool(torch.rand(1) > self.module_dropout)
@@ -380,8 +390,8 @@ class LoKrAdapters:
                 d2.zero_()
 
     def project(self):
-        """d_delta_w (the model's flat gradient slots of the frozen target weights) -> adapter gradients."""
-        G = self.model.flat_grad
+        """d_delta_w (the model's flat gradient slots of the frozen target weights) -> adapter gradients: whatever wgrad() has
+        not projected already, the zeros of dropped entries, then the data-parallel hook."""
         for e in self.entries:
             g1, ga, gb = self._views(e, self.flat_grad)
             if not e["active"]:
@@ -391,18 +401,26 @@ class LoKrAdapters:
                 if not e["has_grad"]:
                     g1.zero_(); ga.zero_(); gb.zero_()
                 continue
-            w1, wa, wb = self._views(e, self.flat_param)
-            if e["factored"]:
-                # d_P -> (d_w1, d_w2_a) by the autograd of kron(w1, w2_a) * scale; d_w2_b was written by wgrad()
-                ga_r = ga if self.R == self.r else e["ga_pad"]
-                ops.lokr_project(w1, self._w2(e)[0], self._eye, self.scale, e["dP"], g1, ga_r, self._gb_dummy, self._ws)
-                if ga_r is not ga:
-                    ga.copy_(ga_r[:, :self.r])
-                continue
-            dd = G[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
-            ops.lokr_project(w1, wa, wb, self.scale, dd, g1, ga, gb, self._ws)
+            if not e.get("projected"):      # (wgrad() projects an entry right behind its weight gradient)
+                self._project_entry(e)
         if self.grad_ready is not None:
             self.grad_ready(0)
+
+    def _project_entry(self, e):
+        """Entry e's d_P (factored) / d_delta_w (dense) -> (d_w1, d_w2_a[, d_w2_b]) on the current stream.  Idempotent: under
+        gradient accumulation d_P holds the window's sum so far and every micro-step rewrites the projections from it."""
+        g1, ga, gb = self._views(e, self.flat_grad)
+        w1, wa, wb = self._views(e, self.flat_param)
+        if e["factored"]:
+            # d_P -> (d_w1, d_w2_a) by the autograd of kron(w1, w2_a) * scale; d_w2_b was written by wgrad()
+            ga_r = ga if self.R == self.r else e["ga_pad"]
+            ops.lokr_project(w1, self._w2(e)[0], self._eye, self.scale, e["dP"], g1, ga_r, self._gb_dummy, e["ws"])
+            if ga_r is not ga:
+                ga.copy_(ga_r[:, :self.r])
+        else:
+            dd = self.model.flat_grad[e["w_off"]:e["w_off"] + e["out"] * e["inn"]].view(e["out"], e["inn"])
+            ops.lokr_project(w1, wa, wb, self.scale, dd, g1, ga, gb, e["ws"])
+        e["projected"] = True
 
     def update_ranges(self):
         """Parameter ranges the optimizer step must touch, with each range's own step count: [(lo, hi, step)].  peft leaves
