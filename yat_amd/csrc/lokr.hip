@@ -216,58 +216,86 @@ __global__ __launch_bounds__(256) void lokr_small_wgrad_final_kernel(int G, int 
 // The two row-streaming products of the factored path, rows = M*in_m (a million at B = 32), N = in_n <= 128, R <= 16:
 //   FWD: t1[row, q]  = bf16( sum_n x[row, n] * wb[q, n] )                       (T1 = x' w2_b^T)
 //   BWD: dx[row, n]  = bf16( bf16( sum_q h[row, q] * wb[q, n] ) + dx[row, n] )  (dx' += H' w2_b, the GEMM's residual rounding)
-// A tiled GEMM spends a 128-wide tile on the 8 useful columns (measured 124 / 202 us per call); here w2_b sits in LDS as
-// fp32, read by broadcast, and the pass is HBM-bound (168 / 315 MB at D = 2240, B = 32).
-// LPR lanes share a row, each owning one 16-byte chunk of it (chunks past N idle): a wave's accesses are contiguous
-// 64/LPR-row runs.  FWD: 8 x R partial products per lane, butterfly over the row's lanes, lane c keeps q = c.  BWD: a lane
-// updates its own chunk, no exchange.  (v1 gave a lane a whole row: every 16-byte load of a wave touched 64 different rows;
-// 109 / 245 us per call against ~40 / ~65 us of traffic.)
-// FWD with im > 0: t1 is written as T1_flat [rows / im, im * R] with row stride ldt -- row (m, j) at io[m * ldt + j * R] -- so that
-// it can be handed to the base Linear's GEMM as its second operand (yat_gemm_epilogue.a2: K2 further columns with A's row stride).
-template <int R, int LPR, bool BWD>
-__global__ __launch_bounds__(256) void lokr_rows_kernel(int64_t rows, int N, const bf16_t* wb, const bf16_t* a, bf16_t* io,
-                                                        int im = 0, int ldt = 0) {
+// A tiled GEMM spends a 128-wide tile on the 8 useful columns (measured 124 / 202 us per call); both are HBM-bound passes
+// (168 / 315 MB at D = 2240, B = 32).
+//
+// FWD on the matrix cores (round 5): a wave takes 16 rows per step; x' is k-contiguous, so a lane's operand fragment of
+// v_mfma_f32_16x16x32_bf16 -- 8 consecutive columns of one row -- is one 16-byte global load, w2_b's fragments (q = lane & 15,
+// zero rows past R) sit in registers for the whole kernel, and with w2_b as the first operand a lane ends up with 4
+// consecutive q of ONE row: an 8-byte store, 16 bytes per row from two lanes.  No LDS, no cross-lane step; four row tiles of
+// loads are in flight per wave.  (v2 -- 8 lanes per row, 64 scalar FMAs + 24 shuffles per 16 bytes loaded, w2_b broadcast from
+// LDS -- was bound by vector issue: 48.8 us for the 168 MB of a D = 2240 target at B = 32 against 27 us of traffic.)
+// With im > 0 the result is written as T1_flat [rows / im, im * R] with row stride ldt -- row (m, j) at io[m * ldt + j * R] -- so
+// that it can be handed to the base Linear's GEMM as its second operand (yat_gemm_epilogue.a2: K2 further columns with A's stride).
+template <int KS>                                              // k-steps of 32 columns: N <= 32 KS
+__global__ __launch_bounds__(256) void lokr_rows_fwd_kernel(int64_t rows, int N, int R, const bf16_t* wb, const bf16_t* x,
+                                                            bf16_t* io, int im, int ldt) {
+    constexpr int U = 4;                                       // row tiles per wave step
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    bf16x8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
+    bf16x8 wf[KS];
+    bool live[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = 32 * ks + 8 * g;
+        live[ks] = c < N;
+        wf[ks] = (li < R && live[ks]) ? *reinterpret_cast<const bf16x8*>(wb + li * N + c) : zero;
+    }
+    const int64_t tiles = (rows + 15) >> 4;
+    for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * U; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * U) {
+        bf16x8 xf[U][KS];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = (t0 + u) * 16 + li;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                xf[u][ks] = (row < rows && live[ks]) ? *reinterpret_cast<const bf16x8*>(x + row * N + 32 * ks + 8 * g) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = mfma16(wf[ks], xf[u][ks], acc);      // acc[r] = t1[row][q = 4 g + r]
+            const int64_t row = (t0 + u) * 16 + li;
+            if (row < rows && 4 * g < R) {
+                bf16_t* dst = io + row * R;
+                if (im > 0) { const int64_t m = row / im; dst = io + m * ldt + (row - m * im) * R; }
+                *reinterpret_cast<u32x2*>(dst + 4 * g) = pack4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+    }
+}
+
+// BWD: dx' is rows of N / 8 16-byte chunks back to back, so the pass is one linear stream of chunks -- thread i of a step owns chunk
+// i (row = i / (N / 8), no idle lanes whatever N / 8 is), reads its row's h (16 or 32 bytes, the same for the row's threads), forms
+// its 8 columns from w2_b in LDS (fp32, per-chunk columns) and updates the chunk in place, no exchange.  (v1 gave a lane a whole
+// row: every 16-byte load of a wave touched 64 different rows, 245 us per call against ~65 us of traffic; v2 padded a row to 8 or
+// 16 lanes: 6 of 16 idle at in_n = 80, 3.2 TB/s.)
+template <int R>
+__global__ __launch_bounds__(256) void lokr_rows_bwd_kernel(uint32_t chunks, int N, const bf16_t* wb, const bf16_t* a, bf16_t* io) {
     __shared__ float w[R][128];
     for (int e = threadIdx.x; e < R * 128; e += 256) w[e >> 7][e & 127] = (e & 127) < N ? bf2f(wb[(e >> 7) * N + (e & 127)]) : 0.f;
     __syncthreads();
-    constexpr int RPB = 256 / LPR;                             // rows per workgroup pass
-    const int c = threadIdx.x % LPR, n = c * 8;
-    const bool live = n < N;
-    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; row < rows; row += (int64_t)gridDim.x * RPB) {
-        if (!BWD) {
-            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc[R];
-            if (live) unpack8(*reinterpret_cast<const u32x4*>(a + row * N + n), x);
+    const uint32_t cpr = (uint32_t)N >> 3;                     // chunks per row
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < chunks; i += gridDim.x * 256u) {
+        const uint32_t row = i / cpr, n = (i - row * cpr) * 8;
+        float h[R], o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(&w[q][n]), hi = *reinterpret_cast<const f32x4*>(&w[q][n + 4]);
-                float s = x[0] * lo[0] + x[1] * lo[1] + x[2] * lo[2] + x[3] * lo[3] + x[4] * hi[0] + x[5] * hi[1] + x[6] * hi[2] +
-                          x[7] * hi[3];
+        for (int v = 0; v < R / 8; ++v) unpack8(*reinterpret_cast<const u32x4*>(a + (int64_t)row * R + v * 8), h + v * 8);
 #pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
-                acc[q] = s;
-            }
-            // every lane of the row now holds all R sums; lane c < R/8 stores 8 of them as one 16-byte vector
-            if (c < R / 8) {
-                bf16_t* dst = io + row * R;
-                if (im > 0) { const int64_t m = row / im; dst = io + m * ldt + (row - m * im) * R; }
-                *reinterpret_cast<u32x4*>(dst + c * 8) = pack8(acc + c * 8);
-            }
-        } else if (live) {
-            float h[R], o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8];
-#pragma unroll
-            for (int v = 0; v < R / 8; ++v) unpack8(*reinterpret_cast<const u32x4*>(a + row * R + v * 8), h + v * 8);
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(&w[q][n]), hi = *reinterpret_cast<const f32x4*>(&w[q][n + 4]);
-                o[0] += h[q] * lo[0]; o[1] += h[q] * lo[1]; o[2] += h[q] * lo[2]; o[3] += h[q] * lo[3];
-                o[4] += h[q] * hi[0]; o[5] += h[q] * hi[1]; o[6] += h[q] * hi[2]; o[7] += h[q] * hi[3];
-            }
-            bf16_t* dp = io + row * N + n;
-            unpack8(*reinterpret_cast<const u32x4*>(dp), d);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) + d[e];
-            *reinterpret_cast<u32x4*>(dp) = pack8(o);
+        for (int q = 0; q < R; ++q) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&w[q][n]), hi = *reinterpret_cast<const f32x4*>(&w[q][n + 4]);
+            o[0] += h[q] * lo[0]; o[1] += h[q] * lo[1]; o[2] += h[q] * lo[2]; o[3] += h[q] * lo[3];
+            o[4] += h[q] * hi[0]; o[5] += h[q] * hi[1]; o[6] += h[q] * hi[2]; o[7] += h[q] * hi[3];
         }
+        bf16_t* dp = io + (int64_t)i * 8;
+        unpack8(*reinterpret_cast<const u32x4*>(dp), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]) + d[e];
+        *reinterpret_cast<u32x4*>(dp) = pack8(o);
     }
 }
 
@@ -461,19 +489,26 @@ int yat_lokr_rows_fwd_flat(int64_t rows, int N, int R, int in_m, const void* w2_
 static int lokr_rows_launch(int64_t rows, int N, int R, int backward, const void* w2_b, const void* a, void* io, int im, int ldt,
                             yat_stream_t stream) {
     if (rows <= 0 || (R != 8 && R != 16) || N <= 0 || N > 128 || (N & 7) || !w2_b || !a || !io) return YAT_EINVAL;
-    const int lpr = N <= 64 ? 8 : 16;
-    int64_t g64 = (rows + 256 / lpr - 1) / (256 / lpr);
-    const dim3 grid((unsigned)(g64 > 4096 ? 4096 : g64)), block(256);
     const bf16_t* wb = (const bf16_t*)w2_b;
     const bf16_t* ap = (const bf16_t*)a;
     bf16_t* iop = (bf16_t*)io;
     hipStream_t st = (hipStream_t)stream;
-#define YAT_ROWS(RR, LL, BB) hipLaunchKernelGGL((lokr_rows_kernel<RR, LL, BB>), grid, block, 0, st, rows, N, wb, ap, iop, im, ldt)
-    if (R == 8 && lpr == 8) { if (backward) YAT_ROWS(8, 8, true); else YAT_ROWS(8, 8, false); }
-    else if (R == 8) { if (backward) YAT_ROWS(8, 16, true); else YAT_ROWS(8, 16, false); }
-    else if (lpr == 8) { if (backward) YAT_ROWS(16, 8, true); else YAT_ROWS(16, 8, false); }
-    else { if (backward) YAT_ROWS(16, 16, true); else YAT_ROWS(16, 16, false); }
-#undef YAT_ROWS
+    const dim3 block(256);
+    if (!backward) {
+        const int64_t g64 = ((rows + 15) / 16 + 15) / 16;                   // 4 waves x 4 row tiles per workgroup step
+        const dim3 grid((unsigned)(g64 > 8192 ? 8192 : g64));
+#define YAT_FWD(KS) hipLaunchKernelGGL((lokr_rows_fwd_kernel<KS>), grid, block, 0, st, rows, N, R, wb, ap, iop, im, ldt)
+        if (N <= 32) YAT_FWD(1); else if (N <= 64) YAT_FWD(2); else if (N <= 96) YAT_FWD(3); else YAT_FWD(4);
+#undef YAT_FWD
+        YAT_CHECK_LAUNCH();
+        return YAT_OK;
+    }
+    const int64_t chunks = rows * (N >> 3);
+    if (chunks > 0xffffffffll) return YAT_EINVAL;
+    const int64_t g64 = (chunks + 255) / 256;
+    const dim3 grid((unsigned)(g64 > 8192 ? 8192 : g64));
+    if (R == 8) hipLaunchKernelGGL((lokr_rows_bwd_kernel<8>), grid, block, 0, st, (uint32_t)chunks, N, wb, ap, iop);
+    else hipLaunchKernelGGL((lokr_rows_bwd_kernel<16>), grid, block, 0, st, (uint32_t)chunks, N, wb, ap, iop);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }
