@@ -117,7 +117,7 @@ def test_gemm_epilogue_is_versioned_by_size(built_lib):
     is read or launched -- a binding written against an older header can never make the library read past its object."""
     lib = ylib.load()
     full = C.sizeof(ylib.GemmEpilogue)
-    assert lib.yat_gemm_epilogue_size() == full == 128
+    assert lib.yat_gemm_epilogue_size() == full == 152          # round 5 appended a2 / b2 / k2 / a2_group_n to the 128-byte layout
     assert ylib.GemmEpilogue().struct_size == full
 
     def call(ep):
@@ -131,9 +131,10 @@ def test_gemm_epilogue_is_versioned_by_size(built_lib):
     import torch
     if not torch.cuda.is_available():
         assert call(ylib.GemmEpilogue()) > 0
-        v1 = ylib.GemmEpilogue()
-        v1.struct_size = 64
-        assert call(v1) > 0
+        for older in (64, 128):                                 # the first published layout, and the one before round 5's fields
+            v = ylib.GemmEpilogue()
+            v.struct_size = older
+            assert call(v) > 0
     for bad in (0, 8, 56, 60, full + 8, 0x7fff0000):
         ep = ylib.GemmEpilogue()
         ep.struct_size = bad
