@@ -307,7 +307,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--lokr-pre-add", action="store_true",
-                    help="LoKr: adapter term as a GEMM of its own + the pre_add epilogue instead of the base GEMM's second operand pair")
+                    help="LoKr / LoRA: adapter term computed by launches of its own + the pre_add epilogue instead of the base GEMM's "
+                         "second operand pair (A/B of the two forms)")
     ap.add_argument("--gemm-detail", default=None, help="write per-shape GEMM timings of the roofline pass to this file")
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the serialized GEMM-timing pass")
     ap.add_argument("--rccl-channels", type=int, default=-1, metavar="N",
@@ -395,7 +396,7 @@ def main():
     elif args.lora:
         from yat_amd.lora import LoRAAdapters
         trained = LoRAAdapters(model, ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2",
-                                       "proj"], r=args.lora, alpha=float(args.lora))
+                                       "proj"], r=args.lora, alpha=float(args.lora), pair=not args.lokr_pre_add)
         log(f"LoRA rank {args.lora}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
     opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
                     overlap_update=os.environ.get("YAT_SERIAL", "0") == "0")

@@ -279,6 +279,12 @@ int yat_lokr_rows_fwd_flat(int64_t rows, int N, int R, int in_m, const void* w2_
  * keep(i) = hash(seed, i) >= p (counter-based, so the backward regenerates the mask); backward_add=0: io = bf16(x * keep / (1-p));
  * backward_add=1: io = bf16(io + bf16(x * keep / (1-p)))  (gradient through the same mask, accumulated into an input gradient) */
 int yat_dropout(int64_t n, float p, uint64_t seed, int backward_add, const void* x, void* io, yat_stream_t stream);
+/* plain LoRA with the adapter term as the base GEMM's second operand pair (yat_gemm_epilogue.a2 = T = x A^T in K2 = 64 columns with
+ * x's row stride, b2 = scaling * lora_B with the weight's row stride): this entry writes b2 for EVERY adapter in one launch --
+ * dst[tgt + n in + q] = bf16(scale * src[off + q out + n]), q < R (8 or 16), n < out, with table[4 e ..] = {off, tgt, out, in} as int64
+ * (device memory), dst a zero-filled shadow of the model's flat weights; in % 8 == 0 and tgt % 8 == 0 (16-byte rows) */
+int yat_lora_scatter_b(int entries, int max_out, int R, float scale, const void* table, const void* src, void* dst,
+                       yat_stream_t stream);
 /* rank-R expansion over a whole layer width (plain LoRA, peft lora/layer.py [RECALL]; the reference's LoraConfig branch at
  * common/trainer.py:214-219): io[row, n] = f(sum_q h[row, q] * w[q, n]), h: bf16 [rows, R], w: bf16 [R, N], io: bf16 [rows, ldio];
  * residual=0: io = bf16(bf16(sum) * scale)  (lora_B(lora_A(x)) * scaling);  residual=1: io = bf16(bf16(sum) + io)  (dx += dT A) */

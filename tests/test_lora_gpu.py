@@ -100,6 +100,64 @@ def test_lora_training_step_matches_oracle(r, alpha, tmp_path):
     assert saved[k0 + "lora_A.weight"].shape == (r, ad.entries[0]["inn"]) and saved[k0 + "lora_B.weight"].shape == (ad.entries[0]["out"], r)
 
 
+
+def test_lora_scatter_b_and_forward_pair():
+    """Plain LoRA through the base GEMM's second operand pair (LoRAAdapters.forward_pair, the default): yat_lora_scatter_b writes
+    scaling * lora_B of every adapter into the first R columns of its target's rows of the weight shadow (nothing else), and the
+    adapted Linear equals the pre_add form (pair=False) and fp32 -- a fused q|k|v view with one adapter per block and a single
+    target, non-zero lora_B, scaling 2."""
+    from types import SimpleNamespace
+    from yat_amd.lora import LoRAAdapters
+    from yat_amd.lokr import adapted_linear
+    D, M, r = 640, 520, 4
+    names = ["blk.to_q", "blk.to_k", "blk.to_v", "blk.to_out.0"]
+    g = torch.Generator().manual_seed(21)
+
+    def make(pair):
+        flat = (torch.randn(4 * D * D, generator=torch.Generator().manual_seed(5)) * D ** -0.5).to(BF).to(DEV)
+        model = SimpleNamespace(P={n + ".weight": flat[i * D * D:(i + 1) * D * D].view(D, D) for i, n in enumerate(names)},
+                                flat_param=flat, flat_grad=torch.zeros_like(flat))
+        ad = LoRAAdapters(model, ["to_q", "to_k", "to_v", "to_out.0"], r=r, alpha=2.0 * r, pair=pair)
+        assert ad.pair == pair and ad.scale == 2.0
+        return model, ad
+    (m1, a1), (m2, a2) = make(True), make(False)
+    for e in a1.entries:
+        _, bt = a1._views(e, a1.flat_param)
+        bt[:r].copy_((torch.randn(r, D, generator=g) * 0.1).to(BF))
+    a2.flat_param.copy_(a1.flat_param)
+    a1.materialize(True); a2.materialize(True)
+    shadow = a1._flatB.view(4, D, D)
+    for i, e in enumerate(a1.entries):
+        _, bt = a1._views(e, a1.flat_param)
+        assert torch.equal(shadow[i, :, :a1.R], (bt.float().T * 2.0).to(BF)) and (shadow[i, :, a1.R:] == 0).all()
+    x, bias = torch.randn(M, D, generator=g).to(BF).to(DEV), torch.randn(3 * D, generator=g).to(BF).to(DEV)
+
+    def truth(lo, hi):
+        W = m1.flat_param[lo * D * D:hi * D * D].view((hi - lo) * D, D).float()
+        dW = torch.zeros_like(W)
+        for j, e in enumerate(a1.entries[lo:hi]):
+            a, bt = (t.float() for t in a1._views(e, a1.flat_param))
+            dW[j * D:(j + 1) * D] = (bt.T @ a) * a1.scale
+        return x.float() @ (W + dW).T
+
+    def rel(a, b):
+        return ((a.float() - b.float()).norm() / b.float().norm()).item()
+    y1 = adapted_linear(a1, x, m1.flat_param[:3 * D * D].view(3 * D, D), bias)
+    y2 = adapted_linear(a2, x, m2.flat_param[:3 * D * D].view(3 * D, D), bias)
+    t = truth(0, 3) + bias.float()
+    assert rel(y1, t) <= rel(y2, t) * 1.05 + 1e-4 and rel(y1, t) < 4e-3, (rel(y1, t), rel(y2, t))
+    o1 = adapted_linear(a1, x, m1.P["blk.to_out.0.weight"])
+    o2 = adapted_linear(a2, x, m2.P["blk.to_out.0.weight"])
+    t = truth(3, 4)
+    assert rel(o1, t) <= rel(o2, t) * 1.05 + 1e-4 and rel(o1, t) < 4e-3
+    # the T kept for d_B is the compact product of both forms; weight gradients agree bit for bit
+    dy = torch.randn(M, 3 * D, generator=g).to(BF).to(DEV)
+    for m, ad in ((m1, a1), (m2, a2)):
+        ad.wgrad(dy, x, m.flat_grad[:3 * D * D].view(3 * D, D))
+    torch.cuda.synchronize()
+    assert torch.equal(a1.flat_grad, a2.flat_grad) and a1.flat_grad.abs().max().item() > 0
+
+
 @pytest.mark.parametrize("rows,R,N,ld", [(1000, 8, 2240, 2240), (333, 16, 11200, 11200), (4096, 8, 64, 192), (77, 8, 520, 520)])
 def test_rank_expand(rows, R, N, ld):
     """io = bf16(bf16(h w) * scale) and io = bf16(bf16(h w) + io): the K = R products of the LoRA path, bit-exact against the

@@ -299,6 +299,24 @@ __global__ __launch_bounds__(256) void lokr_rows_bwd_kernel(uint32_t chunks, int
     }
 }
 
+// Plain LoRA through the base GEMM's second operand pair (yat_gemm_epilogue.b2): lora_B^T [R, out] of EVERY adapter, times
+// `scale`, into the first R columns of its target's rows in a shadow of the model's flat weights (row stride = the target's in):
+// dst[n, q] = bf16(scale * src[q, n]).  One launch for the whole adapter set: table[4 e ..] = {offset of B^T in `src`, offset of the
+// target's first row in `dst`, out, in} (elements).  Reads run along n (coalesced), a thread writes its row's R values at once.
+template <int R>
+__global__ __launch_bounds__(256) void lora_scatter_b_kernel(const int64_t* table, float scale, const bf16_t* src, bf16_t* dst) {
+    const int64_t* t = table + 4 * (int64_t)blockIdx.y;
+    const int out = (int)t[2], in = (int)t[3];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= out) return;
+    const bf16_t* sp = src + t[0] + n;
+    float v[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = bf2f(sp[(int64_t)q * out]) * scale;
+    bf16_t* dp = dst + t[1] + (int64_t)n * in;
+#pragma unroll
+    for (int c = 0; c < R / 8; ++c) *reinterpret_cast<u32x4*>(dp + c * 8) = pack8(v + c * 8);
+}
 // Rank-R expansion over a whole layer width (plain LoRA: u = T B^T with K = R, dx += dT A): a GEMM with an 8-deep reduction
 // is all epilogue, so it runs as a stream instead -- io[row, n] = f(sum_q h[row, q] * w[q, n]) with w's column block
 // (CB = 512 columns, fp32) in LDS, a lane per 16-byte chunk of the output row, a wave per 512 contiguous columns.
@@ -509,6 +527,18 @@ static int lokr_rows_launch(int64_t rows, int N, int R, int backward, const void
     const dim3 grid((unsigned)(g64 > 8192 ? 8192 : g64));
     if (R == 8) hipLaunchKernelGGL((lokr_rows_bwd_kernel<8>), grid, block, 0, st, (uint32_t)chunks, N, wb, ap, iop);
     else hipLaunchKernelGGL((lokr_rows_bwd_kernel<16>), grid, block, 0, st, (uint32_t)chunks, N, wb, ap, iop);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_lora_scatter_b(int entries, int max_out, int R, float scale, const void* table, const void* src, void* dst,
+                       yat_stream_t stream) {
+    if (entries <= 0 || entries > 65535 || max_out <= 0 || (R != 8 && R != 16) || !table || !src || !dst) return YAT_EINVAL;
+    const dim3 grid((max_out + 255) / 256, entries), block(256);
+    if (R == 8) hipLaunchKernelGGL((lora_scatter_b_kernel<8>), grid, block, 0, (hipStream_t)stream, (const int64_t*)table, scale,
+                                   (const bf16_t*)src, (bf16_t*)dst);
+    else hipLaunchKernelGGL((lora_scatter_b_kernel<16>), grid, block, 0, (hipStream_t)stream, (const int64_t*)table, scale,
+                            (const bf16_t*)src, (bf16_t*)dst);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

@@ -88,6 +88,7 @@ SIGNATURES = {
     "yat_lokr_rows": (I, [I64, I, I, I, P, P, P, P]),
     "yat_lokr_rows_fwd_flat": (I, [I64, I, I, I, P, P, P, I, P]),
     "yat_dropout": (I, [I64, F, U64, I, P, P, P]),
+    "yat_lora_scatter_b": (I, [I, I, I, F, P, P, P, P]),
     "yat_rank_expand": (I, [I64, I, I, P, P, P, I, F, I, P]),
     "yat_lokr_small_wgrad_workspace_bytes": (U64, [I64, I, I]),
     "yat_lokr_small_wgrad": (I, [I64, I, I, I, P, P, I, P, I, F, I, P, P]),

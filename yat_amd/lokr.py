@@ -62,6 +62,32 @@ def is_target(module_name: str, targets) -> bool:
     return any(module_name == t or module_name.endswith("." + t) for t in targets)
 
 
+class SlabColumns:
+    """Column slots of [rows, K] slabs for the small per-step products an adapter set hands to the base GEMMs as their second
+    operand (row stride K = the row stride of the x they are computed from).  Slabs are zero-filled, kept from step to step and
+    handed out in call order; ``restart()`` at the start of a step."""
+
+    def __init__(self, device):
+        self.device, self.slabs, self.next = device, {}, {}
+
+    def restart(self):
+        self.next = {}
+
+    def take(self, M, K, width):
+        slabs = self.slabs.setdefault(K, [])
+        i, col = self.next.get(K, (0, 0))
+        if col + width > K:
+            i, col = i + 1, 0
+        if i == len(slabs) or slabs[i].shape[0] < M:
+            buf = torch.zeros(M, K, dtype=BF16, device=self.device)
+            if i == len(slabs):
+                slabs.append(buf)
+            else:
+                slabs[i] = buf                                  # (a larger batch than any before: this step's earlier slots
+        self.next[K] = (i, col + width)                         #  live in the old buffer, which their views keep alive)
+        return slabs[i][:M, col:col + width]
+
+
 def adapted_linear(ad, x, w, bias=None, out=None, **ep):
     """Linear of a (possibly adapted) target, the ``lin`` hook of the models: base_layer(x) + adapter(x) (peft's wrap).  An
     adapter set that can hand its term over as the GEMM's second operand pair (``forward_pair``: the factored LoKr targets)
@@ -171,7 +197,7 @@ class LoKrAdapters:
         for e, n in zip(self.entries, sizes):
             e["ws"], o = ws_all[o:o + n], o + n
         self._lookup = {}
-        self._slabs, self._slab_next = {}, {}          # T1 slabs of forward_pair(): in -> [buffers [rows, in]], next free column
+        self._slabs = SlabColumns(dev)                 # T1 of forward_pair(): columns of [rows, in] slabs
         self.reset_parameters()
         model.adapters = self
 
@@ -230,22 +256,6 @@ class LoKrAdapters:
                 e["t1"] = (x.data_ptr(), t1.view(M, im * R))
         return tmp
 
-    def _t1_slot(self, M, K, width):
-        """``width`` columns of a [rows >= M, K] slab for this step's T1 products (row stride K = the row stride of the x they
-        are computed from); slabs are kept from step to step and handed out in call order."""
-        slabs = self._slabs.setdefault(K, [])
-        i, col = self._slab_next.get(K, (0, 0))
-        if col + width > K:
-            i, col = i + 1, 0
-        if i == len(slabs) or slabs[i].shape[0] < M:
-            buf = torch.zeros(M, K, dtype=BF16, device=self.flat_param.device)
-            if i == len(slabs):
-                slabs.append(buf)
-            else:
-                slabs[i] = buf                                  # (a larger batch than any before: this step's earlier slots
-        self._slab_next[K] = (i, col + width)                   #  live in the old buffer, which their views keep alive)
-        return slabs[i][:M, col:col + width]
-
     def forward_pair(self, x, w):
         """The adapter term of target view ``w`` as the second operand pair of the base GEMM: (a2 [M, n k2] with x's row
         stride, b2 [rows(w), k2] with w's, k2, columns of the output per block of a2) -- or None when the view has no adapter,
@@ -265,7 +275,7 @@ class LoKrAdapters:
                 or any(not e["factored"] or e["in_m"] * R != kr or e["inn"] != K or e["out"] != e0["out"] for e, _ in ents) \
                 or len(ents) * k2 > K or (len(ents) > 1 and e0["out"] % 320 and e0["out"] % 256):
             return None
-        a2 = self._t1_slot(M, K, len(ents) * k2)
+        a2 = self._slabs.take(M, K, len(ents) * k2)
         for j, (e, row0) in enumerate(ents):
             assert row0 == j * e0["out"]
             t1 = a2[:, j * k2:j * k2 + kr]
@@ -366,7 +376,7 @@ class LoKrAdapters:
     def materialize(self, training=True):
         """Rebuild every delta_w from the current adapter parameters (zeros where module dropout drops the adapter)."""
         self.join_pending_update()
-        self._slab_next = {}                # this step's T1 products take the slab columns from the start again
+        self._slabs.restart()               # this step's T1 products take the slab columns from the start again
         first_micro = not getattr(self.model, "accumulate_grads", False)
         for e in self.entries:
             e["projected"] = False

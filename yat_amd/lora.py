@@ -30,13 +30,14 @@ import os
 import torch
 
 from . import ops
-from .lokr import is_target
+from .lokr import is_target, SlabColumns
 
 BF16 = torch.bfloat16
 
 
 class LoRAAdapters:
-    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0, use_rslora: bool = False, seed: int = 0):
+    def __init__(self, model, targets, r: int, alpha: float, dropout: float = 0.0, use_rslora: bool = False, seed: int = 0,
+                 pair: bool = True):
         if not (0.0 <= float(dropout or 0.0) < 1.0):
             raise ValueError("lora_dropout must be in [0, 1)")
         self.model, self.r, self.alpha, self.use_rslora = model, int(r), float(alpha), bool(use_rslora)
@@ -72,6 +73,18 @@ class LoRAAdapters:
         self.grad_ready = None
         self._gate = torch.full((max(max(e["out"] for e in self.entries), R),), self.scale, dtype=BF16, device=dev)
         self._lookup = {}
+        # forward through the base GEMM's second operand pair (forward_pair()): scaling * lora_B of every adapter in the first R
+        # columns of its target's rows of a zero-filled shadow of the flat weights, rebuilt by one launch per step; T in slab columns
+        # (per target: 64 columns must fit a row, and the rows of the shadow must be 16-byte aligned)
+        for e in self.entries:
+            e["pair_ok"] = bool(pair) and e["inn"] >= 64 and e["w_off"] % 8 == 0
+        paired = [e for e in self.entries if e["pair_ok"]]
+        self.pair = bool(paired)
+        if self.pair:
+            self._flatB = torch.zeros_like(model.flat_param)
+            self._slabs = SlabColumns(dev)
+            self._b_table = torch.tensor([[e["ob"], e["w_off"], e["out"], e["inn"]] for e in paired], dtype=torch.int64).to(dev)
+            self._n_paired, self._max_out = len(paired), max(e["out"] for e in paired)
         self.reset_parameters()
         model.adapters = self
 
@@ -106,7 +119,10 @@ class LoRAAdapters:
 
     # ---- per step (interface of yat_amd/lokr.py)
     def materialize(self, training=True):
-        self.join_pending_update()                 # nothing to build: the factors are used as they are
+        self.join_pending_update()
+        if self.pair:                              # b2 of every target for this step; T takes the slab columns from the start
+            ops.lora_scatter_b(self._b_table, self._n_paired, self._max_out, self.R, self.scale, self.flat_param, self._flatB)
+            self._slabs.restart()
         # nn.Dropout on the adapter input: a fresh mask per layer and step in training, none in eval.  The mask is a hash of
         # (seed, element): forward, input gradient and weight gradient regenerate it from the per-(step, layer) seed.
         self._drop = self.dropout if (training and self.dropout > 0.0) else 0.0
@@ -134,6 +150,31 @@ class LoRAAdapters:
             ops.rank_expand(t, bt, tmp[:, row0:row0 + e["out"]], scale=self.scale)         # bf16(bf16(T B^T) * scaling)
             e["t"] = (x.data_ptr(), t)             # kept for d_B (see lokr.py on the lifetime)
         return tmp
+
+    def forward_pair(self, x, w):
+        """The adapter term of target view ``w`` as the second operand pair of the base GEMM (interface of yat_amd/lokr.py):
+        a2 = T = dropout(x) A^T in the first R of 64 slab columns per adapter (row stride of x), b2 = scaling * lora_B in the
+        shadow of the weights, k2 = 64.  base + adapter is accumulated in fp32 and rounded once (peft rounds u, u * scaling and
+        the sum; with scaling a power of two the products are the same numbers)."""
+        ents = self.lookup(w, self.model.flat_param)
+        if not ents:
+            return None
+        M, K, R = x.shape[0], x.shape[1], self.R
+        e0 = ents[0][0]
+        if not self.pair or not x.is_contiguous() or w.stride(0) != K or w.shape[0] != sum(e["out"] for e, _ in ents) \
+                or any(not e["pair_ok"] or e["inn"] != K or e["out"] != e0["out"] for e, _ in ents) or len(ents) * 64 > K \
+                or (len(ents) > 1 and e0["out"] % 320 and e0["out"] % 256):
+            return None
+        a2 = self._slabs.take(M, K, len(ents) * 64)
+        for j, (e, row0) in enumerate(ents):
+            assert row0 == j * e0["out"]
+            a, _ = self._views(e, self.flat_param)
+            t = torch.empty(M, R, dtype=BF16, device=x.device)
+            ops.gemm(self._dropped(e, x), a, t, M=M, N=R, K=K)                                # T = dropout(x) A^T
+            a2[:, j * 64:j * 64 + R].copy_(t)
+            e["t"] = (x.data_ptr(), t)
+        b2 = self._flatB[(w.data_ptr() - self.model.flat_param.data_ptr()) // 2:][:w.shape[0] * K].view(w.shape[0], K)[:, :64]
+        return a2, b2, 64, (e0["out"] if len(ents) > 1 else 0)
 
     def dgrad_term(self, dy, w, dx):
         hs = {}

@@ -373,6 +373,14 @@ def dropout_bwd_add(g, p, seed, io):
     return io
 
 
+def lora_scatter_b(table, entries, max_out, R, scale, src_flat, dst_flat):
+    """Every adapter's scaling * lora_B into the first R columns of its target's rows of ``dst_flat`` (a zero-filled shadow of the
+    model's flat weights): the b2 operands of the base GEMMs (yat_lora_scatter_b; ``table``: int64 [entries, 4] on the device)."""
+    _chk_bf16(src_flat, dst_flat)
+    _l.check(_lib().yat_lora_scatter_b(int(entries), int(max_out), int(R), float(scale), _p(table), _p(src_flat), _p(dst_flat),
+                                       _stream()), "yat_lora_scatter_b")
+
+
 def rank_expand(h2d, w, io2d, scale=1.0, residual=False):
     """io[rows, N] = bf16(bf16(h w) * scale), or bf16(bf16(h w) + io) with residual -- h2d [rows, R], w [R, N]; io2d may be a
     column block of a wider matrix (include/yat_hip.h: yat_rank_expand)."""
