@@ -314,8 +314,9 @@ def main():
     ap.add_argument("--rccl-channels", type=int, default=-1, metavar="N",
                     help="cap RCCL at N channels (NCCL_MAX_NCHANNELS=N before the communicator is built): fewer channels = "
                          "fewer persistent collective workgroups competing with the GEMM tiles for CUs, at lower link "
-                         "bandwidth; 0 = RCCL's default; -1 = the policy of yat_amd/ddp.py (24 unless the site set the "
-                         "variable).  The value in force is reported in the `comm` object")
+                         "bandwidth; 0 = RCCL's default; -1 = the policy of yat_amd/ddp.py (RCCL's default unless "
+                         "YAT_RCCL_CHANNELS asks for a cap; a site's own NCCL_*_NCHANNELS are never rewritten).  The value in "
+                         "force is reported in the `comm` object")
     ap.add_argument("--comm-steps", type=int, default=6, help="steps of each pass of the data-parallel diagnostics")
     ap.add_argument("--transport", choices=["torch", "native"], default=None,
                     help="gradient all-reduce transport of an N > 1 job (yat_amd/ddp.py): torch = torch.distributed's RCCL group "
@@ -398,6 +399,9 @@ def main():
         trained = LoRAAdapters(model, ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2",
                                        "proj"], r=args.lora, alpha=float(args.lora), pair=not args.lokr_pre_add)
         log(f"LoRA rank {args.lora}: {len(trained.entries)} adapted modules, {trained.num_parameters():,} trainable parameters")
+    from yat_amd.common.trainer import adapter_arithmetic
+    if trained is not model:
+        log(f"adapter arithmetic: {adapter_arithmetic(trained)}")
     opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
                     overlap_update=os.environ.get("YAT_SERIAL", "0") == "0")
     ddp = HipDDP(trained, force=force_ddp, coalesce=args.coalesce) if (world > 1 or force_ddp) else None
@@ -488,7 +492,7 @@ def main():
     # default stream, which shares its hardware queue with whatever else the process creates -- with a process group around
     # that was the weight-gradient and optimizer streams, and the step lost 16 ms (profiles/LOG_r01_r03.md section 6, "hardware queues").
     from yat_amd.flat import compute_stream, isolate_streams
-    if isolate_streams():      # (only with a process group around)
+    if isolate_streams() or "chain=" in os.environ.get("YAT_PRIO", ""):      # (only with a process group around; YAT_PRIO: diagnostic)
         hp = compute_stream(dev)
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)
@@ -714,7 +718,8 @@ def main():
             "config": {"workload": ("train_sana.py: SANA-1.6B (D=2240, 20 blocks) 1024px, bf16, "
                                     + (f"LoKr rank {args.lokr} adapters on a frozen base (BASELINE config 5), " if args.lokr
                                        else f"LoRA rank {args.lora} adapters on a frozen base, " if args.lora
-                                       else "full fine-tune, ") +
+                                       else "full fine-tune, ")
+                                    + (f"adapter arithmetic: {adapter_arithmetic(trained)}, " if (args.lokr or args.lora) else "") +
                                     f"cached latents/text embeds, aspect buckets {BUCKETS} round-robin, prompts of 20..300 tokens "
                                     + ("(text rows packed: the masked padding rows to T=512 are not computed)"
                                        if recipe.packs_text(batches[0]["lens"]) else "padded to T=512") + ", AdamW+clip"),

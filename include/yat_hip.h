@@ -227,6 +227,12 @@ int yat_sdpa_bwd_packed(int B, int N, int T, int H, int dh, float scale, const v
  * fwd u_out (nullable, bf16 [B,h,w,2Hc]): the conv output u (pre-GLU) kept for the backward;
  * bwd du_in (nullable, bf16 [B,h,w,2Hc]): du already computed (yat_gemm_epilogue.glu_u in the GEMM that produces dy,
  *      from the kept u) -- pass 1 (recompute u, GLU backward) is skipped and `dy` / `s`-recompute are not needed.
+ * `s` in the backward: read only by pass 1 (du_in == NULL: u is recomputed from s exactly as the forward computed it).
+ *      Pass 2 never reads it, on any shape: every pass-2 kernel recomputes s = bf16(z * sigmoid(z)) from the `z` it loads
+ *      for SiLU' (band / global-z kernels since round 5 -- a quarter of the pass's bytes --, the fallback kernel for w > 64
+ *      or 2Hc not a multiple of 8 since round 6), with this library's SiLU (gemm_common.hpp silu_f: what the conv_inverted
+ *      GEMM's epilogue and yat_act_fwd_bf16 store).  dwdw therefore does not depend on which kernel a shape selects; a
+ *      caller whose `s` came from another SiLU implementation gets dwdw for THIS library's s.
  * ------------------------------------------------------------------------------------------ */
 uint64_t yat_dwconv_glu_bwd_workspace_bytes(int B, int h, int w, int Hc);
 int yat_dwconv_glu_fwd(int B, int h, int w, int Hc, const void* s, const void* wdw, const void* bdw, void* y,

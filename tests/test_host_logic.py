@@ -350,17 +350,28 @@ def test_default_transport_and_group_backend(monkeypatch):
 
 
 def test_rccl_channel_policy(monkeypatch):
-    """yat_amd/ddp.py apply_channel_policy: one-rank jobs export nothing; an N > 1 job caps RCCL at RCCL_CHANNEL_CAP unless
-    the site set NCCL_MAX_NCHANNELS itself; an explicit cap wins, lowers a larger NCCL_MIN_NCHANNELS, and 0 leaves RCCL alone."""
+    """yat_amd/ddp.py apply_channel_policy (round-5 advisor): RCCL is left alone by default -- as the reference leaves it --;
+    a cap is opt-in (argument or YAT_RCCL_CHANNELS); a site's own NCCL_MIN/MAX_NCHANNELS are never rewritten, a request that
+    contradicts them raises."""
+    import pytest
     from yat_amd import ddp
-    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"):
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "YAT_RCCL_CHANNELS"):
         monkeypatch.delenv(k, raising=False)
     assert ddp.apply_channel_policy(1) is None and "NCCL_MAX_NCHANNELS" not in os.environ
-    assert ddp.apply_channel_policy(8) == ddp.RCCL_CHANNEL_CAP and os.environ["NCCL_MAX_NCHANNELS"] == str(ddp.RCCL_CHANNEL_CAP)
-    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "40")
-    assert ddp.apply_channel_policy(8) == 40 and os.environ["NCCL_MAX_NCHANNELS"] == "40"          # the site's own choice
-    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "32")
-    assert ddp.apply_channel_policy(8, 8) == 8
-    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and os.environ["NCCL_MIN_NCHANNELS"] == "8"
-    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    assert ddp.apply_channel_policy(8) is None and "NCCL_MAX_NCHANNELS" not in os.environ            # default: RCCL's own
     assert ddp.apply_channel_policy(8, 0) is None and "NCCL_MAX_NCHANNELS" not in os.environ
+    monkeypatch.setenv("YAT_RCCL_CHANNELS", str(ddp.RCCL_CHANNEL_CAP))                               # opt-in by environment
+    assert ddp.apply_channel_policy(8) == ddp.RCCL_CHANNEL_CAP and os.environ["NCCL_MAX_NCHANNELS"] == "24"
+    monkeypatch.delenv("YAT_RCCL_CHANNELS")
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "40")                                                   # the site's own choice
+    assert ddp.apply_channel_policy(8) == 40 and os.environ["NCCL_MAX_NCHANNELS"] == "40"
+    assert ddp.apply_channel_policy(8, 40) == 40
+    with pytest.raises(ValueError, match="NCCL_MAX_NCHANNELS=40"):
+        ddp.apply_channel_policy(8, 8)
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "40"                                                  # untouched
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "32")
+    with pytest.raises(ValueError, match="NCCL_MIN_NCHANNELS=32"):
+        ddp.apply_channel_policy(8, 8)
+    assert os.environ["NCCL_MIN_NCHANNELS"] == "32" and "NCCL_MAX_NCHANNELS" not in os.environ       # untouched
+    assert ddp.apply_channel_policy(8, 48) == 48 and os.environ["NCCL_MIN_NCHANNELS"] == "32"

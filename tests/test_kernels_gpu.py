@@ -796,6 +796,34 @@ def test_glu_backward_in_gemm_epilogue(ops, B, h, w, Hc, Dm):
         assert torch.equal(a, b_), f"fused GLU backward changes {nm}"
 
 
+@pytest.mark.parametrize("B,h,w,Hc", [(2, 32, 32, 72), (1, 16, 64, 160), (2, 9, 16, 64), (1, 3, 70, 8), (1, 6, 5, 12)])
+def test_dwconv_bwd_pass2_never_reads_s(ops, B, h, w, Hc):
+    """include/yat_hip.h on `s` in yat_dwconv_glu_bwd (round-5 advisor): with du given, no pass-2 kernel -- band, global-z
+    or the fallback for w > 64 / odd channel counts -- reads the `s` argument; each recomputes s = bf16(z sigmoid(z)) from z
+    with the library's own SiLU.  So dwdw cannot depend on which kernel a shape selects: garbage in `s` changes nothing, and
+    dwdw equals the fp32 sum over pixels of (library SiLU(z)) x du taps."""
+    M = B * h * w
+    z = rnd(M, 2 * Hc, seed=61)
+    wdw, bdw = rnd(2 * Hc, 9, scale=1 / 3, seed=62), rnd(2 * Hc, scale=0.1, seed=63)
+    du = rnd(M, 2 * Hc, scale=0.3, seed=64)
+    s_lib = ops.act_fwd(z, "silu", torch.empty_like(z))
+    ws = torch.empty(ops.dwconv_glu_bwd_workspace_bytes(B, h, w, Hc), dtype=torch.uint8, device=DEV)
+    outs = []
+    for s_arg in (s_lib, torch.full_like(z, float("nan")), rnd(M, 2 * Hc, seed=65)):
+        dz, dw, db = torch.empty_like(z), torch.empty_like(wdw), torch.empty_like(bdw)
+        ops.dwconv_glu_bwd(s_arg, z, B, h, w, Hc, wdw, bdw, None, dz, dw, db, ws, du=du)
+        outs.append((dz, dw, db))
+    for o in outs[1:]:
+        for a, b_, nm in zip(outs[0], o, ("dz", "dw", "db")):
+            assert torch.equal(a, b_), f"pass 2 read the s argument ({nm}, {h}x{w}x{Hc})"
+    # dW against the library's s: dW[c, tap(di, dj)] = sum_{b,i,j} s[b, i+di, j+dj, c] du[b, i, j, c]
+    si = s_lib.float().view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
+    dui = du.float().view(B, h, w, 2 * Hc).permute(0, 3, 1, 2)
+    sp = F.pad(si, (1, 1, 1, 1))
+    ref = torch.stack([(sp[:, :, a:a + h, b_:b_ + w] * dui).sum((0, 2, 3)) for a in range(3) for b_ in range(3)], 1)
+    close(outs[0][1], ref.to(BF), f"dwconv_dw_from_lib_s {h}x{w}x{Hc}", atol=2e-2)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise / recipe
 def test_elementwise(ops):
     x, dy = rnd(1000, 37, seed=41), rnd(1000, 37, seed=42)      # numel not a multiple of 8 -> scalar tail

@@ -165,6 +165,29 @@ class HipAccelerator:
             dist.barrier()
 
 
+def adapter_pair(params):
+    """Which arithmetic a LoRA / LoKr adapter set of the trainer uses.  True (the default): the adapter's factored term rides
+    in the base GEMM as a second operand pair -- base + adapter accumulated in fp32 and rounded to bf16 ONCE
+    (yat_amd/lokr.py ``forward_pair``).  False: peft's own op order under bf16 -- base output, adapter output and their sum
+    each rounded (``pre_add`` form; what the reference computes, common/trainer.py:212-241 + peft).  The default is at least
+    as close to the fp32 truth in every parity test but it is NOT the reference's rounding flow: a run's losses part from
+    the peft-order run at step 2 (profiles/r05_zz_adapter_loss_trajectories.txt).  Switches: config key
+    ``lora_fused_pair: false`` or ``YAT_ADAPTER_PAIR=0`` (the environment wins)."""
+    env = os.environ.get("YAT_ADAPTER_PAIR")
+    if env is not None and env != "":
+        return env.strip().lower() not in ("0", "false", "no", "off")
+    return bool(getattr(params, "lora_fused_pair", True))
+
+
+def adapter_arithmetic(adapters):
+    """One line for logs and bench lines: which rounding order the adapter set in force computes in."""
+    if adapters is None:
+        return "none"
+    if getattr(adapters, "pair", False):
+        return "fused_pair (adapter term inside the base GEMM, fp32 sum rounded once; not peft's rounding order)"
+    return "pre_add (peft order: base output, adapter output and their sum each rounded to bf16)"
+
+
 @contextlib.contextmanager
 def _step_stream(dev):
     """Run the step loop on a stream of the compute-stream set (yat_amd/flat.py ``compute_stream``) instead of the default
@@ -365,22 +388,24 @@ class Model:
                 saved = load_file(os.path.join(p.lora_pretrained, "adapter_model.safetensors"))
             if algo not in ("lokr", "lora", "loha"):
                 raise NotImplementedError(f"lora_algo: {algo} is not built (lokr -- BASELINE config 5 --, lora (+ DoRA) and loha are)")
+            pair = adapter_pair(p)
             if algo == "lora" and (getattr(p, "lora_use_dora", False) or dora_saved):      # :214-219 with use_dora=True
                 from ..dora import DoRAAdapters
                 self.adapters = DoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora)
             elif algo == "lora":                                      # :214-219
                 from ..lora import LoRAAdapters
                 self.adapters = LoRAAdapters(self.model, targets, rank, alpha, dropout=drop, use_rslora=rslora,
-                                             seed=int(getattr(p, "dataset_seed", 0) or 0))
+                                             seed=int(getattr(p, "dataset_seed", 0) or 0), pair=pair)
             elif algo == "loha":                                      # :220-224
                 from ..loha import LoHaAdapters
                 self.adapters = LoHaAdapters(self.model, targets, rank, alpha, module_dropout=drop)
             else:                                                     # :226-230
                 from ..lokr import LoKrAdapters
-                self.adapters = LoKrAdapters(self.model, targets, rank, alpha, module_dropout=drop)
+                self.adapters = LoKrAdapters(self.model, targets, rank, alpha, module_dropout=drop, pair=pair)
             if saved is not None:
                 self.adapters.load_state_dict(saved)
             n_ad = self.adapters.num_parameters()
+            print(f"adapter arithmetic: {adapter_arithmetic(self.adapters)}")
             print(f"trainable params: {n_ad:,} || all params: {self.model.numel_flat + n_ad:,} || "
                   f"trainable%: {100.0 * n_ad / (self.model.numel_flat + n_ad):.4f}")       # print_trainable_parameters (:239)
         # with adapters only they are trained (the base has no gradients, so AdamW leaves it alone in the reference too)

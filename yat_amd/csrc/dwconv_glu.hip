@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, 
         for (int t = 0; t < 9; ++t) { wt[t][e] = bf2f(wdw[(c0 + e) * 9 + t]); dW[t][e] = 0.f; }
     }
     const bf16_t* zb = z + (int64_t)b * h * w * C2;
-    const bf16_t* sb_ = sact + (int64_t)b * h * w * C2;
+    (void)sact;
     const bf16_t* dub = du + (int64_t)b * h * w * C2;
     bf16_t* dzb = dz + (int64_t)b * h * w * C2;
     if (active && j0 < w) {
@@ -434,23 +434,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(int h, int w, int Hc, 
                 }
             };
             auto load_z = [&](int jj) { return ld_or_zero(zb + ((int64_t)i * w + jj) * C2 + c0, jj >= 0 && jj < w); };
-            auto load_s = [&](int jj) { return ld_or_zero(sb_ + ((int64_t)i * w + jj) * C2 + c0, jj >= 0 && jj < w); };
+            // s = bf16(z sigmoid(z)), recomputed from z like the band / global-z kernels do (round 6: one definition of s for
+            // every shape, the `s` argument is not read by pass 2 at all; zero past the image, where z loads as zero)
+            auto s_of = [&](u32x2 zz, float (&o)[4]) {
+                unpack4(zz, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] * sigmoid_f(o[e]));
+            };
             float aP[4], aC[4], aN[4], sP[4], sC[4], sN[4], zP[4], zC[4], zN[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { aP[e] = aC[e] = aN[e] = 0.f; }
             // centre-row z window around input column jj: P = jj-1, C = jj, N = jj+1
             unpack4(load_z(j0 - 2), zP);
             unpack4(load_z(j0 - 1), zC);
-            unpack4(load_s(j0 - 2), sP);
-            unpack4(load_s(j0 - 1), sC);
+            s_of(load_z(j0 - 2), sP);
+            s_of(load_z(j0 - 1), sC);
             u32x2 dn[3];
             load_du(j0 - 1, dn);
-            u32x2 zn = load_z(j0), sn = load_s(j0);
+            u32x2 zn = load_z(j0);
             for (int jj = j0 - 1; jj <= j1; ++jj) {
                 u32x2 dc[3] = {dn[0], dn[1], dn[2]};
                 unpack4(zn, zN);
-                unpack4(sn, sN);
-                if (jj < j1) { load_du(jj + 1, dn); zn = load_z(jj + 2); sn = load_s(jj + 2); }      // prefetch
+                s_of(zn, sN);
+                if (jj < j1) { load_du(jj + 1, dn); zn = load_z(jj + 2); }      // prefetch
                 // only contributions to output columns inside [j0, j1) count for dW (each (pixel, tap) pair once)
                 const bool inP = jj - 1 >= j0 && jj - 1 < j1, inC = jj >= j0 && jj < j1, inN = jj + 1 >= j0 && jj + 1 < j1;
 #pragma unroll

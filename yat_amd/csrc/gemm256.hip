@@ -1054,8 +1054,14 @@ int yat_gemm256_launch(int a_t, int b_t, int nt_variant, const GemmP& p, hipStre
         return launch256<true, true, 4, 4>(p, stream);
     }
     if (p.A2) {                    // second operand pair: forward layout, no split-K
+        // (wired into the DEEP loop's DMA only: the diagnostic builds without that loop for the forward layout --
+        //  -DYAT_GEMM_STAMPS, -DYAT_GEMM_DEEP=0, -DYAT_GEMM_DEEP_KH=0 -- do not instantiate EPI 5 and refuse the call)
+#if !defined(YAT_GEMM_STAMPS) && YAT_GEMM_DEEP && YAT_GEMM_DEEP_KH
         if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;
         return nt_variant == 5 ? launch256<false, false, 5, 5>(p, stream) : launch256<false, false, 4, 5>(p, stream);
+#else
+        return YAT_EINVAL;
+#endif
     }
     if (p.pre_add) {               // adapter addend: only the forward layout (x W^T) is instantiated, no split-K
         if (a_t || b_t || p.ksplit > 1) return YAT_EINVAL;

@@ -70,35 +70,40 @@ def group_backend(on_gpu=True):
     return "gloo" if default_transport() == "native" else "nccl"
 
 
-# RCCL channel cap of a data-parallel job.  A channel is a persistent workgroup of the collective kernel, and a gemm256
-# workgroup owns its CU outright (144 KiB of LDS, 2 x 250 VGPRs per SIMD: DESIGN.md section 5), so the two never share a CU:
-# while a bucket's all-reduce runs, every channel takes one CU away from the backward.  3.21 GB of gradients per step have
-# ~50 ms of backward to hide under, and a channel moves roughly 9 GB/s of bus bandwidth over xGMI (RCCL reaches its ~300 GB/s
-# plateau at 8 ranks with 32+ of them), so bandwidth is not what the step is short of -- CUs are:
+# RCCL channels of a data-parallel job: RCCL's own defaults unless somebody asks (round-5 advisor).  A channel is a persistent
+# workgroup of the collective kernel, and a gemm256 workgroup owns its CU outright (144 KiB of LDS, 2 x 250 VGPRs per SIMD:
+# DESIGN.md section 5), so the two never share a CU: while a bucket's all-reduce runs, every channel takes one CU away from the
+# backward.  On paper (ESTIMATES -- nothing below was ever measured on N > 1 GPUs; no such box was available to the builder):
 #   channels   bus GB/s   ring time of 3.21 GB   CU share while it runs   cost to the backward   last bucket (149 MB) exposed
 #      16        ~145          ~39 ms                  6 %                    ~2.4 ms                  ~1.8 ms
 #      24        ~215          ~26 ms                  9 %                    ~2.4 ms                  ~1.2 ms
 #      64        ~300          ~19 ms                 25 %                    ~4.7 ms                  ~0.9 ms
-# 24 keeps the ring time at half the backward (16 leaves too little margin should a channel move less than assumed: a ring
-# that outlasts the backward is exposed in full) at a third of the CUs RCCL would take by itself.  Never measured on N > 1
-# GPUs: a site's own NCCL_MAX_NCHANNELS wins, and ``bench.py --rccl-channels N`` (0 = RCCL's default) is there to sweep it.
-RCCL_CHANNEL_CAP = 24
+# i.e. a cap around 24 might give the backward back ~2 ms of CU time -- or expose the last buckets if a channel moves less than
+# assumed.  The reference leaves RCCL alone, and so does this package by default: the cap is OPT-IN (``YAT_RCCL_CHANNELS=N``,
+# ``bench.py --rccl-channels N``) until an N > 1 sweep is recorded under profiles/.
+RCCL_CHANNEL_CAP = 24            # the value the table suggests trying first; nothing applies it by itself
 
 
 def apply_channel_policy(world, cap=None):
-    """Export NCCL_MAX_NCHANNELS for an N > 1 job before any communicator exists; returns the cap in force (None = RCCL's
-    default).  ``cap``: None = the policy above, 0 = leave RCCL alone, N = that many."""
+    """Called before any RCCL communicator exists; returns the NCCL_MAX_NCHANNELS in force (None = RCCL's default).
+    ``cap``: None = ``YAT_RCCL_CHANNELS`` if set, else leave RCCL alone; 0 = leave RCCL alone; N = ask for at most N.
+    A site's own NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS are never overridden: a request that contradicts them raises
+    instead of rewriting them silently."""
     if world <= 1:
         return None
     if cap is None:
-        if os.environ.get("NCCL_MAX_NCHANNELS"):
-            return int(os.environ["NCCL_MAX_NCHANNELS"])
-        cap = RCCL_CHANNEL_CAP
+        cap = int(os.environ.get("YAT_RCCL_CHANNELS", "0") or 0)
+    site_max = os.environ.get("NCCL_MAX_NCHANNELS")
+    site_min = os.environ.get("NCCL_MIN_NCHANNELS")
     if cap <= 0:
-        return None
+        return int(site_max) if site_max else None
+    if site_max and int(site_max) != cap:
+        raise ValueError(f"RCCL channel cap {cap} requested, but the site exports NCCL_MAX_NCHANNELS={site_max}: "
+                         f"unset one of them")
+    if site_min and int(site_min) > cap:
+        raise ValueError(f"RCCL channel cap {cap} requested, but the site exports NCCL_MIN_NCHANNELS={site_min} > {cap}: "
+                         f"unset one of them")
     os.environ["NCCL_MAX_NCHANNELS"] = str(cap)
-    if int(os.environ.get("NCCL_MIN_NCHANNELS", "0") or 0) > cap:
-        os.environ["NCCL_MIN_NCHANNELS"] = str(cap)
     return cap
 
 

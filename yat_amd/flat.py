@@ -41,14 +41,45 @@ def isolate_streams():
     return dist.is_available() and dist.is_initialized()
 
 
-def compute_stream(device):
-    """A HIP stream for the step's compute (dependent chain, second forward chain, weight-gradient stream, optimizer stream).
+def compute_stream(device, role="chain"):
+    """A HIP stream for the step's compute (``role``: "chain" = dependent chain / second forward chain, "side" =
+    weight-gradient stream, "opt" = optimizer stream).
     The HIP runtime multiplexes streams onto a few hardware queues PER PRIORITY LEVEL, and two streams on one hardware queue
     run their kernels strictly one after the other.  In a data-parallel job the normal level is shared with every stream
     torch, the process group and the copy engine create -- the default stream, the weight-gradient stream and the optimizer
     stream were found on ONE hardware queue, 16 ms per step lost -- so there the four compute streams move to the high level,
     whose only users they are: four streams, four queues ("hardware queues")."""
+    prio = _role_priority(role)
+    if prio is not None:
+        return _hip_stream(device, prio)
     return torch.cuda.Stream(device=device, priority=-1 if isolate_streams() else 0)
+
+
+def _role_priority(role):
+    """Diagnostic (round 6): ``YAT_PRIO="chain=-1,side=1,opt=1"`` gives the streams of a role an
+    explicit HIP priority (-1 high, 0 normal, 1 low).  Unset in a product run."""
+    spec = os.environ.get("YAT_PRIO", "")
+    if not spec:
+        return None
+    table = dict(item.split("=") for item in spec.split(",") if item)
+    return int(table[role]) if role in table else None
+
+
+_HIP = None
+
+
+def _hip_stream(device, priority):
+    """torch.cuda.Stream accepts only the levels torch knows; the low level (+1) is created through the runtime itself."""
+    import ctypes
+    global _HIP
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    with torch.cuda.device(device):
+        s = ctypes.c_void_p()
+        rc = _HIP.hipStreamCreateWithPriority(ctypes.byref(s), ctypes.c_uint(0), ctypes.c_int(priority))
+        if rc != 0:
+            raise RuntimeError(f"hipStreamCreateWithPriority({priority}) -> {rc}")
+    return torch.cuda.ExternalStream(s.value, device=device)
 
 
 GRAD_TAIL = 8        # 16 bytes: the flat gradient buffer stays a whole number of 16-byte vectors
@@ -261,5 +292,5 @@ class FlatParamModule(nn.Module):
 
     def _side_stream(self):
         if self._side is None:
-            self._side = compute_stream(self.flat_param.device)
+            self._side = compute_stream(self.flat_param.device, "side")
         return self._side

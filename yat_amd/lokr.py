@@ -265,17 +265,24 @@ class LoKrAdapters:
         ents = self.lookup(w, self.model.flat_param)
         if not ents:
             return None
-        if not any(e["active"] for e, _ in ents):
-            return "plain"
         M, K, R = x.shape[0], x.shape[1], self.R
         e0 = ents[0][0]
         kr = e0["in_m"] * R
         k2 = (kr + 63) // 64 * 64
-        if not self.pair or not x.is_contiguous() or w.stride(0) != K or w.shape[0] != sum(e["out"] for e, _ in ents) \
-                or any(not e["factored"] or e["in_m"] * R != kr or e["inn"] != K or e["out"] != e0["out"] for e, _ in ents) \
-                or len(ents) * k2 > K or (len(ents) > 1 and e0["out"] % 320 and e0["out"] % 256):
+        applies = not (not self.pair or not x.is_contiguous() or w.stride(0) != K
+                       or w.shape[0] != sum(e["out"] for e, _ in ents)
+                       or any(not e["factored"] or e["in_m"] * R != kr or e["inn"] != K or e["out"] != e0["out"]
+                              for e, _ in ents)
+                       or len(ents) * k2 > K or (len(ents) > 1 and e0["out"] % 320 and e0["out"] % 256))
+        # the slot is taken BEFORE the dropped-target return (round-5 advisor): slots are handed out in call order, so a
+        # target that module dropout drops this step must still consume its slot -- every target then owns the same columns
+        # step after step, and the padding columns kr..k2 of a slot (never written, zero from the slab's creation) can
+        # never hold another target's stale T1
+        a2 = self._slabs.take(M, K, len(ents) * k2) if applies else None
+        if not any(e["active"] for e, _ in ents):
+            return "plain"
+        if not applies:
             return None
-        a2 = self._slabs.take(M, K, len(ents) * k2)
         for j, (e, row0) in enumerate(ents):
             assert row0 == j * e0["out"]
             t1 = a2[:, j * k2:j * k2 + kr]

@@ -89,7 +89,7 @@ class FlatAdamW:
         m.join_pending_update()
         if self._stream is None:
             from .flat import compute_stream
-            self._stream = compute_stream(m.flat_param.device)
+            self._stream = compute_stream(m.flat_param.device, "opt")
         main = torch.cuda.current_stream()
         self._stream.wait_stream(main)
         # one persistent event per bucket, re-recorded every step: the next forward's waits are then the same calls on
