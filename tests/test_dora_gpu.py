@@ -108,10 +108,10 @@ def test_dora_training_step_matches_oracle():
     torch.cuda.synchronize()
     l32, lbf, lh = float(outs["fp32"][0]), float(outs["bf16"][0]), float(loss.detach())
     print(f"[parity] dora loss hip={lh:.6f} oracle_bf16={lbf:.6f} fp32={l32:.6f}")
-    assert abs(lh - l32) <= 1.3 * abs(lbf - l32) + 2e-3 * abs(l32)
+    assert abs(lh - l32) <= 1.15 * abs(lbf - l32) + 2e-3 * abs(l32)
     e_h, e_r = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
     print(f"[parity] dora pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
-    assert e_h <= 1.3 * e_r + 1e-3
+    assert e_h <= 1.15 * e_r + 1e-3
     per = {"lora_A": ([], [], []), "lora_B": ([], [], []), "magnitude": ([], [], [])}
     for e in ad.entries:
         gb, ga, gm = ad._views(e, ad.flat_grad)
@@ -126,7 +126,7 @@ def test_dora_training_step_matches_oracle():
         e_h, e_r = rel(h, f), rel(b, f)
         print(f"[parity] dora d_{attr} hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={h.numel()})")
         assert torch.isfinite(h).all() and f.abs().max() > 0
-        assert e_h <= 1.3 * e_r + 2e-3, attr
+        assert e_h <= 1.15 * e_r + 2e-3, attr
     assert torch.equal(base, hip.flat_param)
     p0 = ad.flat_param.clone()
     FlatAdamW(ad, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0).step()

@@ -4,8 +4,13 @@ caption width 2304, T = 512 ragged) -- on the bench's buckets, HIP vs the CPU or
 Follows the reference's stack loop (utils/patched_sana_transformer.py:301-340): the residual stream after blocks 1 / 5 / 10 /
 20 is compared through the oracle's per-block ``taps``, so error growth with depth is measured rather than assumed, and a
 regression in one block shows at that block rather than only in the loss.  Criteria are the ones of tests/test_sana_gpu.py
-(DESIGN.md section 2): |loss_hip - loss_fp32| <= 1.3 |loss_oracle_bf16 - loss_fp32| + 1e-3 |loss_fp32|;
-rel_l2(hip, fp32) <= 1.3 rel_l2(oracle_bf16, fp32) + 1e-3 for the prediction, the concatenated gradient and every tap.
+(slack tightened in round 6 from 1.3 / 1.5 to what is measured -- ratios 0.95 .. 1.04 on every tap):
+|loss_hip - loss_fp32| <= 1.1 |loss_oracle_bf16 - loss_fp32| + 1e-3 |loss_fp32|;
+rel_l2(hip, fp32) <= 1.1 rel_l2(oracle_bf16, fp32) + 1e-3 for the prediction, the concatenated gradient and every tap
+(gradient buckets: 1.2 x + 2e-3).  And, new in round 6, an ASSERTED bound on the distance to the reference's own arithmetic,
+rel_l2(hip, oracle_bf16): two independent bf16 evaluations would sit sqrt(2) x the common error apart; the HIP path keeps the
+reference's rounding points and sits 0.75 .. 1.06 x the oracle's own fp32 distance from it -- held to <= 1.3 x that distance
+and to absolute caps of 1.25 x the largest value printed on 2026-10-05 (HIP_VS_ORACLE_CAP below).
 """
 import copy
 import time
@@ -21,6 +26,11 @@ DEV = "cuda"
 def rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+# rel_l2(hip, oracle_bf16) caps: 1.25 x the largest value any of the five cases printed (gpurun_out of 2026-10-05:
+# 5.21e-3 / 8.68e-3 / 1.126e-2 / 1.650e-2 after blocks 1 / 5 / 10 / 20, 1.808e-2 on the prediction; the LoKr step 2.148e-2)
+HIP_VS_ORACLE_CAP = {0: 6.5e-3, 4: 1.09e-2, 9: 1.41e-2, 19: 2.06e-2, "pred": 2.26e-2, "lokr_pred": 2.7e-2}
 
 
 @pytest.fixture(scope="module")
@@ -127,26 +137,28 @@ def test_full_depth_step_matches_oracle(full_models, h, w, lens):
     print(f"[parity] full depth {h}x{w}: HIP results below are the device path's (optimize_device: packed text, plans replayed)")
     print(f"[parity] full depth {h}x{w}: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
     for i in tap_blocks:
-        e_h, e_b = rel(taps_h[i], taps_t[i]), rel(taps_b[i], taps_t[i])
+        e_h, e_b, e_hb = rel(taps_h[i], taps_t[i]), rel(taps_b[i], taps_t[i]), rel(taps_h[i], taps_b[i])
         print(f"[parity] full depth {h}x{w}: residual stream after block {i + 1:2d}: hip_vs_fp32={e_h:.3e} "
-              f"oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={rel(taps_h[i], taps_b[i]):.3e}")
-        assert e_h <= 1.3 * e_b + 1e-3, (i, e_h, e_b)
-    e_h, e_b = rel(pred, pred_t), rel(pred_b, pred_t)
+              f"oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={e_hb:.3e}")
+        assert e_h <= 1.1 * e_b + 1e-3, (i, e_h, e_b)
+        assert e_hb <= 1.3 * e_b and e_hb <= HIP_VS_ORACLE_CAP[i], (i, e_hb, e_b)
+    e_h, e_b, e_hb = rel(pred, pred_t), rel(pred_b, pred_t), rel(pred, pred_b)
     print(f"[parity] full depth {h}x{w}: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} "
-          f"hip_vs_oracle_bf16={rel(pred, pred_b):.3e}")
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 1e-3 * abs(l_t)
-    assert e_h <= 1.3 * e_b + 1e-3
+          f"hip_vs_oracle_bf16={e_hb:.3e}")
+    assert abs(l_h - l_t) <= 1.1 * abs(l_b - l_t) + 1e-3 * abs(l_t)
+    assert e_h <= 1.1 * e_b + 1e-3
+    assert e_hb <= 1.3 * e_b and e_hb <= HIP_VS_ORACLE_CAP["pred"], (e_hb, e_b)
     den = g_t.norm().item()
     tot_h, tot_b = (grads_h - g_t).norm().item() / den, (g_b - g_t).norm().item() / den
     print(f"[parity] full depth {h}x{w}: grads (1.6 B, concatenated) hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.1 * tot_b + 1e-3
     # per bucket (embedders | block i): where along the depth the gradient error sits
     for bi, (lo, hi) in enumerate(hip.bucket_bounds):
         if bi in (0, 1, 5, 10, 20):
             d = g_t[lo:hi].norm().item()
             e1, e2 = (grads_h[lo:hi] - g_t[lo:hi]).norm().item() / d, (g_b[lo:hi] - g_t[lo:hi]).norm().item() / d
             print(f"[parity] full depth {h}x{w}: grads bucket {bi:2d}: hip={e1:.3e} oracle_bf16={e2:.3e}")
-            assert e1 <= 1.5 * e2 + 2e-3, (bi, e1, e2)
+            assert e1 <= 1.2 * e2 + 2e-3, (bi, e1, e2)
 
 
 def test_lokr_full_depth_step_matches_oracle(full_models):
@@ -213,16 +225,148 @@ def test_lokr_full_depth_step_matches_oracle(full_models):
         del ref_32, ref_bf
         l_h = loss.item()
         print(f"[parity] lokr full depth: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
-        assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 2e-3 * abs(l_t)
-        e_h, e_b = rel(pred, p_t), rel(p_b, p_t)
-        print(f"[parity] lokr full depth: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={rel(pred, p_b):.3e}")
-        assert e_h <= 1.3 * e_b + 1e-3
+        assert abs(l_h - l_t) <= 1.1 * abs(l_b - l_t) + 2e-3 * abs(l_t)
+        e_h, e_b, e_hb = rel(pred, p_t), rel(p_b, p_t), rel(pred, p_b)
+        print(f"[parity] lokr full depth: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={e_hb:.3e}")
+        assert e_h <= 1.1 * e_b + 1e-3
+        # (the default adapter arithmetic rounds base + adapter once where the oracle's peft order rounds three times: the two
+        #  bf16 evaluations share fewer rounding points than in full fine-tuning -- 1.22 x the oracle's own fp32 distance)
+        assert e_hb <= 1.55 * e_b and e_hb <= HIP_VS_ORACLE_CAP["lokr_pred"], (e_hb, e_b)
         e_h, e_b = rel(g_h, g_t), rel(g_b, g_t)
         print(f"[parity] lokr full depth: adapter grads ({g_t.numel() / 1e6:.2f} M) hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e}")
         assert torch.isfinite(g_h).all() and g_t.abs().max() > 0
-        assert e_h <= 1.3 * e_b + 2e-3
+        assert e_h <= 1.1 * e_b + 2e-3
     finally:
         hip.adapters = None                              # the shared model goes back to full fine-tuning
+
+
+@pytest.mark.parametrize("pair", [True, False])
+def test_lokr_config5_batch32_step_properties(full_models, pair):
+    """BASELINE config 5 at ITS OWN batch (round-5 review item 7): LoKr rank 8 on the frozen SANA-1.6B base, B = 32 images of
+    32 x 32 latents with prompts of 20..300 tokens, module dropout 0.05 as the bench runs it.  The oracle proves the step at
+    B = 2 (test above; 32 images through the fp32 CPU oracle would take ~10 minutes and ~250 GB); here the B = 32 step is
+    held to size-independent properties: finite; deterministic (same draws, same dropout pattern -> the same bits); the
+    prediction of its first two images equals the B = 2 step of those two images up to "another bf16 evaluation" (images
+    are independent of each other in the forward: common/trainer.py:312-344 batches them, nothing mixes them; the GEMM shape
+    policy may pick another tile / split for M = 32768 rows than for 2048); and the adapter gradient of the B = 32 batch is
+    not the B = 2 one (every image contributes).  Both adapter arithmetics (``pair``: DESIGN.md section 11)."""
+    from yat_amd.lokr import LoKrAdapters
+    from yat_amd.recipe import SanaRecipe
+    hip, _ = full_models
+    targets = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
+    cfg = hip.cfg
+    ad = LoKrAdapters(hip, targets, r=8, alpha=8.0, module_dropout=0.05, pair=pair)
+    assert ad.pair == pair
+    try:
+        g = torch.Generator().manual_seed(78)
+        for e in ad.entries:
+            w1, _, _ = ad._views(e, ad.flat_param)
+            w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+        B, h, w_ = 32, 32, 32
+        lens = [int(x) for x in torch.randint(20, 301, (B,), generator=g)]
+        latents = (torch.randn(B, cfg.in_channels, h, w_, generator=g) * 0.5).to(BF)
+        embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in lens]
+        recipe = SanaRecipe(hip, pad_to=512, device=DEV)
+        hip.train()
+
+        def step(nb):
+            torch.manual_seed(1234)                      # the module-dropout draws (torch.rand on the host: peft's own draw)
+            ad.flat_grad.zero_()
+            loss, pred, _ = recipe.optimize(latents[:nb], embs[:nb], torch.Generator().manual_seed(5), return_pred=True)
+            loss.backward()
+            torch.cuda.synchronize()
+            dropped = [e["module"] for e in ad.entries if not e["active"]]
+            return loss.item(), pred.detach().clone(), ad.flat_grad.detach().clone(), dropped
+        l1, p1, g1, d1 = step(B)
+        l2, p2, g2, d2 = step(B)
+        assert 0 < len(d1) < len(ad.entries) // 4 and d1 == d2, "module dropout 0.05 drops a few adapters, the same ones"
+        assert torch.isfinite(p1.float()).all() and torch.isfinite(g1.float()).all() and g1.float().abs().max() > 0
+        assert l1 == l2 and torch.equal(p1, p2) and torch.equal(g1, g2), "the B = 32 step is not deterministic"
+        l_s, p_s, g_s, d_s = step(2)
+        assert d_s == d1                                  # same dropout draws: the same adapted model
+        # NB the recipe draws noise for the whole batch in one call, so images 0 and 1 of the B = 32 batch see other noise /
+        # timesteps than the B = 2 batch: compare through the model call itself on identical inputs instead
+        hip.eval()
+        with torch.no_grad():
+            enc, mask, _, _ = recipe.pad_embeddings(embs)
+            t = torch.linspace(40.0, 960.0, B)
+            out32 = hip(latents.to(DEV), encoder_hidden_states=enc, timestep=t, encoder_attention_mask=mask).sample.clone()
+            out2 = hip(latents[:2].to(DEV), encoder_hidden_states=enc[:2], timestep=t[:2], encoder_attention_mask=mask[:2]).sample
+        d = rel(out32[:2], out2)
+        print(f"[parity] lokr config 5 (pair={pair}): B=32 step loss {l1:.6f}, {len(d1)} of {len(ad.entries)} adapters dropped; "
+              f"first two images of the B=32 forward vs the B=2 forward: {d:.2e} (relative)")
+        assert d <= 2e-2
+        assert rel(g1, g_s) > 1e-2
+    finally:
+        hip.adapters = None
+        hip.train()
+
+
+def test_adapter_multiplier_zero_is_the_base_model_even_after_a_recorded_plan(full_models):
+    """common/trainer.py:270-281,385-397 (`rescale_adapter_scale(model, 0.0)` around validation steps outside the timestep
+    whitelist) on the real path (round-5 advisor / review item 7): the base model records and replays a launch plan; adapters
+    are attached (no plan may be replayed or recorded from here on: the recorded launches know nothing of them).  With the
+    adapter scale multiplied by 0 the step is BIT FOR BIT the step of an identity adapter (w1 = 0: the same launches on the
+    same operands -- nothing keeps a stale scale, in either adapter arithmetic), which is the base model up to "another bf16
+    evaluation" (with adapters the forward is one chain and every target goes through gemm256's pair / pre_add kernels;
+    without, two chains and the shape policy's own pick: other fp32 summation orders for the same rows); with the scale
+    restored it is the adapted step again; with the adapters detached the base model's plans are back and still right."""
+    from yat_amd.common.trainer import rescale_adapter_scale
+    from yat_amd.lokr import LoKrAdapters
+    from yat_amd.recipe import SanaRecipe
+    hip, _ = full_models
+    cfg = hip.cfg
+    g = torch.Generator().manual_seed(79)
+    B, h, w_ = 2, 32, 32
+    latents = (torch.randn(B, cfg.in_channels, h, w_, generator=g) * 0.5).to(BF)
+    embs = [torch.randn(L, cfg.caption_channels, generator=g).to(BF) for L in (33, 210)]
+    recipe = SanaRecipe(hip, pad_to=512, device=DEV)
+    hip.train()
+    assert hip.use_plans and hip.adapters is None
+
+    def device_pred():
+        recipe.optimize_device(latents, embs, torch.Generator())
+        torch.cuda.synchronize()
+        return hip._buf("pred", (B, cfg.out_channels, h * w_)).clone()
+    for _ in range(3):
+        r0 = getattr(hip, "plan_replays", 0)
+        base = device_pred()
+    assert hip.plan_replays - r0 == 2                      # forward and backward of the third call were replays
+    for pair in (True, False):
+        ad = LoKrAdapters(hip, ["to_q", "to_k", "to_v", "to_out.0", "conv_inverted", "conv_point"], r=8, alpha=8.0,
+                          module_dropout=0.0, pair=pair)
+        try:
+            trained = []
+            for e in ad.entries:
+                w1, _, _ = ad._views(e, ad.flat_param)
+                w1.copy_((torch.randn(w1.shape, generator=g) * 0.05).to(BF))
+                trained.append(w1.clone())
+            r0 = hip.plan_replays
+            adapted = device_pred()
+            assert hip.plan_replays == r0, "a plan was replayed with adapters attached"
+            with rescale_adapter_scale(ad, 0.0):
+                assert ad.scale == 0.0
+                zeroed = device_pred()
+            again = device_pred()                          # the trained scaling is back
+            for e in ad.entries:
+                ad._views(e, ad.flat_param)[0].zero_()
+            ident = device_pred()                          # a fresh LoKr adapter (w1 = 0) is the identity
+            for e, w in zip(ad.entries, trained):
+                ad._views(e, ad.flat_param)[0].copy_(w)
+            d_ad, d_base = rel(adapted, ident), rel(ident, base)
+            print(f"[parity] adapter multiplier 0 (pair={pair}): adapted vs identity {d_ad:.2e}; identity-adapter step vs the "
+                  f"base model's replayed plan {d_base:.2e}")
+            assert torch.equal(zeroed, ident), f"multiplier 0 is not the identity adapter (pair={pair}): {rel(zeroed, ident):.2e}"
+            assert torch.equal(again, adapted) and not torch.equal(adapted, zeroed) and d_ad > 1e-3
+            assert d_base <= 2.5e-2
+            assert hip.plan_replays == r0
+        finally:
+            hip.adapters = None
+    # detached: the base model again, from plans (a change of the adapter scale drops recorded plans -- rescale_adapter_scale --
+    # so the first call may record anew; the second one replays)
+    first = device_pred()
+    r0 = hip.plan_replays
+    assert torch.equal(first, base) and torch.equal(device_pred(), base) and hip.plan_replays - r0 == 2
 
 
 # ---- the bench step at its own width and batch, on every bench bucket, without the oracle: what bench.py times is

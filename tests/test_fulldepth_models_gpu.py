@@ -9,8 +9,10 @@ tests/test_fulldepth_gpu.py (SANA):
 Latents are 64 x 64 (PixArt: 1024 image tokens after the 2 x 2 patches) / 48 x 48 (SD3.5: 576) -- the 1024-px bucket has 4096 and
 the CPU oracle's fp32 run at that size takes minutes per pass -- and B = 1: the host time of the oracle is what the GPU suite waits for.  The HIP step is compared with the CPU oracle in bf16 AND fp32; the residual
 stream is tapped after a few blocks so error growth with depth is measured, not assumed.  Criteria as everywhere
-(DESIGN.md section 2): rel_l2(hip, fp32) <= 1.3 rel_l2(oracle_bf16, fp32) + 1e-3 for taps, prediction and the concatenated
-gradient; the loss within 1.3 x the oracle's own bf16 distance (+ one bf16 ulp where the recipe evaluates the loss in bf16).
+(slack 1.3 -> 1.1 in round 6, measured ratios 0.99 .. 1.01): rel_l2(hip, fp32) <= 1.1 rel_l2(oracle_bf16, fp32)
++ 1e-3 for taps, prediction and the concatenated gradient; the loss within 1.1 x the oracle's own bf16 distance (+ one bf16 ulp
+where the recipe evaluates the loss in bf16); and rel_l2(hip, oracle_bf16) <= 1.1 x the oracle's own fp32 distance on every tap and
+the prediction (measured 0.41 .. 1.00 x: these models keep even more of the reference's rounding points than SANA).
 """
 import copy
 import time
@@ -54,19 +56,21 @@ def _flat_grads(hip, model):
 def _check(tag, l_h, l_b, l_t, taps_h, taps_b, taps_t, pred_h, pred_b, pred_t, g_h, g_b, g_t, loss_ulp):
     print(f"[parity] {tag}: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
     for i in sorted(taps_h):
-        e_h, e_b = rel(taps_h[i], taps_t[i]), rel(taps_b[i], taps_t[i])
+        e_h, e_b, e_hb = rel(taps_h[i], taps_t[i]), rel(taps_b[i], taps_t[i]), rel(taps_h[i], taps_b[i])
         print(f"[parity] {tag}: residual stream after block {i + 1:2d}: hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} "
-              f"hip_vs_oracle_bf16={rel(taps_h[i], taps_b[i]):.3e}")
-        assert e_h <= 1.3 * e_b + 1e-3, (i, e_h, e_b)
-    e_h, e_b = rel(pred_h, pred_t), rel(pred_b, pred_t)
-    print(f"[parity] {tag}: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={rel(pred_h, pred_b):.3e}")
-    assert e_h <= 1.3 * e_b + 1e-3
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + loss_ulp * abs(l_t)
+              f"hip_vs_oracle_bf16={e_hb:.3e}")
+        assert e_h <= 1.1 * e_b + 1e-3, (i, e_h, e_b)
+        assert e_hb <= 1.1 * e_b, (i, e_hb, e_b)
+    e_h, e_b, e_hb = rel(pred_h, pred_t), rel(pred_b, pred_t), rel(pred_h, pred_b)
+    print(f"[parity] {tag}: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={e_hb:.3e}")
+    assert e_h <= 1.1 * e_b + 1e-3
+    assert e_hb <= 1.1 * e_b, (e_hb, e_b)
+    assert abs(l_h - l_t) <= 1.1 * abs(l_b - l_t) + loss_ulp * abs(l_t)
     assert torch.isfinite(g_h).all()
     den = g_t.norm().item()
     tot_h, tot_b = (g_h - g_t).norm().item() / den, (g_b - g_t).norm().item() / den
     print(f"[parity] {tag}: grads ({g_t.numel() / 1e9:.2f} B, concatenated) hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.1 * tot_b + 1e-3
 
 
 # side = 128: the 1024 px training resolution itself (BASELINE config 3: 128 x 128 latents, N = 4096 tokens per image)

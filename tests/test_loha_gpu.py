@@ -85,10 +85,10 @@ def test_loha_training_step_matches_oracle():
     torch.cuda.synchronize()
     l32, lbf, lh = float(outs["fp32"][0]), float(outs["bf16"][0]), float(loss.detach())
     print(f"[parity] loha loss hip={lh:.6f} oracle_bf16={lbf:.6f} fp32={l32:.6f}")
-    assert abs(lh - l32) <= 1.3 * abs(lbf - l32) + 2e-3 * abs(l32)
+    assert abs(lh - l32) <= 1.15 * abs(lbf - l32) + 2e-3 * abs(l32)
     e_h, e_r = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
     print(f"[parity] loha pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
-    assert e_h <= 1.3 * e_r + 1e-3
+    assert e_h <= 1.15 * e_r + 1e-3
     hg, bg, fg = [], [], []
     for e in ad.entries:
         g1a, g1b, g2a, g2b = ad._views(e, ad.flat_grad)
@@ -101,7 +101,7 @@ def test_loha_training_step_matches_oracle():
     e_h, e_r = rel(hg, fg), rel(bg, fg)
     print(f"[parity] loha adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
     assert torch.isfinite(hg).all() and fg.abs().max() > 0
-    assert e_h <= 1.3 * e_r + 2e-3
+    assert e_h <= 1.15 * e_r + 2e-3
     before = hip.flat_param.clone()
     p0 = ad.flat_param.clone()
     FlatAdamW(ad, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0).step()

@@ -180,9 +180,12 @@ def test_lokr_forward_pair_matches_the_pre_add_path():
         assert torch.equal(a1.flat_grad, a2.flat_grad)
 
 
-@pytest.mark.parametrize("mode", ["factored", "dense"])
-def test_lokr_training_step_matches_oracle(mode):
-    """One adapted training step (tiny SANA, non-zero w1 so the adapters matter): loss / prediction / adapter gradients
+@pytest.mark.parametrize("mode,pair", [("factored", True), ("factored", False), ("dense", False)])
+def test_lokr_training_step_matches_oracle(mode, pair):
+    """(``pair``: the adapter term inside the base GEMM, rounded once -- the trainer's default -- or peft's own op order, base
+    output + adapter output each rounded, ``pre_add``: the form the reference computes; both are held to the oracle of the
+    peft wrap here, so the switch ``lora_fused_pair: false`` / ``YAT_ADAPTER_PAIR=0`` selects a pinned path.)
+    One adapted training step (tiny SANA, non-zero w1 so the adapters matter): loss / prediction / adapter gradients
     on the HIP path vs the oracle's bf16 and fp32 runs of the peft-wrapped model, then one clip+AdamW step.  Both
     applications of the adapters: factored (T1 = x' w2_b^T, P = kron(w1, w2_a); the tiny caption projection with in_n = 12
     falls back to dense inside it, and r = 2 exercises the rank padding) and dense (delta_w materialised, as peft does)."""
@@ -200,7 +203,8 @@ def test_lokr_training_step_matches_oracle(mode):
     kw = {k: getattr(rcfg, k) for k in SanaConfig.__dataclass_fields__}
     hip = SanaTransformer2DModelHIP(SanaConfig(**kw), device=DEV)
     hip.load_state_dict(ref_bf.state_dict())
-    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=0.0, mode=mode)
+    ad = LoKrAdapters(hip, TARGETS, r=2, alpha=4.0, module_dropout=0.0, mode=mode, pair=pair)
+    assert ad.pair == (pair and mode == "factored"), "the tiny widths admit the pair form (in_m r <= in for every target)"
     nf = sum(e["factored"] for e in ad.entries)
     assert (nf == 0) if mode == "dense" else (0 < nf < len(ad.entries))
     g = torch.Generator().manual_seed(7)
@@ -236,10 +240,10 @@ def test_lokr_training_step_matches_oracle(mode):
     torch.cuda.synchronize()
     l32, lbf, lh = float(outs["fp32"][0]), float(outs["bf16"][0]), float(loss.detach())
     print(f"[parity] lokr loss hip={lh:.6f} oracle_bf16={lbf:.6f} fp32={l32:.6f}")
-    assert abs(lh - l32) <= 1.3 * abs(lbf - l32) + 2e-3 * abs(l32)
+    assert abs(lh - l32) <= 1.15 * abs(lbf - l32) + 2e-3 * abs(l32)
     e_h, e_r = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
     print(f"[parity] lokr pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
-    assert e_h <= 1.3 * e_r + 1e-3
+    assert e_h <= 1.15 * e_r + 1e-3
     # adapter gradients, all targets together
     hip_g, bf_g, f_g = [], [], []
     for e in ad.entries:
@@ -254,7 +258,7 @@ def test_lokr_training_step_matches_oracle(mode):
     e_h, e_r = rel(hg, fg), rel(bg, fg)
     print(f"[parity] lokr adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
     assert torch.isfinite(hg).all() and fg.abs().max() > 0
-    assert e_h <= 1.3 * e_r + 2e-3
+    assert e_h <= 1.15 * e_r + 2e-3
     # one optimizer step over the adapter set only; the base weights do not move
     before = hip.flat_param.clone()
     opt = FlatAdamW(ad, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)

@@ -65,10 +65,10 @@ def test_lora_training_step_matches_oracle(r, alpha, tmp_path):
     torch.cuda.synchronize()
     l32, lbf, lh = float(outs["fp32"][0]), float(outs["bf16"][0]), float(loss.detach())
     print(f"[parity] lora r={r} loss hip={lh:.6f} oracle_bf16={lbf:.6f} fp32={l32:.6f}")
-    assert abs(lh - l32) <= 1.3 * abs(lbf - l32) + 2e-3 * abs(l32)
+    assert abs(lh - l32) <= 1.15 * abs(lbf - l32) + 2e-3 * abs(l32)
     e_h, e_r = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
     print(f"[parity] lora pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
-    assert e_h <= 1.3 * e_r + 1e-3
+    assert e_h <= 1.15 * e_r + 1e-3
     hip_g, bf_g, f_g = [], [], []
     for e in ad.entries:
         ga, gbt = ad._views(e, ad.flat_grad)
@@ -80,7 +80,7 @@ def test_lora_training_step_matches_oracle(r, alpha, tmp_path):
     e_h, e_r = rel(hg, fg), rel(bg, fg)
     print(f"[parity] lora adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
     assert torch.isfinite(hg).all() and fg.abs().max() > 0
-    assert e_h <= 1.3 * e_r + 2e-3
+    assert e_h <= 1.15 * e_r + 2e-3
     before = hip.flat_param.clone()
     opt = FlatAdamW(ad, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
     p0 = ad.flat_param.clone()

@@ -3,7 +3,7 @@ diffusers sub-modules are restated from recall; the recipe follows train_pixart_
 
 Tolerances: the glue kernels (patch gather/scatter, position table add, add_noise, bf16 MSE) are checked BIT-EXACT against
 torch on the CPU; the end-to-end step uses the same yardstick as the SANA tests -- as close to the fp32 truth as the
-reference's own bf16 arithmetic: rel_l2(hip, fp32) <= 1.3 * rel_l2(oracle_bf16, fp32) + 1e-3.
+reference's own bf16 arithmetic: rel_l2(hip, fp32) <= 1.15 * rel_l2(oracle_bf16, fp32) + 1e-3.
 """
 import copy
 
@@ -133,10 +133,10 @@ def test_step_matches_oracle(B, Hl, Wl, lens, pad_to, layers):
     assert loss.dtype == BF and out.shape == (B, 2 * latents.shape[1], Hl, Wl)
     l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
     print(f"[pixart] loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f} timesteps={ts.tolist()}")
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 2.0 ** -7 * abs(l_t)      # the loss itself is a bf16 number
+    assert abs(l_h - l_t) <= 1.15 * abs(l_b - l_t) + 2.0 ** -7 * abs(l_t)      # the loss itself is a bf16 number
     e_h, e_b, e_hb = rel(out, out_32), rel(out_bf, out_32), rel(out, out_bf)
     print(f"[pixart] out   hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={e_hb:.3e}")
-    assert e_h <= 1.3 * e_b + 1e-3
+    assert e_h <= 1.15 * e_b + 1e-3
 
     p32 = dict(ref_32.named_parameters())
     worst, num_h, num_b, den = [], 0.0, 0.0, 0.0
@@ -151,7 +151,7 @@ def test_step_matches_oracle(B, Hl, Wl, lens, pad_to, layers):
     print(f"[pixart] grads (all params) hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
     for eh, eb, name in sorted(worst, reverse=True)[:8]:
         print(f"[pixart]   {name}: hip={eh:.3e} oracle_bf16={eb:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.15 * tot_b + 1e-3
     for eh, eb, name in worst:
         if name.endswith("to_k.bias"):
             # softmax is invariant to a per-head constant added to every key score: the true gradient is exactly zero and
@@ -271,7 +271,7 @@ def test_pixart_lora_step_matches_oracle():
     torch.cuda.synchronize()
     e_h, e_r = rel(out, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
     print(f"[pixart] lora out hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
-    assert e_h <= 1.3 * e_r + 1e-3
+    assert e_h <= 1.15 * e_r + 1e-3
     hip_g, bf_g, f_g = [], [], []
     for e in ad.entries:
         ga, gbt = ad._views(e, ad.flat_grad)
@@ -281,7 +281,7 @@ def test_pixart_lora_step_matches_oracle():
     hg, bg, fg = torch.cat(hip_g), torch.cat(bf_g), torch.cat(f_g)
     e_h, e_r = rel(hg, fg), rel(bg, fg)
     print(f"[pixart] lora adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
-    assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.3 * e_r + 2e-3
+    assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.15 * e_r + 2e-3
     assert torch.equal(base, hip.flat_param)
 
 
@@ -316,8 +316,8 @@ def test_real_width_block_matches_oracle():
     l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
     e_h, e_b = rel(out, out_32), rel(out_bf, out_32)
     print(f"[pixart] real width: loss hip={l_h:.5f} oracle_bf16={l_b:.5f} fp32={l_t:.5f}; out hip={e_h:.3e} oracle_bf16={e_b:.3e}")
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 2.0 ** -7 * abs(l_t)
-    assert e_h <= 1.3 * e_b + 1e-3
+    assert abs(l_h - l_t) <= 1.15 * abs(l_b - l_t) + 2.0 ** -7 * abs(l_t)
+    assert e_h <= 1.15 * e_b + 1e-3
     p32 = dict(ref_32.named_parameters())
     num_h = num_b = den = 0.0
     for name, pb in ref_bf.named_parameters():
@@ -326,7 +326,7 @@ def test_real_width_block_matches_oracle():
         num_h += (gh - gt).pow(2).sum().item(); num_b += (gb - gt).pow(2).sum().item(); den += gt.pow(2).sum().item()
     tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
     print(f"[pixart] real width: grads hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.15 * tot_b + 1e-3
 
 
 def test_pixart_launch_plan_replay_is_bit_identical():
@@ -463,4 +463,4 @@ def test_pixart_validation_sampler_matches_oracle():
     e_hip, e_ref = rel(out, o_32), rel(o_bf, o_32)
     print(f"[parity] pixart sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
     assert torch.isfinite(out.float()).all() and out.shape == x0.shape
-    assert e_hip <= 1.3 * e_ref + 2e-3
+    assert e_hip <= 1.15 * e_ref + 2e-3

@@ -5,10 +5,10 @@ train_sana.py:21-22,39) and in fp32 (ground truth).  Stated tolerances:
 
 * loss: the north star asks for 1e-3 relative; the reference's own bf16 loss sits up to ~2e-3 from the fp32
   value of the same step, so the check is against the fp32 truth with the reference's own error as the yardstick:
-  |hip - fp32| <= 1.3 * |oracle_bf16 - fp32| + 1e-3 * |fp32|;
+  |hip - fp32| <= 1.1 * |oracle_bf16 - fp32| + 1e-3 * |fp32|   (1.3 until round 6);
 * predicted noise / gradients: bf16 tensors of two correct implementations differ by rounding noise,
   so the requirement is "as close to the fp32 truth as the reference's own bf16 arithmetic":
-  rel_l2(hip, fp32) <= 1.3 * rel_l2(oracle_bf16, fp32) + 1e-3, reported next to rel_l2(hip, oracle_bf16);
+  rel_l2(hip, fp32) <= 1.1 * rel_l2(oracle_bf16, fp32) + 1e-3, reported next to rel_l2(hip, oracle_bf16);
 * one clip+AdamW step: updated parameters within 1 bf16 ulp of torch's CPU optimizer on >= 99 % of
   elements (the optimizer kernel itself is bit-exact, see test_kernels_gpu; differences here come
   only from the rounding noise of the gradients that feed it).
@@ -71,10 +71,10 @@ def test_step_matches_oracle(B, h, w, lens, pad_to, layers, modified):
 
     l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
     print(f"[parity] loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 1e-3 * abs(l_t)
+    assert abs(l_h - l_t) <= 1.1 * abs(l_b - l_t) + 1e-3 * abs(l_t)
     e_h, e_b, e_hb = rel(pred, pred_32), rel(pred_bf, pred_32), rel(pred, pred_bf)
     print(f"[parity] pred  hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} hip_vs_oracle_bf16={e_hb:.3e}")
-    assert e_h <= 1.3 * e_b + 1e-3
+    assert e_h <= 1.1 * e_b + 1e-3
 
     # gradients, every parameter tensor
     p32 = dict(ref_32.named_parameters())
@@ -91,7 +91,7 @@ def test_step_matches_oracle(B, h, w, lens, pad_to, layers, modified):
     print(f"[parity] grads (all params) hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
     for eh, eb, name in sorted(worst, reverse=True)[:8]:
         print(f"[parity]   {name}: hip={eh:.3e} oracle_bf16={eb:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.1 * tot_b + 1e-3
     for eh, eb, name in worst:
         assert eh <= 2.0 * eb + 2e-2, (name, eh, eb)
 
@@ -197,7 +197,7 @@ def test_validation_sampler_matches_oracle():
     e_hip, e_ref = rel(out, o_32), rel(o_bf, o_32)
     print(f"[parity] sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
     assert torch.isfinite(out.float()).all() and out.shape == x0.shape
-    assert e_hip <= 1.3 * e_ref + 2e-3
+    assert e_hip <= 1.1 * e_ref + 2e-3
 
 
 def test_real_width_block_matches_oracle():
@@ -229,8 +229,8 @@ def test_real_width_block_matches_oracle():
     l_h, l_b, l_t = loss.item(), loss_bf.item(), loss_32.item()
     e_h, e_b = rel(pred, pred_32), rel(pred_bf, pred_32)
     print(f"[parity] real width: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} fp32={l_t:.6f}; pred hip={e_h:.3e} oracle_bf16={e_b:.3e}")
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 1e-3 * abs(l_t)
-    assert e_h <= 1.3 * e_b + 1e-3
+    assert abs(l_h - l_t) <= 1.1 * abs(l_b - l_t) + 1e-3 * abs(l_t)
+    assert e_h <= 1.1 * e_b + 1e-3
     p32 = dict(ref_32.named_parameters())
     num_h = num_b = den = 0.0
     for name, pb in ref_bf.named_parameters():
@@ -239,7 +239,7 @@ def test_real_width_block_matches_oracle():
         num_h += (gh - gt).pow(2).sum().item(); num_b += (gb - gt).pow(2).sum().item(); den += gt.pow(2).sum().item()
     tot_h, tot_b = (num_h / den) ** 0.5, (num_b / den) ** 0.5
     print(f"[parity] real width: grads hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.1 * tot_b + 1e-3
 
 
 def test_launch_plan_replay_is_bit_identical():

@@ -132,11 +132,11 @@ def _compare_step(rcfg, ref_bf, ref_32, hip, B, Hl, Wl, T, tag, seed=0, check_ad
     l_h, l_b, l_t = loss.item(), outs["bf16"][0], outs["fp32"][0]
     print(f"[parity] sd3 {tag}: loss hip={l_h:.6f} oracle_bf16={l_b:.6f} oracle_fp32={l_t:.6f}")
     # the loss itself is a bf16 number in this recipe (MSELoss evaluated in bf16): one bf16 ulp of slack
-    assert abs(l_h - l_t) <= 1.3 * abs(l_b - l_t) + 2 ** -7 * abs(l_t)
+    assert abs(l_h - l_t) <= 1.15 * abs(l_b - l_t) + 2 ** -7 * abs(l_t)
     e_h, e_b = rel(pred, outs["fp32"][1]), rel(outs["bf16"][1], outs["fp32"][1])
     print(f"[parity] sd3 {tag}: pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_b:.3e} "
           f"hip_vs_oracle_bf16={rel(pred, outs['bf16'][1]):.3e}")
-    assert e_h <= 1.3 * e_b + 1e-3
+    assert e_h <= 1.15 * e_b + 1e-3
     p32 = dict(ref_32.named_parameters())
     worst, num_h, num_b, den = [], 0.0, 0.0, 0.0
     for name, pb in ref_bf.named_parameters():
@@ -148,7 +148,7 @@ def _compare_step(rcfg, ref_bf, ref_32, hip, B, Hl, Wl, T, tag, seed=0, check_ad
     print(f"[parity] sd3 {tag}: grads (all params) hip_vs_fp32={tot_h:.3e} oracle_bf16_vs_fp32={tot_b:.3e}")
     for eh, eb, name in sorted(worst, reverse=True)[:6]:
         print(f"[parity]   {name}: hip={eh:.3e} oracle_bf16={eb:.3e}")
-    assert tot_h <= 1.3 * tot_b + 1e-3
+    assert tot_h <= 1.15 * tot_b + 1e-3
     for eh, eb, name in worst:
         assert eh <= 2.0 * eb + 2e-2, (name, eh, eb)
     if check_adamw:
@@ -198,7 +198,7 @@ def test_sd3_validation_sampler_matches_oracle():
     e_hip, e_ref = rel(out, o_32), rel(o_bf, o_32)
     print(f"[parity] sd3 sampler: hip_vs_fp32={e_hip:.3e} oracle_bf16_vs_fp32={e_ref:.3e} hip_vs_oracle_bf16={rel(out, o_bf):.3e}")
     assert torch.isfinite(out.float()).all() and out.shape == x0.shape
-    assert e_hip <= 1.3 * e_ref + 2e-3
+    assert e_hip <= 1.15 * e_ref + 2e-3
     # without guidance: one conditional pass per step, no negative branch
     out1 = sample_latents_sd3(hip, enc, pool, None, None, Hl, Wl, num_inference_steps=2, guidance_scale=1.0, latents=x0)
     assert torch.isfinite(out1.float()).all() and out1.shape == x0.shape
@@ -384,7 +384,7 @@ def test_sd3_adapter_step_matches_oracle(algo):
     torch.cuda.synchronize()
     e_h, e_r = rel(pred, outs["fp32"][0]), rel(outs["bf16"][0], outs["fp32"][0])
     print(f"[parity] sd3 {algo} pred hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e}")
-    assert e_h <= 1.3 * e_r + 1e-3
+    assert e_h <= 1.15 * e_r + 1e-3
     hg, bg, fg = [], [], []
     for e in ad.entries:
         views = ad._views(e, ad.flat_grad)
@@ -398,7 +398,7 @@ def test_sd3_adapter_step_matches_oracle(algo):
     hg, bg, fg = torch.cat(hg), torch.cat(bg), torch.cat(fg)
     e_h, e_r = rel(hg, fg), rel(bg, fg)
     print(f"[parity] sd3 {algo} adapter grads hip_vs_fp32={e_h:.3e} oracle_bf16_vs_fp32={e_r:.3e} (n={hg.numel()})")
-    assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.3 * e_r + 2e-3
+    assert torch.isfinite(hg).all() and fg.abs().max() > 0 and e_h <= 1.15 * e_r + 2e-3
     assert torch.equal(base, hip.flat_param)
 
 
