@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC passes (separate runs, counters only + kernel trace): SQ wave/wait/LDS/MFMA counters, then HBM FETCH_SIZE, then WRITE_SIZE.
+#   gpu_pmc.sh ["sq fetch write"] [SCRIPT ARGS...]      default target: the serialized bench (the launch mix of its roofline pass);
+#   another target, e.g. a micro-benchmark: gpu_pmc.sh "sq fetch write" scripts/dwconv_bench.py
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -7,7 +9,8 @@ export TMPDIR=/tmp
 # streams serialized, one forward chain: the launch mix of bench.py's roofline pass (which the per-launch traffic is quoted for)
 export YAT_SERIAL=1
 PASSES="${1:-sq fetch write}"
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timer"
+[ $# -gt 0 ] && shift
+ARGS="${*:-bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-timer}"
 run() { # name counters...
   name=$1; shift
   timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -o pmc -- python3 $ARGS > gpurun_out/pmc_$name.json 2> gpurun_out/pmc_$name.err

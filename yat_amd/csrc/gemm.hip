@@ -180,7 +180,7 @@ double est_time_256(int M, int N, int K, int BNv, int ksplit, int streams) {
     // for the launch alone.  More: the launch is charged its CU-time (tiles / 256 rounds) but at least 0.375 of the chip, so K
     // is still split until ~96 workgroups exist (a 25-tile K = 32768 weight gradient left unsplit is cheap in CU-time and
     // 0.75 ms long: the side stream becomes the critical path).  Measured in the step on one box, every bench
-    // (scripts/gpu_policy_sweep.sh): whole rounds -> this: SANA 88.3 -> 86.0 ms, PixArt 235 -> 232, LoKr B=32 354 -> 352;
+    // (git history: scripts/gpu_policy_sweep.sh; today scripts/gpu_ab.sh): whole rounds -> this: SANA 88.3 -> 86.0 ms, PixArt 235 -> 232, LoKr B=32 354 -> 352;
     // floor 0.25 loses PixArt (260), no floor loses LoKr (431) and PixArt (315); planning for a 128-CU share with whole
     // rounds of THAT (the obvious model) keeps half the gain (87.4).  YAT_GEMM_ROUND_W / _FLOOR: the sweep's knobs.
     static const double round_w = YAT_TUNE_F64("YAT_GEMM_ROUND_W", -1.0);

@@ -67,7 +67,7 @@ __device__ unsigned int yat_sdpa_wg_times[4096 * 6];
 // Wave priority by loop phase (s_setprio): raised while a wave issues its MFMA phases, dropped for its softmax.  Two workgroups
 // share a CU and their waves a SIMD at unrelated points of the same loop; with the priority the wave that has matrix work
 // gets the issue slots first and the partner's exponentials fill the gaps (and the s_setprio keeps the compiler from mixing
-// the phases).  Measured at N = T = 4096 (scripts/gpu_attn_libs.sh, profiles/r04_l_*): dK/dV kernel 1.43 -> 1.36 ms (dh 72) and
+// the phases).  Measured at N = T = 4096 (git history: scripts/gpu_attn_libs.sh; profiles/r04_l_*): dK/dV kernel 1.43 -> 1.36 ms (dh 72) and
 // 1.88 -> 1.80 ms (dh 64); forward 1.02 -> 0.98 ms at dh 64, level at dh 72; the dQ kernel 1 % slower with it -> not there.
 // The opposite assignment (softmax high) costs the forward 3..7 %.
 // A tie-break between the two waves of a SIMD (matrix phases at level 2 or 3 by the parity of the wave slot, HW_ID bit 0, so that
