@@ -317,6 +317,10 @@ def main():
                          "bandwidth; 0 = RCCL's default; -1 = the policy of yat_amd/ddp.py (RCCL's default unless "
                          "YAT_RCCL_CHANNELS asks for a cap; a site's own NCCL_*_NCHANNELS are never rewritten).  The value in "
                          "force is reported in the `comm` object")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1 (or YAT_DDP_FORCE=1): reduce-scatter the gradient buckets, AdamW on 1 / N of every bucket, all-gather "
+                         "the parameters under the next forward (yat_amd/ddp.py shard_optimizer; also YAT_SHARD_OPTIMIZER=1); "
+                         "bit-identical to the replicated step")
     ap.add_argument("--comm-steps", type=int, default=6, help="steps of each pass of the data-parallel diagnostics")
     ap.add_argument("--transport", choices=["torch", "native"], default=None,
                     help="gradient all-reduce transport of an N > 1 job (yat_amd/ddp.py): torch = torch.distributed's RCCL group "
@@ -404,7 +408,8 @@ def main():
         log(f"adapter arithmetic: {adapter_arithmetic(trained)}")
     opt = FlatAdamW(trained, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0,
                     overlap_update=os.environ.get("YAT_SERIAL", "0") == "0")
-    ddp = HipDDP(trained, force=force_ddp, coalesce=args.coalesce) if (world > 1 or force_ddp) else None
+    ddp = HipDDP(trained, force=force_ddp, coalesce=args.coalesce, shard_optimizer=True if args.shard_optimizer else None) \
+        if (world > 1 or force_ddp) else None
     # small consensus / timing scalars of the launcher-level group: host tensors when it is gloo (no device round trip)
     ctl_dev = dev if (world > 1 or force_ddp) and dist.is_initialized() and dist.get_backend() == "nccl" else torch.device("cpu")
 
@@ -622,6 +627,8 @@ def main():
                 "overlap_frac": (1.0 - min(1.0, exposed / comm_ms)) if comm_ms > 0 else None,
                 "rccl_channels": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")},
                 "coalesce": ddp.coalesce, "steps_per_pass": K,
+                "optimizer": ("sharded: reduce-scatter -> AdamW on 1 / %d of every bucket -> all-gather" % ddp.world) if ddp.shard is not None
+                else "replicated: all-reduce -> AdamW over every parameter on every rank",
                 "note": ("exposed = step - step with the collective switched off (same inputs, same hooks / events / streams); "
                          "overlap_frac = 1 - exposed / summed comm-stream time; optimizer_wait = how long the compute stream sat "
                          "in HipDDP.wait() before clip + AdamW" + ("; ONE rank: RCCL runs its one-rank copy kernel, the link "

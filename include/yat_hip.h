@@ -418,6 +418,19 @@ int yat_joint_rows(int B, int N, int T, int C, void* joint, int ld_joint, void* 
 uint64_t yat_gradnorm_workspace_bytes(int64_t n, int nseg);
 int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_start, float max_norm, float* norm_out,
                       float* clip_coef, void* workspace, yat_stream_t stream);
+/* The same norm over PIECES (round 6; what yat_amd/optim.py FlatAdamW calls): a piece is a whole tensor or the part of a
+ * tensor inside one eighth of its data-parallel bucket.  piece_start[npiece + 1]: element offsets (16-byte aligned, ascending);
+ * chunk_base[npiece + 1]: prefix sums of ceil(piece length / 2^18) -- partial[chunk_base[p] + c] receives the sum of squares of
+ * chunk c of piece p, or 0 when owned != NULL and owned[p] == 0; max_piece_chunks = the largest piece's chunk count.
+ * finish: tensor t = pieces [tensor_first_piece[t], tensor_first_piece[t + 1]); per-tensor sums in piece / chunk order, then
+ * torch's clip_grad_norm_ arithmetic as in yat_gradnorm_clip.  Partition invariance: a data-parallel rank that holds reduced
+ * gradients only for its shard of every bucket sums only its own pieces; the partial arrays of all ranks are added (each slot
+ * has one non-zero contributor, so the sum is exact) and finish yields the clip coefficient of the one-rank run bit for bit.
+ * replaces: the same torch.nn.utils.clip_grad_norm_ (common/trainer.py:347). */
+int yat_gradnorm_pieces_partial(const void* grad, int npiece, const int64_t* piece_start, const int* chunk_base,
+                                int max_piece_chunks, const unsigned char* owned, float* partial, yat_stream_t stream);
+int yat_gradnorm_pieces_finish(int ntensor, const int* tensor_first_piece, const int* chunk_base, const float* partial,
+                               float max_norm, float* norm_out, float* clip_coef, yat_stream_t stream);
 /* background: 0 = full-width launch (the update alone on the GPU); N > 0 = at most N workgroups of a 48-VGPR variant
  * that can share a CU with two resident GEMM waves -- for an update that runs under the next forward's GEMMs. */
 int yat_adamw_step(int64_t n, void* param, void* grad, void* exp_avg, void* exp_avg_sq, const float* clip_coef,
@@ -463,6 +476,13 @@ int yat_plan_replay(const yat_plan_entry* entries, int n, int* failed_index);
  *   yat_comm_allreduce : in-place all-reduce of `count` elements on `stream`, stream-ordered like any kernel; dtype 0 = bf16,
  *       1 = f32; op 0 = mean, 1 = sum.  For the bulk collectives outside the bucket schedule (the EMA mean over ranks before
  *       validation, common/trainer.py:374-377), so that they too use the library's one communicator
+ *   yat_bucket_reduce_scatter_async : as yat_bucket_allreduce_async, but a reduce-scatter(mean): rank r receives, in place,
+ *       the mean of bytes [r nbytes / world, (r + 1) nbytes / world) of the bucket; the other slices keep the rank's local
+ *       values.  nbytes must be a multiple of 16 * world.  With yat_comm_allgather this is the sharded optimizer step (SURVEY.md
+ *       section 5: reduce-scatter -> AdamW on 1 / world of every bucket -> all-gather; the same bytes on the wire as the
+ *       all-reduce); completion through yat_comm_wait like any bucket
+ *   yat_comm_allgather : in-place all-gather on `stream`: every rank contributes slice `rank` of the nbytes at ptr and
+ *       receives all of them (the updated parameters of a bucket); nbytes a multiple of 16 * world
  *   yat_comm_wait      : compute_stream waits (on the device; the host does not block) for bucket_id, or for every
  *       outstanding bucket when bucket_id < 0
  *   yat_comm_destroy   : releases the communicator and the events
@@ -477,6 +497,9 @@ int yat_comm_broadcast(void* ptr, uint64_t nbytes, int root, yat_stream_t stream
 int yat_bucket_allreduce_async(void* ptr, uint64_t nbytes, int bucket_id, yat_stream_t producer_stream,
                                yat_stream_t comm_stream);
 int yat_comm_allreduce(void* ptr, uint64_t count, int dtype, int op, yat_stream_t stream);
+int yat_bucket_reduce_scatter_async(void* ptr, uint64_t nbytes, int bucket_id, yat_stream_t producer_stream,
+                                    yat_stream_t comm_stream);
+int yat_comm_allgather(void* ptr, uint64_t nbytes, yat_stream_t stream);
 int yat_comm_wait(int bucket_id, yat_stream_t compute_stream);
 int yat_comm_destroy(void);
 const char* yat_comm_last_error(void);

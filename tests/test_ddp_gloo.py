@@ -183,6 +183,84 @@ def test_world2_gloo(tmp_path):
     mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
 
 
+def _shard_worker(rank, world, port, tmp):
+    """Sharded optimizer step (yat_amd/ddp.py shard_optimizer, yat_amd/optim.py _sharded_update) on the REAL model's flat layout,
+    CPU + gloo: what each collective leaves where, who owns which norm pieces, and that 'update the own slice, all-gather the
+    bucket' reproduces the replicated update on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pytest
+    from yat_amd.ddp import HipDDP
+    from yat_amd.optim import NORM_PARTS, norm_pieces
+    from yat_amd.sana import SanaConfig, SanaTransformer2DModelHIP
+    real = SanaTransformer2DModelHIP(SanaConfig(num_layers=3, num_attention_heads=2, num_cross_attention_heads=2,
+                                                cross_attention_head_dim=32, cross_attention_dim=64, caption_channels=96,
+                                                in_channels=8, out_channels=8, sample_size=4), device="cpu")
+    n = real.numel_flat
+    # the layout: every bucket a whole number of 8 x 16-byte parts (yat_amd/flat.py SHARD_ALIGN), tensors still 16-byte aligned
+    assert all((hi - lo) % 64 == 0 and hi > lo for lo, hi in real.bucket_bounds) and n % 64 == 0
+    assert all(int(o) % 8 == 0 for o in real.seg_start)
+    real.flat_param, real.flat_grad = real.flat_param.float(), real.flat_grad.float()       # (gloo has no bf16 reduction)
+    ddp = HipDDP(real, shard_optimizer=True)
+    assert real.shard is ddp.shard and (ddp.shard.rank, ddp.shard.world) == (rank, world) and real.loss_ready is None
+    local = torch.arange(n, dtype=torch.float32) * (rank + 1) + rank
+    for step in range(2):
+        real.flat_grad[:] = local
+        for i in (3, 2, 1, 0):
+            real.grad_ready(i)
+        ddp.wait()
+        mean = torch.arange(n, dtype=torch.float32) * 1.5 + 0.5
+        for lo, hi in real.bucket_bounds:
+            per = (hi - lo) // world
+            for r in range(world):
+                sl = slice(lo + r * per, lo + (r + 1) * per)
+                # own slice: the mean over ranks; every other slice: still this rank's local values (RCCL's in-place form)
+                assert torch.equal(real.flat_grad[sl], mean[sl] if r == rank else local[sl]), (step, lo, r)
+    assert ddp.bytes_reduced == 2 * n * 4
+    # norm pieces: never across an eighth of a bucket; the pieces a rank owns tile exactly its slices; all ranks together
+    # tile the whole buffer once
+    ps, tf, cb, mx, part = norm_pieces(real.seg_start.tolist(), real.bucket_bounds)
+    assert ps[0] == 0 and ps[-1] == n and all(b > a for a, b in zip(ps, ps[1:])) and tf[-1] == len(ps) - 1
+    per8 = NORM_PARTS // world
+    owned = torch.zeros(n, dtype=torch.int32)
+    for (a, b), (bi, k) in zip(zip(ps, ps[1:]), part):
+        lo, hi = real.bucket_bounds[bi]
+        e = (hi - lo) // NORM_PARTS
+        assert k >= 0 and lo + k * e <= a and b <= lo + (k + 1) * e, "a piece straddles an eighth of its bucket"
+        if rank * per8 <= k < (rank + 1) * per8:
+            owned[a:b] += 1
+    want = torch.zeros(n, dtype=torch.int32)
+    for lo, hi in real.bucket_bounds:
+        per = (hi - lo) // world
+        want[lo + rank * per:lo + (rank + 1) * per] = 1
+    assert torch.equal(owned, want)
+    both = [torch.zeros_like(owned) for _ in range(world)]
+    dist.all_gather(both, owned)
+    assert torch.all(both[0] + both[1] == 1)
+    # the update: every rank applies f to its slices only, the buckets are all-gathered -> f applied everywhere, on every rank
+    real.flat_param[:] = torch.arange(n, dtype=torch.float32)
+    f = lambda p, g_: p * 0.5 - g_                            # noqa: E731  (any elementwise update)
+    for lo, hi in real.bucket_bounds:
+        per = (hi - lo) // world
+        sl = slice(lo + rank * per, lo + (rank + 1) * per)
+        real.flat_param[sl] = f(real.flat_param[sl], real.flat_grad[sl])
+        ddp.allgather_bulk(real.flat_param[lo:hi])
+    assert torch.equal(real.flat_param, f(torch.arange(n, dtype=torch.float32), mean))
+    # what cannot be sharded says so: 3 ranks, ragged buckets, coalesced buckets
+    with pytest.raises(ValueError, match="not whole numbers"):
+        HipDDP(type("M", (), {"flat_param": torch.zeros(100), "flat_grad": torch.zeros(100), "bucket_bounds": [(0, 100)],
+                              "grad_ready": None})(), shard_optimizer=True)
+    with pytest.raises(ValueError, match="coalesce"):
+        HipDDP(real, shard_optimizer=True, coalesce=2)
+    # the default stays the replicated step, and rebuilding the wrapper takes the shard descriptor off the model again
+    assert HipDDP(real).shard is None and real.shard is None
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_sharded_optimizer_collectives(tmp_path):
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
 class _FakeCommLib:
     """The four entry points NativeComm's rendezvous touches; ``fail_on``: {rank: entry point that returns YAT_ENOCOMM}."""
 

@@ -511,7 +511,9 @@ class Model:
             opt = self.optimizer
             trained = opt.model                            # the transformer, or its adapter set
             trained.join_pending_update()                  # the overlapped AdamW/EMA update must have landed
-            if opt.ema_shadow is not None and self.accelerator.num_processes > 1:
+            if opt.ema_shadow is not None and opt.gather_ema():
+                pass        # sharded optimizer step: the ranks' slices of the (identical) shadow all-gathered instead of averaged
+            elif opt.ema_shadow is not None and self.accelerator.num_processes > 1:
                 # one flat all-reduce instead of ~600 per-tensor calls, through the transport the gradient buckets use (the
                 # library's communicator when it is the transport: the launcher group is then gloo and would stage 3 GB
                 # through the host)

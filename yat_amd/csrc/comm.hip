@@ -28,6 +28,8 @@ struct Api {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -77,6 +79,8 @@ int bind_rccl(Api& a) {
     YAT_BIND(CommDestroy, "ncclCommDestroy")
     YAT_BIND(AllReduce, "ncclAllReduce")
     YAT_BIND(Broadcast, "ncclBroadcast")
+    YAT_BIND(ReduceScatter, "ncclReduceScatter")
+    YAT_BIND(AllGather, "ncclAllGather")
     YAT_BIND(GetErrorString, "ncclGetErrorString")
 #undef YAT_BIND
     a.handle = h;
@@ -161,6 +165,38 @@ int yat_bucket_allreduce_async(void* ptr, uint64_t nbytes, int bucket_id, yat_st
     if (int rc = hip_rc(hipEventRecord(g.done[bucket_id], cs), "hipEventRecord")) return rc;
     g.pending[bucket_id] = true;
     return YAT_OK;
+}
+
+// Sharded optimizer step (yat_amd/ddp.py ``shard_optimizer``): the bucket's gradients are REDUCE-SCATTERED instead of
+// all-reduced -- rank r ends up with the mean of slice r of the bucket, in place (RCCL's in-place form: the receive buffer
+// is the rank's own slice of the send buffer; the other slices keep this rank's local values) -- and the updated parameters
+// come back by an in-place all-gather.  Same bytes on the wire as the all-reduce the pair replaces.
+int yat_bucket_reduce_scatter_async(void* ptr, uint64_t nbytes, int bucket_id, yat_stream_t producer_stream,
+                                    yat_stream_t comm_stream) {
+    if (!g.comm) return YAT_ENOCOMM;
+    if (!ptr || !nbytes || bucket_id < 0 || bucket_id >= MAX_BUCKETS || nbytes % ((uint64_t)16 * g.world)) return YAT_EINVAL;
+    hipStream_t prod = (hipStream_t)producer_stream, cs = (hipStream_t)comm_stream;
+    if (!g.done[bucket_id]) {
+        if (int rc = hip_rc(hipEventCreateWithFlags(&g.ready[bucket_id], hipEventDisableTiming), "hipEventCreate")) return rc;
+        if (int rc = hip_rc(hipEventCreateWithFlags(&g.done[bucket_id], hipEventDisableTiming), "hipEventCreate")) return rc;
+    }
+    if (prod != cs) {
+        if (int rc = hip_rc(hipEventRecord(g.ready[bucket_id], prod), "hipEventRecord")) return rc;
+        if (int rc = hip_rc(hipStreamWaitEvent(cs, g.ready[bucket_id], 0), "hipStreamWaitEvent")) return rc;
+    }
+    const uint64_t slice = nbytes / g.world;
+    if (int rc = nccl_rc(g.api.ReduceScatter(ptr, (char*)ptr + slice * g.rank, slice / 2, ncclBfloat16, ncclAvg, g.comm, cs),
+                         "ncclReduceScatter")) return rc;
+    if (int rc = hip_rc(hipEventRecord(g.done[bucket_id], cs), "hipEventRecord")) return rc;
+    g.pending[bucket_id] = true;
+    return YAT_OK;
+}
+
+int yat_comm_allgather(void* ptr, uint64_t nbytes, yat_stream_t stream) {
+    if (!g.comm) return YAT_ENOCOMM;
+    if (!ptr || !nbytes || nbytes % ((uint64_t)16 * g.world)) return YAT_EINVAL;
+    const uint64_t slice = nbytes / g.world;
+    return nccl_rc(g.api.AllGather((char*)ptr + slice * g.rank, ptr, slice, ncclUint8, g.comm, (hipStream_t)stream), "ncclAllGather");
 }
 
 int yat_comm_wait(int bucket_id, yat_stream_t compute_stream) {

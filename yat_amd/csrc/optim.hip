@@ -62,6 +62,68 @@ __global__ __launch_bounds__(256) void gradnorm_final_kernel(int nseg, const int
     }
 }
 
+// ---- the same norm over PIECES (round 6): a piece is a tensor, or the part of a tensor inside one eighth of its
+// data-parallel bucket; partial sums live compactly at chunk_base[piece] + chunk.  A tensor's sum of squares is the sum over its
+// pieces, in order, of the sum over each piece's chunks, in order -- the same numbers whoever computed each piece, which is
+// what lets N ranks each sum only the pieces they hold reduced gradients for (``owned``), add the arrays up (every slot has
+// exactly one non-zero contributor) and arrive at the clip coefficient of the one-rank run BIT FOR BIT.
+__global__ __launch_bounds__(256) void gradnorm_pieces_partial_kernel(const bf16_t* g, const int64_t* piece_start,
+                                                                      const int* chunk_base, const unsigned char* owned,
+                                                                      float* partial) {
+    const int pc = blockIdx.y, ck = blockIdx.x;
+    const int nck = chunk_base[pc + 1] - chunk_base[pc];
+    if (ck >= nck) return;
+    float* dst = partial + chunk_base[pc] + ck;
+    if (owned && !owned[pc]) {
+        if (threadIdx.x == 0) *dst = 0.f;
+        return;
+    }
+    const int64_t s1 = piece_start[pc + 1];
+    const int64_t c0 = piece_start[pc] + (int64_t)ck * NORM_CHUNK;
+    const int64_t c1 = (c0 + NORM_CHUNK < s1) ? c0 + NORM_CHUNK : s1;
+    float s = 0.f;
+    const int64_t nvec = (c1 - c0) >> 3;
+    for (int64_t i = threadIdx.x; i < nvec; i += 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(g + c0 + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+    }
+    for (int64_t i = c0 + (nvec << 3) + threadIdx.x; i < c1; i += 256) { const float v = bf2f(g[i]); s += v * v; }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void gradnorm_pieces_final_kernel(int ntensor, const int* tensor_first_piece,
+                                                                    const int* chunk_base, const float* partial,
+                                                                    float max_norm, float* norm_out, float* clip_coef) {
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < ntensor; t += 256) {
+        float s = 0.f;
+        for (int pc = tensor_first_piece[t]; pc < tensor_first_piece[t + 1]; ++pc) {
+            float sp = 0.f;
+            for (int c = chunk_base[pc]; c < chunk_base[pc + 1]; ++c) sp += partial[c];
+            s += sp;
+        }
+        const float nb = rbf(sqrtf(s));   // per-tensor norm comes back as a bf16 tensor
+        acc += nb * nb;
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = rbf(sqrtf(red[0] + red[1] + red[2] + red[3]));
+        float coef = rbf(max_norm / rbf(total + 1e-6f));
+        coef = fminf(coef, 1.0f);
+        norm_out[0] = total;
+        clip_coef[0] = coef;
+    }
+}
+
 struct AdamP {
     float wd_mul, w1, beta2, om_b2, bc2_sqrt, eps, neg_step_size, ema_omd;
     int use_wd, zero_grad;
@@ -192,6 +254,25 @@ int yat_gradnorm_clip(int64_t n, const void* grad, int nseg, const int64_t* seg_
     YAT_CHECK_LAUNCH();
     hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nseg, seg_start, mc,
                        (const float*)workspace, max_norm, norm_out, clip_coef);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_gradnorm_pieces_partial(const void* grad, int npiece, const int64_t* piece_start, const int* chunk_base,
+                                int max_piece_chunks, const unsigned char* owned, float* partial, yat_stream_t stream) {
+    if (!grad || npiece <= 0 || npiece > 65535 || !piece_start || !chunk_base || max_piece_chunks <= 0 || !partial)
+        return YAT_EINVAL;
+    hipLaunchKernelGGL(gradnorm_pieces_partial_kernel, dim3(max_piece_chunks, npiece), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)grad, piece_start, chunk_base, owned, partial);
+    YAT_CHECK_LAUNCH();
+    return YAT_OK;
+}
+
+int yat_gradnorm_pieces_finish(int ntensor, const int* tensor_first_piece, const int* chunk_base, const float* partial,
+                               float max_norm, float* norm_out, float* clip_coef, yat_stream_t stream) {
+    if (ntensor <= 0 || !tensor_first_piece || !chunk_base || !partial || !norm_out || !clip_coef) return YAT_EINVAL;
+    hipLaunchKernelGGL(gradnorm_pieces_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ntensor, tensor_first_piece,
+                       chunk_base, partial, max_norm, norm_out, clip_coef);
     YAT_CHECK_LAUNCH();
     return YAT_OK;
 }

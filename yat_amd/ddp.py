@@ -202,6 +202,19 @@ class NativeComm:
         self._l.check(self.lib.yat_comm_allreduce(t.data_ptr(), t.numel(), code, 0 if mean else 1, st.cuda_stream),
                       "yat_comm_allreduce")
 
+    def reduce_scatter_async(self, t, bucket_id, producer_stream, comm_stream):
+        """In-place reduce-scatter(mean) of a bucket: this rank's slice of ``t`` receives the mean (sharded optimizer step)."""
+        self._l.check(self.lib.yat_bucket_reduce_scatter_async(t.data_ptr(), t.numel() * t.element_size(), bucket_id,
+                                                               producer_stream.cuda_stream, comm_stream.cuda_stream),
+                      "yat_bucket_reduce_scatter_async")
+
+    def allgather(self, t, stream=None):
+        """In-place all-gather of a contiguous device tensor on ``stream`` (default: the current one): slice ``rank`` is sent."""
+        if not t.is_contiguous():
+            raise ValueError("NativeComm.allgather: contiguous tensors")
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self._l.check(self.lib.yat_comm_allgather(t.data_ptr(), t.numel() * t.element_size(), st.cuda_stream), "yat_comm_allgather")
+
     def wait(self, stream, bucket_id=-1):
         self._l.check(self.lib.yat_comm_wait(bucket_id, stream.cuda_stream), "yat_comm_wait")
 
@@ -215,9 +228,20 @@ class HipDDP:
     default of a multi-rank job (``default_transport``); "native" = the library's own communicator through the C ABI
     (``yat_comm_*``; opt-in with ``YAT_COMM=native``, the launcher-level group is then built over gloo:
     ``group_backend``).  Same buckets, same streams, same arithmetic (RCCL mean) either way.  ``allreduce_bulk`` sends any
-    other device tensor (the EMA mean before validation) through whichever transport the buckets use."""
+    other device tensor (the EMA mean before validation) through whichever transport the buckets use.
 
-    def __init__(self, model, process_group=None, average=True, force=False, transport=None, coalesce=1):
+    ``shard_optimizer`` (round 6; SURVEY.md section 5's design point; default: ``YAT_SHARD_OPTIMIZER=1``): every bucket is
+    REDUCE-SCATTERED instead of all-reduced -- rank r ends up with the mean of slice r of the bucket, the other slices keep its
+    local values -- ``FlatAdamW`` updates those slices only (1 / N of the 16 bytes per parameter the replicated update reads
+    and writes on every rank) and all-gathers each bucket's parameters in forward order under the next forward
+    (yat_amd/optim.py ``_sharded_update``); the clip norm is summed over pieces each rank owns and combined by one small
+    all-reduce.  Same bytes on the wire as the all-reduce, same reduced gradients in -> the same parameters out, bit for bit
+    (tests/test_ddp_gpu.py, tests/test_ddp_gloo.py).  Needs every bucket to be a whole number of N x 16-byte slices with
+    N in {1, 2, 4, 8}: the models' flat layouts are built for it (yat_amd/flat.py SHARD_ALIGN); an adapter set's single small
+    bucket usually is not, and has nothing to gain.  The step's logged loss then comes from the reference's own fp32
+    gather (no spare gradient element rides a reduce-scatter)."""
+
+    def __init__(self, model, process_group=None, average=True, force=False, transport=None, coalesce=1, shard_optimizer=None):
         self.model = model
         self.force = force            # run the collectives even in a one-rank group (single-GPU rehearsal of the N>1 path)
         self.pg = process_group
@@ -263,6 +287,24 @@ class HipDDP:
         # go out as one collective -- fewer, larger messages; 1 = one per transformer block (bench.py --coalesce)
         self.coalesce = max(1, int(coalesce))
         self._pending = None
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("YAT_SHARD_OPTIMIZER", "0") != "0"
+        self.shard = None
+        model.shard = None
+        if shard_optimizer and (self.world > 1 or force):
+            from types import SimpleNamespace
+            rank = dist.get_rank(self.pg) if (dist.is_initialized() and self.world > 1) else 0
+            if 8 % self.world:
+                raise ValueError(f"shard_optimizer: {self.world} ranks (1, 2, 4 or 8: a bucket is cut into eighths)")
+            bad = [i for i, (lo, hi) in enumerate(model.bucket_bounds) if (hi - lo) % 64 or hi <= lo]
+            if bad:
+                raise ValueError(f"shard_optimizer: buckets {bad[:4]} of this {type(model).__name__} are not whole numbers of "
+                                 f"8 x 16-byte parts; use the replicated optimizer step")
+            if self.coalesce > 1:
+                raise ValueError("shard_optimizer: buckets are scattered one by one (coalesce=1)")
+            if not average:
+                raise ValueError("shard_optimizer reduces to the mean (DDP semantics)")
+            self.shard = model.shard = SimpleNamespace(ddp=self, rank=rank, world=self.world)
         model.grad_ready = self.bucket_ready
         # The logged loss (``accelerator.gather(avg_loss).mean()``, common/trainer.py:359) without a collective of its own:
         # a caller that wants it calls ``track_loss(running sum)`` before the micro-step; the model reports the step's loss
@@ -270,7 +312,8 @@ class HipDDP:
         # and travels with the top bucket -- the first one the backward completes -- and ``wait()`` leaves the mean over
         # ranks in ``carried_loss``.  Without ``track_loss`` (bench.py) nothing of this runs.
         tail = getattr(model, "grad_tail", None)
-        self._tail = tail if (tail is not None and tail.numel() >= 2 and hasattr(model, "_grad_store")) else None
+        self._tail = tail if (tail is not None and tail.numel() >= 2 and hasattr(model, "_grad_store")
+                              and self.shard is None) else None
         self._loss_acc, self._track, self._tail_armed, self._tail_sent = None, False, False, False
         self._loss_offset = None             # previous step's carried mean (device scalar, the same on every rank)
         # which value train/loss shows under data parallel: the carried one (default: bf16 head + remainder of the difference
@@ -302,6 +345,32 @@ class HipDDP:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
             if mean:
                 t /= dist.get_world_size(self.pg)
+        return t
+
+    def allgather_bulk(self, t):
+        """In-place all-gather of a contiguous flat tensor whose slice ``rank`` (of ``world`` equal 16-byte-aligned slices) this
+        rank holds -- a bucket's updated parameters, or its EMA shadow -- stream-ordered on the CURRENT stream: the collective
+        starts after what that stream has enqueued and the stream continues after it."""
+        n = self.world
+        if t.numel() * t.element_size() % (16 * n) or not t.is_contiguous():
+            raise ValueError("allgather_bulk: a contiguous tensor of world x 16-byte slices")
+        if self.world == 1 and not self.force:
+            return t
+        if self.native is not None and t.is_cuda:
+            self.native.allgather(t)
+            return t
+        if not (dist.is_initialized() and dist.get_world_size(self.pg) >= 1):
+            return t
+        rank, per = dist.get_rank(self.pg), t.numel() // n
+        own = t[rank * per:(rank + 1) * per]
+        if t.is_cuda and dist.get_backend(self.pg) == "nccl":
+            dist.all_gather_into_tensor(t, own, group=self.pg, async_op=True).wait()     # (the current stream waits, not the host)
+        else:
+            parts = [torch.empty_like(own) for _ in range(n)]                            # gloo: CPU tests / one-GPU rehearsal
+            dist.all_gather(parts, own.clone(), group=self.pg)
+            for r_, part in enumerate(parts):
+                if r_ != rank:
+                    t[r_ * per:(r_ + 1) * per].copy_(part)
         return t
 
     def track_loss(self, running_sum=None):
@@ -350,6 +419,18 @@ class HipDDP:
         self.bytes_reduced += chunk.numel() * chunk.element_size()
         self.buckets_reduced += 1
         rccl = self.on_gpu and (self.native is not None or dist.get_backend(self.pg) == "nccl")
+        own = None
+        if self.shard is not None:                       # reduce-scatter: this rank's slice of the bucket receives the mean
+            per = (hi - lo) // self.shard.world
+            own = chunk[self.shard.rank * per:(self.shard.rank + 1) * per]
+
+        def scatter_over_gloo():
+            # gloo has no reduce-scatter: sum a COPY and keep the own slice only, so that -- as with RCCL's in-place form --
+            # every other slice of the bucket still holds this rank's local values (nothing may read them as reduced)
+            tmp = chunk.clone()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.pg)
+            mine = tmp[self.shard.rank * per:(self.shard.rank + 1) * per]
+            own.copy_(mine / self.world if self.average else mine)
         if self.dryrun and rccl and not self.timing and self.native is None:
             return                  # torch transport, collective off: its live form below touches no stream of ours either
         if self.on_gpu and (self.timing or (self.dryrun and rccl)):
@@ -367,10 +448,15 @@ class HipDDP:
                 if self.dryrun and rccl:
                     pass
                 elif self.native is not None:
-                    self.native.allreduce_async(chunk, i, self.comm_stream, self.comm_stream)    # (runs ON that stream)
+                    (self.native.allreduce_async if own is None else self.native.reduce_scatter_async)(
+                        chunk, i, self.comm_stream, self.comm_stream)                            # (runs ON that stream)
+                elif rccl and own is not None:
+                    dist.reduce_scatter_tensor(own, chunk, op=dist.ReduceOp.AVG, group=self.pg, async_op=True).wait()
                 elif rccl:
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM, group=self.pg,
                                     async_op=True).wait()          # the communication stream waits; the host does not
+                elif own is not None:
+                    scatter_over_gloo()
                 else:
                     dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
                     if self.average:
@@ -381,10 +467,21 @@ class HipDDP:
             return
         if self.native is not None:
             # event on the stream that finished the bucket -> all-reduce on the communication stream, all inside the library
-            self.native.allreduce_async(chunk, i, torch.cuda.current_stream(), self.comm_stream)
+            (self.native.allreduce_async if own is None else self.native.reduce_scatter_async)(
+                chunk, i, torch.cuda.current_stream(), self.comm_stream)
             return
         op = dist.ReduceOp.AVG if (self.average and rccl) else dist.ReduceOp.SUM
-        if rccl:
+        if own is not None and rccl:
+            self._works.append(dist.reduce_scatter_tensor(own, chunk, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+        elif own is not None and self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                scatter_over_gloo()
+        elif own is not None:
+            scatter_over_gloo()                          # (CPU multi-process tests: synchronous)
+        elif rccl:
             # torch's RCCL group runs every collective on a stream of its own and makes THAT stream wait for the stream the
             # call is issued from -- here the one that has just finished the bucket -- so no stream of ours sits in between.
             # (Through round 4 the call went out under ``comm_stream`` behind an event: one more stream for the runtime to

@@ -82,6 +82,7 @@ def _hip_stream(device, priority):
     return torch.cuda.ExternalStream(s.value, device=device)
 
 
+SHARD_ALIGN = 64     # elements: 8 parts x 16 bytes -- bucket starts of the flat layout (``_alloc_flat``)
 GRAD_TAIL = 8        # 16 bytes: the flat gradient buffer stays a whole number of 16-byte vectors
 
 
@@ -90,13 +91,22 @@ ARENA_INIT = None
 
 
 class FlatParamModule(nn.Module):
-    def _alloc_flat(self, specs, device):
-        """``specs``: [(diffusers key, shape)] in forward-execution order."""
+    def _alloc_flat(self, specs, device, bucket_first=None):
+        """``specs``: [(diffusers key, shape)] in forward-execution order.  ``bucket_first(key)`` -> True for the tensor a
+        data-parallel bucket starts with: those offsets and the total are multiples of SHARD_ALIGN elements, so that every
+        bucket splits into 8 equal 16-byte-aligned parts -- what a sharded optimizer step (reduce-scatter, AdamW on 1 / N of
+        every bucket, all-gather: yat_amd/ddp.py, yat_amd/optim.py) and the partition-invariant gradient norm
+        (``FlatAdamW.norm_pieces``) need for N in {1, 2, 4, 8}.  The padding (< 64 elements per bucket, zero parameters with zero
+        gradients) belongs to the tensor in front of it as far as the optimizer is concerned and to nobody otherwise."""
         self.dev = torch.device(device)
         offs, off = [], 0
-        for _, shape in specs:
+        for name, shape in specs:
+            if bucket_first is not None and bucket_first(name):
+                off = (off + SHARD_ALIGN - 1) // SHARD_ALIGN * SHARD_ALIGN
             offs.append(off)
             off += (math.prod(shape) + 7) // 8 * 8            # 16-byte aligned segment starts
+        if bucket_first is not None:
+            off = (off + SHARD_ALIGN - 1) // SHARD_ALIGN * SHARD_ALIGN
         self.numel_flat = off
         self.flat_param = torch.zeros(off, dtype=BF16, device=self.dev)
         # GRAD_TAIL spare elements behind the gradients: the data-parallel wrapper lets the step's loss ride in the first of them

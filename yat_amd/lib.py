@@ -106,6 +106,8 @@ SIGNATURES = {
     "yat_joint_rows": (I, [I, I, I, I, P, I, P, I, P, I, I, P]),
     "yat_gradnorm_workspace_bytes": (U64, [I64, I]),
     "yat_gradnorm_clip": (I, [I64, P, I, P, F, P, P, P, P]),
+    "yat_gradnorm_pieces_partial": (I, [P, I, P, P, I, P, P, P]),
+    "yat_gradnorm_pieces_finish": (I, [I, P, P, P, F, P, P, P]),
     "yat_adamw_step": (I, [I64, P, P, P, P, P, D, D, D, D, D, I, I, P, D, I, P]),
     "yat_plan_op_id": (I, [C.c_char_p]),
     "yat_plan_replay": (I, [C.POINTER(PlanEntry), I, C.POINTER(I)]),
@@ -117,6 +119,8 @@ SIGNATURES = {
     "yat_comm_broadcast": (I, [P, U64, I, P]),
     "yat_bucket_allreduce_async": (I, [P, U64, I, P, P]),
     "yat_comm_allreduce": (I, [P, U64, I, I, P]),
+    "yat_bucket_reduce_scatter_async": (I, [P, U64, I, P, P]),
+    "yat_comm_allgather": (I, [P, U64, P]),
     "yat_comm_wait": (I, [I, P]),
     "yat_comm_destroy": (I, []),
     "yat_comm_last_error": (C.c_char_p, []),

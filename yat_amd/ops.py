@@ -782,6 +782,20 @@ def gradnorm_clip(grad_flat, seg_start_i64, max_norm, norm_out, clip_coef, works
     _l.check(rc, "yat_gradnorm_clip")
 
 
+def gradnorm_pieces_partial(grad_flat, piece_start_i64, chunk_base_i32, max_piece_chunks, owned_u8, partial_f32):
+    """Sums of squares per (piece, 2^18-element chunk) into ``partial_f32[chunk_base[p] + c]``; pieces with ``owned_u8[p] == 0``
+    get zeros (``owned_u8`` None: all of them).  See include/yat_hip.h on partition invariance."""
+    rc = _lib().yat_gradnorm_pieces_partial(_p(grad_flat), piece_start_i64.numel() - 1, _p(piece_start_i64), _p(chunk_base_i32),
+                                            int(max_piece_chunks), _p(owned_u8), _p(partial_f32), _stream())
+    _l.check(rc, "yat_gradnorm_pieces_partial")
+
+
+def gradnorm_pieces_finish(tensor_first_piece_i32, chunk_base_i32, partial_f32, max_norm, norm_out, clip_coef):
+    rc = _lib().yat_gradnorm_pieces_finish(tensor_first_piece_i32.numel() - 1, _p(tensor_first_piece_i32), _p(chunk_base_i32),
+                                           _p(partial_f32), float(max_norm), _p(norm_out), _p(clip_coef), _stream())
+    _l.check(rc, "yat_gradnorm_pieces_finish")
+
+
 def adamw_step(param, grad, exp_avg, exp_avg_sq, clip_coef, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True,
                ema_shadow=None, ema_decay=0.0, background=0):
     rc = _lib().yat_adamw_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(clip_coef), lr, beta1,

@@ -140,7 +140,7 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         self.cfg = cfg
         self.config = SimpleNamespace(**asdict(cfg))
         specs = _param_specs(cfg)
-        offs, total = self._alloc_flat(specs, device)
+        offs, total = self._alloc_flat(specs, device, bucket_first=lambda k: k.startswith("transformer_blocks.") and k.split(".", 2)[2] == "scale_shift_table")
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers)
         # weight gradients / text branch on a 2nd stream; independent forward chains over image ranges: 241.9 -> 237.9 ms per
         # step with two (same box).  (GELU' in the ff.net.2 dgrad epilogue -- yat_gemm_epilogue.dact_z, 92 us less kernel
@@ -255,6 +255,9 @@ class PixArtTransformer2DModelHIP(FlatParamModule):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None
+        # the embedders / text branch below must not inherit the policy word's stream count from the previous call (1 in the
+        # very first step, the backward's value afterwards): yat_amd/sana.py forward_impl has the story
+        ops.gemm_concurrency(2 if self.side_wgrad else 1)
 
         def lin(x_, w_, bias_=None, out=None, **ep):
             """Linear of a (possibly adapted) target: the adapter term is folded in through the GEMM's pre_add epilogue."""

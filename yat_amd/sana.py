@@ -142,7 +142,7 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         self.cfg = cfg
         self.config = SimpleNamespace(**asdict(cfg))          # diffusers-style `.config.sample_size`
         specs = _param_specs(cfg)
-        offs, total = self._alloc_flat(specs, device)
+        offs, total = self._alloc_flat(specs, device, bucket_first=lambda k: k.startswith("transformer_blocks.") and k.split(".", 2)[2] == "scale_shift_table")
         # bucket boundaries for data parallel reduction: head | one per block (+tail on the last)
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers)
         # weight gradients on a second stream; independent forward chains over image ranges (flat.schedule: YAT_SERIAL=1
@@ -284,6 +284,13 @@ class SanaTransformer2DModelHIP(FlatParamModule):
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.side_wgrad else None
         pev, self.param_events = self.param_events, None      # per-bucket events of an AdamW update still in flight
+        # The policy word of every GEMM launch below carries "how many GEMM streams share the chip" (ops.gemm_concurrency:
+        # host state of yat_amd/ops.py).  The embedders and the text branch are launched before the chains set their own
+        # value: without this line they inherited whatever the previous call left -- 1 in the very first step, the backward's
+        # value in every later one -- so step 0 picked other tiles / split-K for three small GEMMs than steps 1.. (another fp32
+        # summation order: 1-ulp differences in the modulation tables; found by the run-to-run determinism test of round 6,
+        # tests/test_fulldepth_gpu.py).  Set to what every step but the first has always seen.
+        ops.gemm_concurrency(2 if self.side_wgrad else 1)
         ad = self.adapters
         if ad is not None:
             ad.materialize(self.training)                     # delta_w of every target for this step (yat_amd/lokr.py)

@@ -154,7 +154,7 @@ class SD3Transformer2DModelHIP(FlatParamModule):
         self.cfg = cfg
         self.config = SimpleNamespace(**asdict(cfg))
         specs = _param_specs(cfg)
-        offs, total = self._alloc_flat(specs, device)
+        offs, total = self._alloc_flat(specs, device, bucket_first=lambda k: k.startswith("transformer_blocks.") and k.split(".", 2)[2] == "norm1.linear.weight")
         self.bucket_bounds = self._block_buckets(specs, offs, total, cfg.num_layers, first_key="norm1.linear.weight")
         # weight gradients / modulation linears on a 2nd stream (flat.schedule)
         # (a third stream for the text tokens' own chain was measured in round 2 -- 405.0 vs 399.7 ms per step, no gain -- and
