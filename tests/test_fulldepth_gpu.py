@@ -174,7 +174,8 @@ def test_lokr_full_depth_step_matches_oracle(full_models):
     targets = ["conv_inverted", "conv_point", "to_q", "to_k", "to_v", "to_out.0", "linear_1", "linear_2", "proj"]
     ref_bf = copy.deepcopy(ref_shared)                   # the wrap replaces modules: not on the shared oracle
     cfg = ref_bf.cfg
-    ad = LoKrAdapters(hip, targets, r=8, alpha=8.0, module_dropout=0.0)
+    torch.manual_seed(4077)         # the adapters' own init (peft's kaiming_uniform_) draws from the global CPU RNG: without a seed
+    ad = LoKrAdapters(hip, targets, r=8, alpha=8.0, module_dropout=0.0)      # the numbers below depend on which tests ran before
     try:
         g = torch.Generator().manual_seed(77)
         for e in ad.entries:

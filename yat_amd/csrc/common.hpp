@@ -122,6 +122,20 @@ __device__ __forceinline__ void xcd_contiguous3(int& bx, int& by, int& bz) {
     bz = u / (gx * gy);
 }
 
+// The same for a grid (x = blocks of one (y, z) pair, y, z) whose per-pair work depends on z only (attention over ragged key
+// counts: x = query blocks, y = head, z = image): units ordered x fastest, then z, then y.  An XCD's contiguous run then
+// holds whole pairs (their x blocks read the same K / V: one L2 fetch instead of eight) AND every image about equally often
+// (total / 8 units = a few heads x ALL images), so ragged lengths do not pile up on one XCD as they do with z slowest.
+__device__ __forceinline__ void xcd_contiguous3_zfast(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    bx = u % gx;
+    bz = (u / gx) % gz;
+    by = u / (gx * gz);
+}
+
 // ---- MFMA 16x16x32 bf16 fragment loaders (wave64) -------------------------------------------
 // Operand register layout (both A and B): lane l holds index idx = l & 15 (row of A / col of B)
 // and k = 8*(l>>4) + j, j = 0..7.  Result: lane holds D[row = 4*(l>>4) + r][col = l & 15].

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(SdpaP p) {
     const int g = lane >> 4, li = lane & 15;
     // the query blocks of one (image, head) read the same K / V: give them to one XCD (one L2) instead of all eight
     int bx, h, b;
-    if (p.xcd_remap) xcd_contiguous3(bx, h, b);
+    if (p.xcd_remap == 2) xcd_contiguous3_zfast(bx, h, b);
+    else if (p.xcd_remap) xcd_contiguous3(bx, h, b);
     else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
     const int q0 = bx * (64 * QS) + wave * (16 * QS);
     const int kvl = (!NOBIAS && p.kv_len) ? p.kv_len[b] : 0;
@@ -481,7 +482,8 @@ __global__ __launch_bounds__(64 * NW) void sdpa_bwd_dq_kernel(SdpaP p) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, li = lane & 15;
     int bx, h, b;
-    if (p.xcd_remap) xcd_contiguous3(bx, h, b);
+    if (p.xcd_remap == 2) xcd_contiguous3_zfast(bx, h, b);
+    else if (p.xcd_remap) xcd_contiguous3(bx, h, b);
     else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
     const int q0 = bx * (16 * NW * QS) + wave * (16 * QS);               // QS 16-query sub-tiles per wave, as in the forward
     const int kvl = (!NOBIAS && p.kv_len) ? p.kv_len[b] : 0;
@@ -640,7 +642,12 @@ __global__ __launch_bounds__(64 * NW, (KS <= 3 && NW == 4) ? 2 : 1) void sdpa_bw
     // per idle workgroup, 230 us for the 70 % idle tiles of a T=512 / kv_len~160 batch), so the host hands a compact
     // (batch, key tile) list built from the embedding lengths it already knows; the dense grid remains as a fallback.
     int bx = blockIdx.x, h = blockIdx.y, bz = blockIdx.z;
-    if (p.xcd_remap && !p.work) xcd_contiguous3(bx, h, bz);         // key tiles of one (image, head) share Q / dO in one L2
+    // key tiles of one (image, head) share Q / dO in one L2.  With the compact work list (grid = (work items, heads)) every
+    // unit is ONE key tile -- equal work -- so contiguous runs are balanced whatever the lengths; units x fastest = the key
+    // tiles of one image, one head, side by side (round 6: the list path ran unmapped, the three tiles of an (image, head)
+    // on three XCDs, each fetching its own copy of Q and dO).  Dense grid: mode 2 = images fastest among the pairs (ragged).
+    if (p.xcd_remap == 2 && !p.work) xcd_contiguous3_zfast(bx, h, bz);
+    else if (p.xcd_remap) xcd_contiguous3(bx, h, bz);
     const int b = p.work ? p.work[2 * bx] : bz;
     const int tile = p.work ? p.work[2 * bx + 1] : bx;
     const int k0 = tile * KT + wave * (16 * KB);
@@ -993,6 +1000,10 @@ int sdpa_fwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
     p.q_bytes = (uint64_t)B * N * ldq * 2; p.kv_bytes = (uint64_t)kv_rows * ldkv * 2; p.bias_bytes = (uint64_t)B * T * 4;
     // XCD-contiguous order only for long uniform key loops (self-attention): with ragged kv_len the images with long
     // captions would pile up on one XCD (measured: T = 300 cross-attention 81 -> 104 us; N = T = 4096 1175 -> 1117 us)
+    // (round 6: mode 2 -- pairs ordered images-fastest, so that an XCD's run holds whole (image, head) pairs, one L2 copy of
+    // their K / V instead of eight, and every image about equally often -- measured on the SANA cross-attention, B = 8, ragged
+    // 20..300 keys: forward 44.9 -> 46.0 us, dQ 59.0 -> 63.9 us: the K / V copies were never what these kernels wait for.
+    // Not the default; reachable in tuning builds, YAT_SDPA_XCD=2.  profiles/r06_b_cross_attention_xcd_order.txt)
     static const int xcd_env = YAT_TUNE_INT("YAT_SDPA_XCD", -1);
     p.xcd_remap = xcd_env >= 0 ? xcd_env : (T >= 1024);
     // 128-query workgroups once there are enough of them to fill the chip twice over (PixArt-Sigma: N = 4096)
@@ -1044,7 +1055,14 @@ int sdpa_bwd_impl(int B, int N, int T, int H, int dh, float scale, const void* q
         if (rc != YAT_OK) return rc;
     }
     if (!(parts & 2)) return YAT_OK;
-    if (work_list && n_work > 0) { p.work = work_list; p.n_work = n_work; }
+    if (work_list && n_work > 0) {
+        p.work = work_list; p.n_work = n_work;
+        // the compact list's units are single key tiles (equal work): an XCD-contiguous order is balanced whatever the lengths and
+        // puts the key tiles of one (image, head) -- which read the same Q / dO -- on one L2: 67.3 -> 56.8 us on the ragged
+        // SANA batch (round 6, profiles/r06_b_cross_attention_xcd_order.txt; the list path ran unmapped before)
+        static const int xcd_work = YAT_TUNE_INT("YAT_SDPA_XCD_WORK", 1);
+        p.xcd_remap = xcd_work;
+    }
     // 128-key workgroups: dense grid only (the host's compact work list counts 64-key tiles)
     // dK/dV: 128-key workgroups of 4 waves x 32 keys (code 2) on the dense grid (the host's compact work list counts 64-key
     // tiles) while the head dim leaves the registers for two waves per SIMD (dh <= 80: 222 VGPRs once the query tile is
