@@ -754,6 +754,10 @@ def main():
                 with open(tj) as f:
                     tdat = json.load(f)
                 traffic, traffic_src = tdat["hbm_bytes_per_launch"], tdat["source"]
+                col = tdat.get("collected")
+                traffic_src = (f"{traffic_src} -- NOT measured in this run: collected {col['when']} on {col['where']}"
+                               + (f", tree {col['tree']}" if col.get("tree") else "")) if col else \
+                    f"{traffic_src} -- NOT measured in this run (separate rocprofv3 --pmc passes on a builder's box)"
             alg_bytes = sum(t[4] for t in timer if len(t) > 4) / max(1, sum(1 for t in timer if len(t) > 4))
             res["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel / gemm_bf16_kernel (NT/NN/TN, all epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

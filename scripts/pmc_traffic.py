@@ -23,6 +23,11 @@ out = {"kernel_family": "gemm256_kernel / gemm256_grouped_kernel / gemm_bf16_ker
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/gpu_pmc.sh, streams serialized: "
                  "YAT_SERIAL=1), KiB units, FETCH_SIZE doubled per the gfx950 "
                  "correction of MI355X_MICROARCH.md",
-       "source": sys.argv[1] if len(sys.argv) > 1 else "profiles/pmc_per_kernel.txt"}
+       "source": sys.argv[1] if len(sys.argv) > 1 else "profiles/pmc_per_kernel.txt",
+       # bench.py quotes this file in `roofline.traffic`: say where and when it was measured (round-5 review item 3)
+       "collected": {"when": __import__("datetime").datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
+                     "where": "a builder's one-GPU MI355X box (gpurun), NOT the run that prints the bench line: rocprofv3 --pmc "
+                              "passes cannot share a run with the timed region",
+                     "tree": (sys.argv[2] if len(sys.argv) > 2 else "")}}
 json.dump(out, open("profiles/gemm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
