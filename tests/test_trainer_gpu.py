@@ -297,3 +297,76 @@ def test_exploration_steps_keep_the_min_loss_draw(tmp_path, monkeypatch):
         train = calls[4 * s + 3]
         assert all(not g for g, _ in trial) and train[0]
         assert train[1] == min(l for _, l in trial), (trial, train)
+
+
+def _trainer_world2_worker(rank, world, port, tmp, shard):
+    """One rank of a two-rank trainer job on this one GPU (gloo: RCCL refuses two ranks on one device)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      YAT_DIST_BACKEND="gloo", YAT_SHARD_OPTIMIZER="1" if shard else "0", YAT_TENSORBOARD="0")
+    os.chdir(tmp)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.cuda.set_device(0)
+    from train_sana import SanaModel
+    from yat_amd.common.training_parameters_reader import TrainingParameters
+    from yat_amd.sana import SanaConfig
+    cfg = SanaConfig(num_layers=2, num_attention_heads=4, attention_head_dim=32, num_cross_attention_heads=2,
+                     cross_attention_head_dim=64, cross_attention_dim=128, caption_channels=96, in_channels=8, out_channels=8,
+                     sample_size=32)
+    params = TrainingParameters()
+    params.read_yaml(os.path.join(tmp, "config.yaml"))
+    torch.manual_seed(5)
+    import random
+    random.seed(5)
+    trainer = SanaModel(params, config=cfg)
+    trainer.run()
+    torch.cuda.synchronize()
+    ddp = trainer.accelerator.ddp
+    assert ddp is not None and (ddp.shard is not None) == shard and ddp.world == 2
+    opt = trainer.optimizer
+    opt.gather_ema()
+    torch.save(dict(param=trainer.model.flat_param.cpu(), ema=opt.ema_shadow.cpu(), losses=[float(x) for x in trainer.loss_history],
+                    norm=opt.grad_norm.cpu()), os.path.join(tmp, f"trainer_rank{rank}_{'shard' if shard else 'rep'}.pt"))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_trainer_world2_sharded_optimizer_equals_replicated(tmp_path):
+    """The whole trainer loop (common/trainer.py:298-403) as a two-rank job on one GPU, once with the replicated optimizer step
+    and once with YAT_SHARD_OPTIMIZER=1: gradient accumulation 2, warm-up, EMA, validation + checkpoint (the EMA shadow is
+    all-gathered instead of averaged), the logged loss through the reference's own gather.  Same shards, same draws -> the same
+    parameters and EMA shadow on both ranks, bit for bit, and the same logged losses (to the carried loss's own 2e-3)."""
+    import socket
+    import torch.multiprocessing as mp
+    from yat_amd.sana import SanaConfig
+    cfg = SanaConfig(num_layers=2, num_attention_heads=4, attention_head_dim=32, num_cross_attention_heads=2,
+                     cross_attention_head_dim=64, cross_attention_dim=128, caption_channels=96, in_channels=8, out_channels=8,
+                     sample_size=32)
+    paths = _write_shards(tmp_path, cfg)
+    (tmp_path / "config.yaml").write_text("\n".join([
+        "urls:", "  - unused", "local_shard_paths:", *[f"  - {p}" for p in paths], "num_shards: 2", "dataset_seed: 7",
+        "batch_size: 4", "learning_rate: 1e-3", "steps: 4", "num_steps_per_validation: 2", "validation_prompts:", "  - x",
+        "bfloat16: true", "gradient_accumulation_steps: 2", "warmup_steps: 2", "weight_decay: 0.01", "aspect_ratio: 1024",
+        "use_ema: true", "train_unconditional_prob: 0.0", ""]))
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(1, 12, cfg.caption_channels, generator=g).to(BF)
+    torch.save([(pe, torch.ones(1, 12, dtype=torch.long), torch.zeros(1, 12, cfg.caption_channels, dtype=BF),
+                 torch.cat([torch.ones(1, 1, dtype=torch.long), torch.zeros(1, 11, dtype=torch.long)], 1))],
+               tmp_path / "validation_embeds.pt")
+    out = {}
+    for shard in (False, True):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_trainer_world2_worker, args=(2, port, str(tmp_path), shard), nprocs=2, join=True)
+        out[shard] = [torch.load(tmp_path / f"trainer_rank{r}_{'shard' if shard else 'rep'}.pt") for r in (0, 1)]
+    rep, sh = out[False], out[True]
+    assert torch.equal(rep[0]["param"], rep[1]["param"]) and torch.isfinite(rep[0]["param"].float()).all()
+    for r in (0, 1):
+        assert torch.equal(sh[r]["param"], rep[0]["param"]), f"rank {r}: the sharded trainer's parameters differ"
+        assert torch.equal(sh[r]["ema"], rep[0]["ema"]) and torch.equal(sh[r]["norm"], rep[0]["norm"])
+        assert len(sh[r]["losses"]) == 4
+        for a, b in zip(sh[r]["losses"], rep[0]["losses"]):
+            assert abs(a - b) <= 2e-3 * abs(b), (sh[r]["losses"], rep[0]["losses"])
+    assert sorted(os.listdir(tmp_path / "models")), "no checkpoint written by the two-rank job"
