@@ -18,7 +18,7 @@ M, D, Hc, NP = 8048.0, 2240.0, 5600.0, 1.6045e9
 T = 1300.0            # packed text rows per batch (mean)
 BYTES = [            # (regex on the kernel name, algorithmic bytes per call, what is counted)
     (r"adamw_kernel", 14 * NP, "p, g, m, v read; p, m, v written (bf16): 14 B / parameter, one launch"),
-    (r"gradnorm_partial", 2 * NP, "g read"),
+    (r"gradnorm(_pieces)?_partial", 2 * NP, "g read"),
     (r"dwglu_(tile|stream)_kernel", 10 * M * Hc, "s read; u (kept for the backward) and y written"),
     (r"dwglu_bwd2", 12 * M * Hc, "du, z read; dz written (s = SiLU(z) is recomputed since round 5)"),
     (r"ln_mod_fwd", 4 * M * D, "x read, h written"),
