@@ -169,6 +169,10 @@ class LoRAAdapters:
         for j, (e, row0) in enumerate(ents):
             assert row0 == j * e0["out"]
             a, _ = self._views(e, self.flat_param)
+            # T is computed contiguous and copied into its slab columns (round-5 advisor: "write it straight into the slab"):
+            # the weight gradient d_B = scaling T^T dy reads T through yat_lokr_small_wgrad, whose first operand has no row
+            # stride -- an [M, 8] copy (0.5 MB at B = 32) is cheaper than a second T product.  Slots are fixed per target
+            # (plain LoRA never returns "plain"), so the columns R..63 of a slot stay the zeros the slab was created with.
             t = torch.empty(M, R, dtype=BF16, device=x.device)
             ops.gemm(self._dropped(e, x), a, t, M=M, N=R, K=K)                                # T = dropout(x) A^T
             a2[:, j * 64:j * 64 + R].copy_(t)
