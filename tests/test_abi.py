@@ -162,6 +162,37 @@ def test_comm_entry_points_without_a_communicator(built_lib):
     assert lib.yat_comm_init(0, 0, b"x" * 128) == -1 and lib.yat_comm_init(2, 2, b"x" * 128) == -1
     assert lib.yat_comm_init(0, 1, None) == -1 and lib.yat_comm_unique_id(None) == -1
     assert isinstance(lib.yat_comm_last_error(), bytes)
+    # round 6: the sharded optimizer step's two collectives
+    assert lib.yat_bucket_reduce_scatter_async(1, 128, 0, None, None) == -2
+    assert lib.yat_comm_allgather(1, 128, None) == -2
+
+
+def test_gradnorm_pieces_argument_checks(built_lib):
+    """The piece form of the clip norm (round 6, include/yat_hip.h): argument errors are refused before any launch -- no GPU
+    needed -- and the host-side piece table (yat_amd/optim.py norm_pieces) cuts tensors exactly at the eighths of their buckets."""
+    lib = ylib.load()
+    assert lib.yat_gradnorm_pieces_partial(None, 4, 1, 1, 1, None, 1, None) == -1            # no gradient buffer
+    assert lib.yat_gradnorm_pieces_partial(1, 0, 1, 1, 1, None, 1, None) == -1               # no pieces
+    assert lib.yat_gradnorm_pieces_partial(1, 70000, 1, 1, 1, None, 1, None) == -1           # more pieces than grid.y holds
+    assert lib.yat_gradnorm_pieces_partial(1, 4, 1, 1, 0, None, 1, None) == -1               # no chunk
+    assert lib.yat_gradnorm_pieces_partial(1, 4, 1, 1, 1, None, None, None) == -1            # no output
+    assert lib.yat_gradnorm_pieces_finish(0, 1, 1, 1, 1.0, 1, 1, None) == -1                 # no tensors
+    assert lib.yat_gradnorm_pieces_finish(3, 1, 1, 1, 1.0, None, 1, None) == -1              # no norm output
+    from yat_amd.optim import NORM_CHUNK, norm_pieces
+    seg = [0, 1000 * 64, 1000 * 64 + 8, 9000 * 64]                    # three tensors; the middle one is a bias of 8 elements
+    buckets = [(0, 1000 * 64), (1000 * 64, 9000 * 64)]
+    ps, tf, cb, mx, part = norm_pieces(seg, buckets)
+    assert ps[0] == 0 and ps[-1] == seg[-1] and all(b > a for a, b in zip(ps, ps[1:]))
+    assert tf == [0, 8, 9, len(ps) - 1]                                # tensor 0 = 8 pieces (it IS bucket 0), the bias 1, the rest of bucket 1
+    for bi, (lo, hi) in enumerate(buckets):
+        e = (hi - lo) // 8
+        assert all(lo + k * e in ps for k in range(8))                 # every eighth starts a piece
+    assert all(0 <= k < 8 for _, k in part)
+    assert cb[-1] == sum((b - a + NORM_CHUNK - 1) // NORM_CHUNK for a, b in zip(ps, ps[1:])) and mx == max(
+        (b - a + NORM_CHUNK - 1) // NORM_CHUNK for a, b in zip(ps, ps[1:]))
+    # a bucket that is not 8 x 16-byte parts is not cut (and cannot be sharded: part -1)
+    ps2, tf2, _, _, part2 = norm_pieces([0, 100, 200], [(0, 200)])
+    assert ps2 == [0, 100, 200] and tf2 == [0, 1, 2] and part2 == [(0, -1), (0, -1)]
 
 
 def test_integration_stub_matches_the_header():
