@@ -411,6 +411,8 @@ class Model:
         # with adapters only they are trained (the base has no gradients, so AdamW leaves it alone in the reference too)
         trained = self.adapters if self.adapters is not None else self.model
         self.optimizer = self.make_optimizer(trained)
+        if getattr(p, "shard_optimizer", False) and self.adapters is None:
+            os.environ.setdefault("YAT_SHARD_OPTIMIZER", "1")       # (HipDDP reads it; an adapter set keeps the replicated step)
         self.accelerator.prepare(trained)
         self.lr_scheduler = None
         if getattr(p, "warmup_steps", None) is not None:
